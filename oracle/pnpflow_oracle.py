@@ -1,0 +1,490 @@
+"""CPU oracle for the PnP-Flow restoration hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch CPU restatement (torch fp32 functional ops, no nn.Module,
+no reference import) of the algorithm on the path named by BASELINE.json's north_star:
+
+    PNP_FLOW.solve_ip  ->  Degradation.H / H_adj  ->  UNet.forward
+
+It is the *checker*: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+may import it.  The product path (pnpflow_amd/) never imports anything from oracle/ and
+fails loudly when the HIP extension is missing.
+
+Parity pinning: the oracle is pinned against golden vectors generated in the build
+container by importing the *real* reference from /root/reference (tools/make_golden.py;
+fixtures in tests/golden/*.npz) and against the reference's single known-answer test
+(pnpflow/tests/test_unit.py:14-20).  See tests/test_oracle_golden.py.
+
+Every function cites the reference file:line (relative to /root/reference) it restates.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------
+# U-Net velocity field  v_theta(x, t)            (pnpflow/models.py:24-495)
+# --------------------------------------------------------------------------------------
+
+def unet_config(input_channels: int, input_height: int, ch: int = 32,
+                ch_mult: Sequence[int] = (1, 2, 4, 8), num_res_blocks: int = 6,
+                attn_resolutions: Sequence[int] = (16, 8), output_channels: Optional[int] = None) -> dict:
+    """Hyper-parameter record of `UNet.__init__` (pnpflow/models.py:302-334).
+
+    `define_model` (pnpflow/utils.py:170-180) uses ch=32, ch_mult=(1,2,4,8), 6 blocks,
+    attention at resolutions (16, 8)."""
+    assert input_height % 2 ** (len(ch_mult) - 1) == 0  # models.py:334-335
+    return dict(input_channels=input_channels, input_height=input_height, ch=ch,
+                ch_mult=tuple(ch_mult), num_res_blocks=num_res_blocks,
+                attn_resolutions=tuple(attn_resolutions),
+                output_channels=input_channels if output_channels is None else output_channels)
+
+
+def swish(x: torch.Tensor) -> torch.Tensor:
+    """pnpflow/models.py:24-30 : sigmoid(x) * x."""
+    return torch.sigmoid(x) * x
+
+
+def group_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """pnpflow/models.py:33-38 : GroupNorm(32 groups, eps 1e-6, affine)."""
+    return F.group_norm(x, 32, w, b, eps=1e-6)
+
+
+def sinusoidal_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """pnpflow/models.py:253-279.  t is used raw (in [0,1)), not scaled by 999
+    (pnpflow/methods/pnp_flow.py:21)."""
+    half = dim // 2
+    freq = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1)))
+    e = t.to(torch.float32)[:, None] * freq[None, :]
+    e = torch.cat([torch.sin(e), torch.cos(e)], dim=1)
+    if dim % 2 == 1:
+        e = F.pad(e, (0, 1))
+    return e
+
+
+def timestep_embedding(sd: Dict[str, torch.Tensor], t: torch.Tensor, ch: int) -> torch.Tensor:
+    """pnpflow/models.py:282-299 : Linear(ch->4ch) . Swish . Linear(4ch->4ch)."""
+    e = sinusoidal_embedding(t, ch)
+    e = F.linear(e, sd["temb_net.main.0.weight"], sd["temb_net.main.0.bias"])
+    e = swish(e)
+    return F.linear(e, sd["temb_net.main.2.weight"], sd["temb_net.main.2.bias"])
+
+
+def residual_block(sd, p: str, x: torch.Tensor, temb: torch.Tensor) -> torch.Tensor:
+    """pnpflow/models.py:94-113."""
+    h = swish(group_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"]))
+    h = F.conv2d(h, sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1)
+    h = h + F.linear(swish(temb), sd[p + "temb_proj.weight"], sd[p + "temb_proj.bias"])[:, :, None, None]
+    h = swish(group_norm(h, sd[p + "norm2.weight"], sd[p + "norm2.bias"]))
+    h = F.conv2d(h, sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1)
+    if (p + "shortcut.weight") in sd:  # 1x1 conv when in_ch != out_ch (models.py:85-92)
+        x = F.conv2d(x, sd[p + "shortcut.weight"], sd[p + "shortcut.bias"])
+    return x + h
+
+
+def self_attention(sd, p: str, x: torch.Tensor) -> torch.Tensor:
+    """pnpflow/models.py:145-162 : single head, softmax over keys, scale C^-0.5."""
+    B, C, H, W = x.shape
+    h = group_norm(x, sd[p + "norm.weight"], sd[p + "norm.bias"])
+    q = F.conv2d(h, sd[p + "attn_q.weight"], sd[p + "attn_q.bias"]).view(B, C, H * W)
+    k = F.conv2d(h, sd[p + "attn_k.weight"], sd[p + "attn_k.bias"]).view(B, C, H * W)
+    v = F.conv2d(h, sd[p + "attn_v.weight"], sd[p + "attn_v.bias"]).view(B, C, H * W)
+    attn = torch.bmm(q.permute(0, 2, 1), k) * (int(C) ** (-0.5))
+    attn = torch.softmax(attn, dim=-1)
+    h = torch.bmm(v, attn.permute(0, 2, 1)).view(B, C, H, W)
+    h = F.conv2d(h, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"])
+    return x + h
+
+
+def unet_forward(sd: Dict[str, torch.Tensor], cfg: dict, x: torch.Tensor, t: torch.Tensor,
+                 taps: Optional[dict] = None) -> torch.Tensor:
+    """pnpflow/models.py:442-495.  `taps`, if given, receives named intermediates
+    (used to localise a parity failure to one block)."""
+    nres, nlev = cfg["num_res_blocks"], len(cfg["ch_mult"])
+    attn_res = cfg["attn_resolutions"]
+    temb = timestep_embedding(sd, t, cfg["ch"])
+    if taps is not None:
+        taps["temb"] = temb
+    hs: List[torch.Tensor] = [F.conv2d(x, sd["begin_conv.weight"], sd["begin_conv.bias"], padding=1)]
+    for lvl in range(nlev):
+        for blk in range(nres):
+            p = f"down_modules.{lvl}.{lvl}a_{blk}a_block."
+            h = residual_block(sd, p, hs[-1], temb)
+            if h.shape[2] in attn_res:
+                h = self_attention(sd, f"down_modules.{lvl}.{lvl}a_{blk}b_attn.", h)
+            hs.append(h)
+            if taps is not None:
+                taps[f"down{lvl}_{blk}"] = h
+        if lvl != nlev - 1:
+            p = f"down_modules.{lvl}.{lvl}b_downsample."
+            hs.append(F.conv2d(hs[-1], sd[p + "weight"], sd[p + "bias"], stride=2, padding=1))
+            if taps is not None:
+                taps[f"downsample{lvl}"] = hs[-1]
+    h = hs[-1]
+    h = residual_block(sd, "mid_modules.0.", h, temb)
+    h = self_attention(sd, "mid_modules.1.", h)
+    h = residual_block(sd, "mid_modules.2.", h, temb)
+    if taps is not None:
+        taps["mid"] = h
+    for idx, lvl in enumerate(reversed(range(nlev))):
+        for blk in range(nres + 1):
+            p = f"up_modules.{idx}.{lvl}a_{blk}a_block."
+            h = residual_block(sd, p, torch.cat([h, hs.pop()], dim=1), temb)
+            if h.shape[2] in attn_res:
+                h = self_attention(sd, f"up_modules.{idx}.{lvl}a_{blk}b_attn.", h)
+            if taps is not None:
+                taps[f"up{lvl}_{blk}"] = h
+        if lvl != 0:
+            p = f"up_modules.{idx}.{lvl}b_upsample.up_conv."
+            h = F.interpolate(h, scale_factor=2, mode="nearest")  # models.py:41-47
+            h = F.conv2d(h, sd[p + "weight"], sd[p + "bias"], padding=1)
+            if taps is not None:
+                taps[f"upsample{lvl}"] = h
+    assert not hs
+    h = swish(group_norm(h, sd["end_conv.0.weight"], sd["end_conv.0.bias"]))
+    return F.conv2d(h, sd["end_conv.2.weight"], sd["end_conv.2.bias"], padding=1)
+
+
+def unet_param_shapes(cfg: dict) -> Dict[str, tuple]:
+    """Names and shapes of the state_dict of `UNet` (pnpflow/models.py:337-436),
+    derived from the hyper-parameters only.  Order = module registration order."""
+    ch, mult, nres = cfg["ch"], cfg["ch_mult"], cfg["num_res_blocks"]
+    nlev, attn_res = len(mult), cfg["attn_resolutions"]
+    cin, cout_img, ht = cfg["input_channels"], cfg["output_channels"], cfg["input_height"]
+    tch = 4 * ch
+    shp: Dict[str, tuple] = {}
+
+    def lin(p, i, o):
+        shp[p + "weight"] = (o, i); shp[p + "bias"] = (o,)
+
+    def conv(p, i, o, k):
+        shp[p + "weight"] = (o, i, k, k); shp[p + "bias"] = (o,)
+
+    def gn(p, c):
+        shp[p + "weight"] = (c,); shp[p + "bias"] = (c,)
+
+    def res(p, i, o):
+        lin(p + "temb_proj.", tch, o); gn(p + "norm1.", i); conv(p + "conv1.", i, o, 3)
+        gn(p + "norm2.", o); conv(p + "conv2.", o, o, 3)
+        if i != o:
+            conv(p + "shortcut.", i, o, 1)
+
+    def attn(p, c):
+        for n in ("attn_q.", "attn_k.", "attn_v.", "proj_out."):
+            conv(p + n, c, c, 1)
+        gn(p + "norm.", c)
+
+    lin("temb_net.main.0.", ch, tch); lin("temb_net.main.2.", tch, tch)
+    conv("begin_conv.", cin, ch, 3)
+    chans, c, h = [ch], ch, ht
+    for lvl in range(nlev):
+        o = ch * mult[lvl]
+        for blk in range(nres):
+            res(f"down_modules.{lvl}.{lvl}a_{blk}a_block.", c, o)
+            if h in attn_res:
+                attn(f"down_modules.{lvl}.{lvl}a_{blk}b_attn.", o)
+            chans.append(o); c = o
+        if lvl != nlev - 1:
+            conv(f"down_modules.{lvl}.{lvl}b_downsample.", o, o, 3)
+            h //= 2; chans.append(o)
+    res("mid_modules.0.", c, c); attn("mid_modules.1.", c); res("mid_modules.2.", c, c)
+    for idx, lvl in enumerate(reversed(range(nlev))):
+        o = ch * mult[lvl]
+        for blk in range(nres + 1):
+            res(f"up_modules.{idx}.{lvl}a_{blk}a_block.", c + chans.pop(), o)
+            if h in attn_res:
+                attn(f"up_modules.{idx}.{lvl}a_{blk}b_attn.", o)
+            c = o
+        if lvl != 0:
+            conv(f"up_modules.{idx}.{lvl}b_upsample.up_conv.", o, o, 3)
+            h *= 2
+    assert not chans
+    gn("end_conv.0.", c); conv("end_conv.2.", c, cout_img, 3)
+    return shp
+
+
+def synthetic_state_dict(cfg: dict, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seed-fixed synthetic weights (no checkpoint is reachable offline).
+
+    NOT the reference initialiser (which leaves conv2/proj_out/end_conv at gain 1e-10,
+    models.py:84,131-137,432, so half the net would be untested): every tensor is drawn
+    from its own numpy Philox stream keyed by (seed, name-hash) so the recipe is
+    reproducible anywhere without torch RNG:  weights ~ U(-a, a), a = sqrt(3/fan_in);
+    GN gamma ~ 1 + 0.1 U(-1,1); biases/GN beta ~ 0.05 U(-1,1)."""
+    import zlib
+    sd = {}
+    for name, shape in unet_param_shapes(cfg).items():
+        rng = np.random.Generator(np.random.Philox(key=[seed, zlib.crc32(name.encode())]))
+        u = rng.uniform(-1.0, 1.0, size=shape).astype(np.float32)
+        if name.endswith("weight") and len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            u *= np.float32(math.sqrt(3.0 / fan_in))
+        elif name.endswith("weight"):
+            u = np.float32(1.0) + np.float32(0.1) * u
+        else:
+            u *= np.float32(0.05)
+        sd[name] = torch.from_numpy(u)
+    return sd
+
+
+# --------------------------------------------------------------------------------------
+# Degradation operators H / H_adj                (pnpflow/degradations.py:6-127)
+# --------------------------------------------------------------------------------------
+
+def square_mask(x: torch.Tensor, half: int) -> torch.Tensor:
+    """pnpflow/utils.py:327-336 (d = x.shape[2]//2 is used for BOTH axes)."""
+    d = x.shape[2] // 2
+    m = torch.ones_like(x)
+    m[:, :, d - half:d + half, d - half:d + half] = 0
+    return m * x
+
+
+def random_mask_array(B: int, H: int, W: int, p: float) -> np.ndarray:
+    """pnpflow/utils.py:357-359 : np.random.seed(42); binomial(1, 1-p, (B,H,W)) int64.
+    (Uses a private RandomState -- identical stream, without clobbering the global one.)"""
+    return np.random.RandomState(42).binomial(n=1, p=1 - p, size=(B, H, W))
+
+
+def random_mask(x: torch.Tensor, p: float) -> torch.Tensor:
+    """pnpflow/utils.py:353-361."""
+    m = torch.from_numpy(random_mask_array(x.shape[0], x.shape[2], x.shape[3], p))
+    return m.unsqueeze(1) * x
+
+
+def gaussian_2d_kernel(sigma: float, size: int) -> torch.Tensor:
+    """pnpflow/utils.py:273-280."""
+    ax = torch.arange(-size // 2 + 1.0, size // 2 + 1.0)
+    xx, yy = torch.meshgrid(ax, ax, indexing="ij")
+    k = torch.exp(-(xx ** 2 + yy ** 2) / (2 * sigma ** 2))
+    return k / k.sum()
+
+
+def gaussian_1d_taps(sigma: float, size: int) -> np.ndarray:
+    """Separable factor of `gaussian_2d_kernel`: k2d = outer(g, g) with
+    g = exp(-x^2/2s^2)/sum (exact up to fp32 rounding). float64."""
+    ax = np.arange(-size // 2 + 1.0, size // 2 + 1.0)
+    g = np.exp(-(ax ** 2) / (2 * sigma ** 2))
+    return g / g.sum()
+
+
+class Degradation:
+    """pnpflow/degradations.py:6-12."""
+    def H(self, x):
+        raise NotImplementedError()
+
+    def H_adj(self, x):
+        raise NotImplementedError()
+
+
+class Denoising(Degradation):
+    """pnpflow/degradations.py:15-20."""
+    def H(self, x):
+        return x
+
+    def H_adj(self, x):
+        return x
+
+
+class BoxInpainting(Degradation):
+    """pnpflow/degradations.py:23-32."""
+    def __init__(self, half_size_mask):
+        self.half_size_mask = half_size_mask
+
+    def H(self, x):
+        return square_mask(x, self.half_size_mask)
+
+    H_adj = H
+
+
+class RandomInpainting(Degradation):
+    """pnpflow/degradations.py:35-44."""
+    def __init__(self, p):
+        self.p = p
+
+    def H(self, x):
+        return random_mask(x, self.p)
+
+    H_adj = H
+
+
+class GaussianDeblurring(Degradation):
+    """pnpflow/degradations.py:55-89, mode 'fft' : circular convolution via FFT."""
+    def __init__(self, sigma_blur, kernel_size, mode="fft", num_channels=3, dim_image=128, device="cpu"):
+        assert mode == "fft"
+        self.sigma, self.kernel_size = sigma_blur, kernel_size
+        self.kernel = gaussian_2d_kernel(sigma_blur, kernel_size)
+        f = torch.zeros((1, num_channels, dim_image, dim_image))
+        f[..., :kernel_size, :kernel_size] = self.kernel
+        s = -(kernel_size - 1) // 2
+        self.filter = torch.roll(f, shifts=(s, s), dims=(2, 3))
+
+    def H(self, x):
+        return torch.real(torch.fft.ifft2(torch.fft.fft2(x) * torch.fft.fft2(self.filter)))
+
+    def H_adj(self, x):
+        return torch.real(torch.fft.ifft2(torch.fft.fft2(x) * torch.conj(torch.fft.fft2(self.filter))))
+
+
+class Superresolution(Degradation):
+    """pnpflow/degradations.py:92-127 with mode=None (the only one main.py:165 uses):
+    H = x[..., ::sf, ::sf] (utils.py:302-310); H_adj = zero-fill (utils.py:283-299).
+    The dense downsampling matrix (degradations.py:110-111) is only read by ot_ode."""
+    def __init__(self, sf, dim_image, mode=None, device="cpu"):
+        assert mode is None
+        self.sf = sf
+
+    def H(self, x):
+        return x[..., ::self.sf, ::self.sf]
+
+    def H_adj(self, x):
+        z = torch.zeros((x.shape[0], x.shape[1], x.shape[2] * self.sf, x.shape[3] * self.sf), dtype=x.dtype)
+        z[..., ::self.sf, ::self.sf] = x
+        return z
+
+
+def make_degradation(problem: str, dim_image: int, num_channels: int = 3, noise_type: str = "gaussian"):
+    """Problem table of main.py:120-179  ->  (degradation, sigma_noise)."""
+    lap = noise_type == "laplace"
+    if problem == "denoising":
+        return Denoising(), (0.3 if lap else 0.2)
+    if problem == "inpainting":
+        half = {128: 20, 256: 40}[dim_image]
+        return BoxInpainting(half), (0.3 if lap else 0.05)
+    if problem == "random_inpainting":
+        return RandomInpainting(0.7), (0.3 if lap else 0.01)
+    if problem == "superresolution":
+        sf = {128: 2, 256: 4}[dim_image]
+        return Superresolution(sf, dim_image), (0.3 if lap else 0.05)
+    if problem == "gaussian_deblurring_FFT":
+        sb = {128: 1.0, 256: 3.0}[dim_image]
+        return GaussianDeblurring(sb, 61, "fft", num_channels, dim_image), (0.3 if lap else 0.05)
+    raise ValueError(problem)
+
+
+# --------------------------------------------------------------------------------------
+# PnP-Flow solver                                 (pnpflow/methods/pnp_flow.py:10-188)
+# --------------------------------------------------------------------------------------
+
+def learning_rate_strat(lr: float, t: torch.Tensor, gamma_style: str, alpha: float) -> torch.Tensor:
+    """pnpflow/methods/pnp_flow.py:29-37."""
+    t = t.view(-1, 1, 1, 1)
+    if gamma_style == "1_minus_t":
+        return lr * (1 - t)
+    if gamma_style == "sqrt_1_minus_t":
+        return lr * torch.sqrt(1 - t)
+    if gamma_style == "alpha_1_minus_t":
+        return lr * (1 - t) ** alpha
+    return lr * torch.ones_like(t)  # 'constant' and unknown styles
+
+
+def pnp_flow_restore(model: Callable, degradation: Degradation, noisy_img: torch.Tensor, sigma_noise: float, *,
+                     steps: int, num_samples: int, lr_pnp: float = 1.0, gamma_style: str = "alpha_1_minus_t",
+                     alpha: float = 1.0, noise_fn: Optional[Callable] = None,
+                     record: Optional[Callable] = None) -> torch.Tensor:
+    """Inner loop of PNP_FLOW.solve_ip for one batch, gaussian noise
+    (pnpflow/methods/pnp_flow.py:60-62, 93, 102-121).
+
+    model(x, t)->v;  noise_fn(iteration, sample, like)->eps replaces torch.randn_like
+    (pnp_flow.py:48) so that trajectories are comparable across devices;  record(it, x)
+    is called after each outer iteration."""
+    H, H_adj = degradation.H, degradation.H_adj
+    lr = sigma_noise ** 2 * lr_pnp                                   # :60-62
+    delta = 1.0 / steps
+    x = H_adj(torch.ones_like(noisy_img))                            # :93
+    if noise_fn is None:
+        noise_fn = lambda it, s, like: torch.randn_like(like)
+    with torch.no_grad():
+        for it in range(int(steps)):
+            t1 = torch.ones(len(x)) * delta * it                     # :107-108
+            lr_t = learning_rate_strat(lr, t1, gamma_style, alpha)   # :109
+            z = x - lr_t * (H_adj(H(x) - noisy_img) / sigma_noise ** 2)   # :111-112, :39-41
+            x_new = torch.zeros_like(x)
+            tv = t1.view(-1, 1, 1, 1)
+            for s in range(num_samples):                             # :114-118
+                z_tilde = tv * z + noise_fn(it, s, z) * (1 - tv)     # :47-48
+                x_new += z_tilde + (1 - tv) * model(z_tilde, t1)     # :50-52
+            x_new /= num_samples                                     # :120
+            x = x_new
+            if record is not None:
+                record(it, x)
+    return x
+
+
+def make_measurement(clean: torch.Tensor, degradation: Degradation, sigma_noise: float, batch: int,
+                     noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pnpflow/methods/pnp_flow.py:77-80 : y = H(clean) + sigma * randn (seed = batch index).
+    `noise` overrides the draw (multi-GPU shards slice one global draw)."""
+    y = degradation.H(clean.clone())
+    if noise is None:
+        torch.manual_seed(batch)
+        noise = torch.randn_like(y)
+    return y + noise * sigma_noise
+
+
+# --------------------------------------------------------------------------------------
+# Metric                                           (pnpflow/utils.py:560-577, 594-625)
+# --------------------------------------------------------------------------------------
+
+def postprocess(img: torch.Tensor) -> torch.Tensor:
+    """pnpflow/utils.py:560-577 for model in {ot,...}: (img+1)/2, no clamp.
+    (The non-afhq branch is Normalize(mean=-1, std=2) == (x+1)/2 as well.)"""
+    return (img + 1) / 2
+
+
+def psnr_per_image(rec: torch.Tensor, clean: torch.Tensor) -> torch.Tensor:
+    """torchmetrics peak_signal_noise_ratio(data_range=1.0, dim=(1,2,3), reduction=None)
+    restated (torchmetrics is absent offline; its published formula):
+    10*log10(data_range^2 / mean_{c,h,w}((a-b)^2)) per image (pnpflow/utils.py:610)."""
+    a, b = postprocess(rec), postprocess(clean)
+    mse = ((a - b) ** 2).flatten(1).mean(1)
+    return 10.0 * torch.log10(1.0 / mse)
+
+
+def psnr_batch(rec: torch.Tensor, clean: torch.Tensor) -> float:
+    """torchmetrics default reduction 'elementwise_mean' over the per-image values."""
+    return float(psnr_per_image(rec, clean).mean())
+
+
+# --------------------------------------------------------------------------------------
+# Engine RNG restatement (build-defined; no reference counterpart: the reference draws
+# torch.randn_like on the device generator, pnp_flow.py:48, which is not reproducible
+# across devices).  Philox4x32-10 + Box-Muller exactly as csrc/pointwise.hip does it.
+# --------------------------------------------------------------------------------------
+
+_PH_M0, _PH_M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_PH_W0, _PH_W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
+
+
+def philox4x32_10(ctr: np.ndarray, key: np.ndarray) -> np.ndarray:
+    """ctr: (n,4) uint32, key: (2,) uint32 -> (n,4) uint32 (Salmon et al. 2011)."""
+    c = ctr.astype(np.uint32).copy()
+    k0, k1 = np.uint32(key[0]), np.uint32(key[1])
+    for _ in range(10):
+        p0 = _PH_M0 * c[:, 0].astype(np.uint64)
+        p1 = _PH_M1 * c[:, 2].astype(np.uint64)
+        hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), p0.astype(np.uint32)
+        hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), p1.astype(np.uint32)
+        c = np.stack([hi1 ^ c[:, 1] ^ k0, lo1, hi0 ^ c[:, 3] ^ k1, lo0], axis=1)
+        with np.errstate(over="ignore"):
+            k0 = np.uint32(k0 + _PH_W0); k1 = np.uint32(k1 + _PH_W1)
+    return c
+
+
+def engine_normal(n: int, seed: int, stream: int) -> np.ndarray:
+    """n standard normals: element 4q+j comes from Philox counter (q, 0, stream_lo, stream_hi),
+    key (seed_lo, seed_hi); u = (r + 0.5) * 2^-32; Box-Muller pairs (0,1) and (2,3):
+    z0 = sqrt(-2 ln u0) cos(2 pi u1), z1 = sqrt(-2 ln u0) sin(2 pi u1)."""
+    nq = (n + 3) // 4
+    ctr = np.zeros((nq, 4), dtype=np.uint32)
+    ctr[:, 0] = np.arange(nq, dtype=np.uint64).astype(np.uint32)
+    ctr[:, 2] = np.uint32(stream & 0xFFFFFFFF); ctr[:, 3] = np.uint32((stream >> 32) & 0xFFFFFFFF)
+    r = philox4x32_10(ctr, np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32))
+    u = (r.astype(np.float64) + 0.5) * (2.0 ** -32)
+    rad0, rad1 = np.sqrt(-2.0 * np.log(u[:, 0])), np.sqrt(-2.0 * np.log(u[:, 2]))
+    a0, a1 = 2.0 * np.pi * u[:, 1], 2.0 * np.pi * u[:, 3]
+    z = np.stack([rad0 * np.cos(a0), rad0 * np.sin(a0), rad1 * np.cos(a1), rad1 * np.sin(a1)], axis=1)
+    return z.reshape(-1)[:n].astype(np.float32)

@@ -1,0 +1,52 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def det_normal(shape, seed, idx=0):
+    """Same deterministic-input recipe as tools/make_golden.py (numpy Philox)."""
+    g = np.random.Generator(np.random.Philox(key=[seed, idx]))
+    return torch.from_numpy(g.standard_normal(size=shape, dtype=np.float32))
+
+
+def det_image(shape, seed):
+    """Same synthetic clean-image recipe as tools/make_golden.py."""
+    x = det_normal(shape, seed, 7)
+    k = torch.ones(shape[1], 1, 3, 3) / 9.0
+    for _ in range(5):
+        x = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (1, 1, 1, 1), mode="replicate"), k, groups=shape[1])
+    lo = x.amin(dim=(1, 2, 3), keepdim=True); hi = x.amax(dim=(1, 2, 3), keepdim=True)
+    return ((x - lo) / (hi - lo) * 2 - 1).contiguous()
+
+
+def checksums(t):
+    d = t.double()
+    return np.array([d.sum().item(), d.abs().sum().item(), (d * d).sum().item()], dtype=np.float64)
+
+
+CFGS = {
+    "mnist": dict(input_channels=1, input_height=28, ch=32, ch_mult=(1, 2), num_res_blocks=2, attn_resolutions=(16,)),
+    "tiny4": dict(input_channels=3, input_height=64, ch=32, ch_mult=(1, 2, 4, 8), num_res_blocks=1, attn_resolutions=(16, 8)),
+    "celeba128": dict(input_channels=3, input_height=128, ch=32, ch_mult=(1, 2, 4, 8), num_res_blocks=6, attn_resolutions=(16, 8)),
+    "afhq256": dict(input_channels=3, input_height=256, ch=32, ch_mult=(1, 2, 4, 8), num_res_blocks=6, attn_resolutions=(16, 8)),
+}
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name + ".npz"))
+    return load

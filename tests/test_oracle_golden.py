@@ -1,0 +1,146 @@
+"""Pins oracle/ against golden vectors produced by the REAL reference (tools/make_golden.py)
+and against the reference's own known-answer test.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import CFGS, checksums, det_image, det_normal
+from oracle import pnpflow_oracle as O
+
+
+@pytest.mark.parametrize("name,B", [("mnist", 3), ("tiny4", 2), ("celeba128", 1), ("afhq256", 1)])
+def test_unet_forward_matches_reference(golden, name, B):
+    g = golden("unet_" + name)
+    cfg = O.unet_config(**CFGS[name])
+    sd = O.synthetic_state_dict(cfg, 0)
+    assert sum(v.numel() for v in sd.values()) == int(g["nparams"])
+    shape = tuple(int(v) for v in g["shape"])
+    x = det_normal(shape, 11)
+    t = torch.from_numpy(g["t"])
+    taps = {}
+    with torch.no_grad():
+        out = O.unet_forward(sd, cfg, x, t, taps)
+    if "out" in g:
+        np.testing.assert_allclose(out.numpy(), g["out"], rtol=0, atol=2e-5)
+    else:
+        H = shape[2]
+        np.testing.assert_allclose(out[:, :, H // 2 - 16:H // 2 + 16, H // 2 - 16:H // 2 + 16].numpy(), g["out_crop"], rtol=0, atol=5e-5)
+        np.testing.assert_allclose(out[:, :, :8, :8].numpy(), g["out_corner"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(checksums(out), g["out_checksum"], rtol=1e-5)
+    np.testing.assert_allclose(checksums(taps["temb"]), g["tap_temb"], rtol=1e-5)
+    np.testing.assert_allclose(checksums(taps["mid"]), g["tap_mid2"], rtol=1e-5)
+
+
+def test_param_counts_match_survey():
+    # 128^2 net 34 473 667 params, 256^2 net 31 045 827, MNIST net 917 889
+    n = lambda name: sum(int(np.prod(s)) for s in O.unet_param_shapes(O.unet_config(**CFGS[name])).values())
+    assert n("celeba128") == 34473667
+    assert n("afhq256") == 31045827
+    assert n("mnist") == 917889
+
+
+def test_reference_known_answer_box_mask():
+    # pnpflow/tests/test_unit.py:14-20
+    y = O.BoxInpainting(32).H(torch.ones(1, 3, 128, 128))
+    torch.testing.assert_close(y[:, :, 32:64, 32:64], torch.zeros(1, 3, 32, 32))
+    assert y[:, :, :32].min() == 1 and y[:, :, 96:].min() == 1
+
+
+def test_degradations_match_reference(golden):
+    g = golden("degradations")
+    x64 = det_normal((2, 3, 64, 64), 21)
+    for half in (10, 20):
+        d = O.BoxInpainting(half)
+        np.testing.assert_array_equal(d.H(x64).numpy(), g[f"box{half}_H"])
+        np.testing.assert_array_equal(d.H_adj(x64).numpy(), g[f"box{half}_Hadj"])
+    m128 = O.BoxInpainting(20).H(torch.ones(1, 1, 128, 128))[0, 0]
+    z = (m128.sum(1) < 128).nonzero()
+    assert [int(z.min()), int(z.max())] == list(g["box20_mask128_rows"]) == [44, 83]
+    m256 = O.BoxInpainting(40).H(torch.ones(1, 1, 256, 256))[0, 0]
+    z = (m256.sum(1) < 256).nonzero()
+    assert [int(z.min()), int(z.max())] == list(g["box40_mask256_rows"])
+    np.testing.assert_array_equal(O.RandomInpainting(0.7).H(x64).numpy(), g["rand_H"])
+    m = O.random_mask_array(4, 128, 128, 0.7).astype(np.uint8)
+    np.testing.assert_array_equal(np.packbits(m.reshape(-1)), g["randmask_B4_128_bits"])
+    for (B, S) in ((4, 128), (32, 128), (16, 256)):
+        m = O.random_mask_array(B, S, S, 0.7).astype(np.uint8)
+        np.testing.assert_array_equal(m.reshape(B, -1).sum(1), g[f"randmask_B{B}_{S}_rowsum"])
+        np.testing.assert_array_equal(m.reshape(B, -1)[:, :64], g[f"randmask_B{B}_{S}_first64"])
+    # prefix consistency in B: shards slice one global mask
+    np.testing.assert_array_equal(O.random_mask_array(32, 128, 128, 0.7)[:4], O.random_mask_array(4, 128, 128, 0.7))
+    for sf in (2, 4):
+        d = O.Superresolution(sf, 64)
+        y = d.H(x64).contiguous()
+        np.testing.assert_array_equal(y.numpy(), g[f"sr{sf}_H"])
+        np.testing.assert_array_equal(d.H_adj(y).numpy(), g[f"sr{sf}_Hadj"])
+    for sig in (1.0, 3.0):
+        d = O.GaussianDeblurring(sig, 61, "fft", 3, 64)
+        np.testing.assert_allclose(d.H(x64).numpy(), g[f"blur{sig}_H"], atol=1e-6)
+        np.testing.assert_allclose(d.H_adj(x64).numpy(), g[f"blur{sig}_Hadj"], atol=1e-6)
+    x128 = det_normal((1, 3, 128, 128), 22)
+    d = O.GaussianDeblurring(1.0, 61, "fft", 3, 128)
+    np.testing.assert_allclose(d.H(x128)[:, :, :16, :16].numpy(), g["blur1.0_128_H_crop"], atol=1e-6)
+    x256 = det_normal((1, 3, 256, 256), 23)
+    d = O.GaussianDeblurring(3.0, 61, "fft", 3, 256)
+    np.testing.assert_allclose(d.H(x256)[:, :, :16, :16].numpy(), g["blur3.0_256_H_crop"], atol=1e-6)
+    np.testing.assert_allclose(d.H_adj(x256)[:, :, 120:136, 120:136].numpy(), g["blur3.0_256_Hadj_crop"], atol=1e-6)
+    np.testing.assert_allclose(O.gaussian_2d_kernel(1.0, 61)[25:36, 25:36].numpy(), g["gauss2d_1.0_61_center"], atol=1e-9)
+    # separable factorisation used by the HIP blur kernel
+    for sig in (1.0, 3.0):
+        g1 = O.gaussian_1d_taps(sig, 61)
+        np.testing.assert_allclose(np.outer(g1, g1), O.gaussian_2d_kernel(sig, 61).numpy(), atol=1e-7)
+
+
+def test_adjoint_identity():
+    x = det_normal((2, 3, 64, 64), 5)
+    for d, yshape in ((O.BoxInpainting(10), (2, 3, 64, 64)), (O.RandomInpainting(0.7), (2, 3, 64, 64)),
+                      (O.Superresolution(2, 64), (2, 3, 32, 32)), (O.GaussianDeblurring(3.0, 61, "fft", 3, 64), (2, 3, 64, 64))):
+        y = det_normal(yshape, 6)
+        a = (d.H(x).double() * y.double()).sum(); b = (x.double() * d.H_adj(y).double()).sum()
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a))
+
+
+TRAJ = [("mnist_denoising", "mnist", lambda S: (O.Denoising(), 0.2)),
+        ("tiny4_inpainting", "tiny4", lambda S: (O.BoxInpainting(10), 0.05)),
+        ("tiny4_superresolution", "tiny4", lambda S: (O.Superresolution(2, S), 0.05)),
+        ("tiny4_deblurring", "tiny4", lambda S: (O.GaussianDeblurring(1.0, 61, "fft", 3, S), 0.05)),
+        ("tiny4_random_inpainting", "tiny4", lambda S: (O.RandomInpainting(0.7), 0.01))]
+
+
+@pytest.mark.parametrize("tag,net,mk", TRAJ)
+def test_pnp_flow_trajectory_matches_reference(golden, tag, net, mk):
+    g = golden("pnp_traj_" + tag)
+    cfg = O.unet_config(**CFGS[net])
+    sd = O.synthetic_state_dict(cfg, 0)
+    S, C = cfg["input_height"], cfg["input_channels"]
+    degradation, sigma = mk(S)
+    assert sigma == float(g["sigma"])
+    steps, ns = int(g["steps"]), int(g["num_samples"])
+    clean = det_image((2, C, S, S), 31)
+    y = O.make_measurement(clean, degradation, sigma, batch=0, noise=det_normal(tuple(degradation.H(clean).shape), 41, 0))
+    np.testing.assert_allclose(y.numpy(), g["noisy"], atol=1e-6)
+    its = {}
+    x = O.pnp_flow_restore(lambda a, t: O.unet_forward(sd, cfg, a, t), degradation, y, sigma, steps=steps, num_samples=ns,
+                           alpha=float(g["alpha"]), noise_fn=lambda it, s, like: det_normal(tuple(like.shape), 41, 1 + it * ns + s),
+                           record=lambda it, xx: its.__setitem__(it, xx.clone()))
+    for it in (0, 1, 4, 9):
+        np.testing.assert_allclose(its[it].numpy(), g[f"x_it{it}"], atol=2e-5, err_msg=f"iterate {it}")
+    # the reference scales args.lr_pnp by sigma^2 in place (pnp_flow.py:61)
+    assert abs(float(g["lr_pnp_after"]) - sigma ** 2) < 1e-12
+
+
+def test_psnr_formula():
+    a = torch.zeros(2, 3, 8, 8); b = torch.zeros(2, 3, 8, 8)
+    b[0] += 0.2; b[1] += 0.02          # in [-1,1] units -> 0.1 / 0.01 after postprocess
+    p = O.psnr_per_image(b, a)
+    np.testing.assert_allclose(p.numpy(), [20.0, 40.0], atol=1e-4)
+
+
+def test_engine_rng_restatement_statistics():
+    z = O.engine_normal(1 << 16, seed=1234, stream=5)
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02
+    # known-answer of Philox4x32-10 (Random123 kat_vectors): ctr=0,key=0 -> 6627e8d5 e169c58d bc57ac4c 9b00dbd8
+    r = O.philox4x32_10(np.zeros((1, 4), np.uint32), np.zeros(2, np.uint32))[0]
+    assert [hex(int(v)) for v in r] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    r = O.philox4x32_10(np.full((1, 4), 0xFFFFFFFF, np.uint32), np.full(2, 0xFFFFFFFF, np.uint32))[0]
+    assert [hex(int(v)) for v in r] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]

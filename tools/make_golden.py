@@ -1,0 +1,216 @@
+"""Generate tests/golden/*.npz by running the REAL reference (/root/reference) here.
+
+Run in the build container only:   python tools/make_golden.py
+The fixtures hold inputs-by-recipe (seeded numpy Philox, see `det_normal`), the
+reference's outputs (full tensors for small cases, crops + float64 checksums for the
+128^2 / 256^2 nets) and nothing else - no reference source travels.
+
+What each fixture pins:
+  unet_*.npz        UNet.forward of pnpflow/models.py:442-495 on synthetic weights
+  degradations.npz  H / H_adj of pnpflow/degradations.py + helper masks (utils.py:327-361)
+  pnp_traj_*.npz    PNP_FLOW.solve_ip (pnpflow/methods/pnp_flow.py:54-172) iterates with
+                    torch.randn_like replaced by a supplied noise sequence
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from ref_import import import_reference  # noqa: E402
+from oracle import pnpflow_oracle as O  # noqa: E402  (only for configs / weight recipe / det inputs)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_num_threads(8)
+
+
+def det_normal(shape, seed, idx=0):
+    """Deterministic N(0,1) float32 tensor from numpy Philox(key=[seed, idx])."""
+    g = np.random.Generator(np.random.Philox(key=[seed, idx]))
+    return torch.from_numpy(g.standard_normal(size=shape, dtype=np.float32))
+
+
+def det_image(shape, seed):
+    """Smooth-ish synthetic clean image in [-1,1]: randn -> 5x 3x3 box blur
+    -> per-image min-max."""
+    x = det_normal(shape, seed, 7)
+    k = torch.ones(shape[1], 1, 3, 3) / 9.0
+    for _ in range(5):
+        x = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (1, 1, 1, 1), mode="replicate"), k, groups=shape[1])
+    lo = x.amin(dim=(1, 2, 3), keepdim=True); hi = x.amax(dim=(1, 2, 3), keepdim=True)
+    return ((x - lo) / (hi - lo) * 2 - 1).contiguous()
+
+
+def checksums(t):
+    d = t.double()
+    return np.array([d.sum().item(), d.abs().sum().item(), (d * d).sum().item()], dtype=np.float64)
+
+
+CFGS = {
+    "mnist": dict(input_channels=1, input_height=28, ch=32, ch_mult=(1, 2), num_res_blocks=2, attn_resolutions=(16,)),
+    "tiny4": dict(input_channels=3, input_height=64, ch=32, ch_mult=(1, 2, 4, 8), num_res_blocks=1, attn_resolutions=(16, 8)),
+    "celeba128": dict(input_channels=3, input_height=128, ch=32, ch_mult=(1, 2, 4, 8), num_res_blocks=6, attn_resolutions=(16, 8)),
+    "afhq256": dict(input_channels=3, input_height=256, ch=32, ch_mult=(1, 2, 4, 8), num_res_blocks=6, attn_resolutions=(16, 8)),
+}
+
+
+def build_ref_unet(models, name):
+    c = CFGS[name]
+    cfg = O.unet_config(**c)
+    sd = O.synthetic_state_dict(cfg, seed=0)
+    m = models.UNet(c["input_channels"], c["input_height"], c["ch"], ch_mult=c["ch_mult"],
+                    num_res_blocks=c["num_res_blocks"], attn_resolutions=c["attn_resolutions"])
+    assert list(m.state_dict().keys()) == list(sd.keys()), "state_dict key order mismatch"
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    return m, cfg, sd
+
+
+def gen_unet(models):
+    for name, B in (("mnist", 3), ("tiny4", 2), ("celeba128", 1), ("afhq256", 1)):
+        m, cfg, sd = build_ref_unet(models, name)
+        c = CFGS[name]
+        shape = (B, c["input_channels"], c["input_height"], c["input_height"])
+        x = det_normal(shape, 11)
+        t = torch.tensor([0.0, 0.37, 0.99][:B], dtype=torch.float32)
+        taps = {}
+        hooks = []
+        # forward hooks on the top-level stages give per-stage checksums
+        def mk(nm):
+            def hook(mod, inp, out):
+                taps[nm] = checksums(out)
+            return hook
+        hooks.append(m.begin_conv.register_forward_hook(mk("begin_conv")))
+        hooks.append(m.temb_net.register_forward_hook(mk("temb")))
+        for i, md in enumerate(m.mid_modules):
+            hooks.append(md.register_forward_hook(mk(f"mid{i}")))
+        with torch.no_grad():
+            out = m(x, t)
+        for h in hooks:
+            h.remove()
+        rec = dict(t=t.numpy(), shape=np.array(shape), out_checksum=checksums(out),
+                   nparams=np.array(sum(v.numel() for v in sd.values())))
+        for k, v in taps.items():
+            rec["tap_" + k] = v
+        if name in ("mnist", "tiny4"):
+            rec["out"] = out.numpy()
+        else:
+            H = c["input_height"]
+            rec["out_crop"] = out[:, :, H // 2 - 16:H // 2 + 16, H // 2 - 16:H // 2 + 16].numpy()
+            rec["out_corner"] = out[:, :, :8, :8].numpy()
+        np.savez_compressed(os.path.join(OUT, f"unet_{name}.npz"), **rec)
+        print("unet", name, out.abs().mean().item(), out.std().item())
+
+
+def gen_degradations(degr, utils):
+    rec = {}
+    x64 = det_normal((2, 3, 64, 64), 21)
+    # the reference's only known-answer test (pnpflow/tests/test_unit.py:14-20)
+    y = degr.BoxInpainting(32).H(torch.ones(1, 3, 128, 128))
+    rec["box32_ones128_zero_rows"] = np.array([int((y[0, 0].sum(1) == 64).nonzero().min()), int((y[0, 0].sum(1) == 64).nonzero().max())])
+    for half in (10, 20):
+        d = degr.BoxInpainting(half)
+        rec[f"box{half}_H"] = d.H(x64).numpy(); rec[f"box{half}_Hadj"] = d.H_adj(x64).numpy()
+    d = degr.BoxInpainting(20)
+    m128 = d.H(torch.ones(1, 1, 128, 128))[0, 0]
+    rec["box20_mask128_rows"] = np.array([int((m128.sum(1) < 128).nonzero().min()), int((m128.sum(1) < 128).nonzero().max())])
+    d = degr.BoxInpainting(40)
+    m256 = d.H(torch.ones(1, 1, 256, 256))[0, 0]
+    rec["box40_mask256_rows"] = np.array([int((m256.sum(1) < 256).nonzero().min()), int((m256.sum(1) < 256).nonzero().max())])
+    # random mask: exact bit patterns
+    d = degr.RandomInpainting(0.7)
+    rec["rand_H"] = d.H(x64).numpy()
+    for (B, S) in ((4, 128), (32, 128), (16, 256)):
+        m = d.H(torch.ones(B, 1, S, S))[:, 0].numpy().astype(np.uint8)
+        if B == 4:
+            rec["randmask_B4_128_bits"] = np.packbits(m.reshape(-1))
+        rec[f"randmask_B{B}_{S}_rowsum"] = m.reshape(B, -1).sum(1).astype(np.int64)
+        rec[f"randmask_B{B}_{S}_first64"] = m.reshape(B, -1)[:, :64].copy()
+    # superresolution
+    for sf, S in ((2, 64), (4, 64)):
+        d = degr.Superresolution(sf, S, device="cpu")
+        ylow = d.H(x64)
+        rec[f"sr{sf}_H"] = ylow.contiguous().numpy(); rec[f"sr{sf}_Hadj"] = d.H_adj(ylow.contiguous()).numpy()
+    # gaussian deblurring (FFT, circular)
+    for sig, S in ((1.0, 64), (3.0, 64)):
+        d = degr.GaussianDeblurring(sig, 61, "fft", 3, S, "cpu")
+        rec[f"blur{sig}_H"] = d.H(x64).numpy(); rec[f"blur{sig}_Hadj"] = d.H_adj(x64).numpy()
+    x128 = det_normal((1, 3, 128, 128), 22)
+    d = degr.GaussianDeblurring(1.0, 61, "fft", 3, 128, "cpu")
+    rec["blur1.0_128_H_crop"] = d.H(x128)[:, :, :16, :16].numpy()
+    rec["blur1.0_128_H_checksum"] = checksums(d.H(x128))
+    x256 = det_normal((1, 3, 256, 256), 23)
+    d = degr.GaussianDeblurring(3.0, 61, "fft", 3, 256, "cpu")
+    rec["blur3.0_256_H_crop"] = d.H(x256)[:, :, :16, :16].numpy()
+    rec["blur3.0_256_Hadj_crop"] = d.H_adj(x256)[:, :, 120:136, 120:136].numpy()
+    rec["blur3.0_256_H_checksum"] = checksums(d.H(x256))
+    rec["gauss2d_1.0_61_center"] = utils.gaussian_2d_kernel(1.0, 61)[25:36, 25:36].numpy()
+    rec["gauss2d_3.0_61_row30"] = utils.gaussian_2d_kernel(3.0, 61)[30].numpy()
+    np.savez_compressed(os.path.join(OUT, "degradations.npz"), **rec)
+    print("degradations ok")
+
+
+def gen_traj(models, degr, utils, pnp):
+    """Run the real PNP_FLOW.solve_ip with torch.randn_like replaced by a supplied sequence."""
+    cases = [
+        ("mnist_denoising", "mnist", "denoising", lambda S: (degr.Denoising(), 0.2), 0.8, 2),
+        ("tiny4_inpainting", "tiny4", "inpainting", lambda S: (degr.BoxInpainting(10), 0.05), 0.5, 2),
+        ("tiny4_superresolution", "tiny4", "superresolution", lambda S: (degr.Superresolution(2, S, device="cpu"), 0.05), 0.3, 2),
+        ("tiny4_deblurring", "tiny4", "gaussian_deblurring_FFT", lambda S: (degr.GaussianDeblurring(1.0, 61, "fft", 3, S, "cpu"), 0.05), 0.01, 2),
+        ("tiny4_random_inpainting", "tiny4", "random_inpainting", lambda S: (degr.RandomInpainting(0.7), 0.01), 0.01, 2),
+    ]
+    steps, num_samples = 10, 2
+    for tag, net, problem, mk, alpha, B in cases:
+        m, cfg, sd = build_ref_unet(models, net)
+        c = CFGS[net]
+        S = c["input_height"]
+        degradation, sigma = mk(S)
+        clean = det_image((B, c["input_channels"], S, S), 31)
+        args = utils.CfgNode(dict(method="pnp_flow", model="ot", dataset="celeba", problem=problem,
+                                  noise_type="gaussian", num_samples=num_samples, steps_pnp=steps, lr_pnp=1.0,
+                                  gamma_style="alpha_1_minus_t", alpha=alpha, max_batch=1, compute_time=False,
+                                  compute_memory=False, save_results=True, batch=0, save_path_ip="/tmp"))
+        iterates = {}
+        seq = {"n": 0}
+
+        def fake_randn_like(like, **kw):
+            i = seq["n"]; seq["n"] += 1
+            return det_normal(tuple(like.shape), 41, i)   # call 0 = measurement noise, then (it, sample) order
+
+        def cap_psnr(clean_img, noisy_img, rec_img, a, H_adj, iter="final"):
+            iterates.setdefault(int(iter), rec_img.clone())
+            iterates["noisy"] = noisy_img.clone()
+        noop = lambda *a, **k: None
+        saved = (torch.randn_like, utils.compute_psnr, utils.compute_ssim, utils.compute_lpips, utils.save_images,
+                 utils.compute_average_psnr, utils.compute_average_ssim, utils.compute_average_lpips)
+        torch.randn_like = fake_randn_like
+        utils.compute_psnr, utils.compute_ssim, utils.compute_lpips, utils.save_images = cap_psnr, noop, noop, noop
+        utils.compute_average_psnr = utils.compute_average_ssim = utils.compute_average_lpips = noop
+        try:
+            solver = pnp.PNP_FLOW(m, torch.device("cpu"), args)
+            solver.solve_ip([(clean, torch.zeros(B))], degradation, sigma)
+        finally:
+            (torch.randn_like, utils.compute_psnr, utils.compute_ssim, utils.compute_lpips, utils.save_images,
+             utils.compute_average_psnr, utils.compute_average_ssim, utils.compute_average_lpips) = saved
+        assert seq["n"] == 1 + steps * num_samples
+        rec = dict(steps=np.array(steps), num_samples=np.array(num_samples), alpha=np.array(alpha), sigma=np.array(sigma),
+                   noisy=iterates["noisy"].numpy(), lr_pnp_after=np.array(args.lr_pnp))
+        for it in (0, 1, 4, 9):
+            rec[f"x_it{it}"] = iterates[it].numpy()
+        np.savez_compressed(os.path.join(OUT, f"pnp_traj_{tag}.npz"), **rec)
+        print("traj", tag, iterates[9].abs().mean().item())
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    models, degr, utils, pnp = import_reference()
+    which = sys.argv[1:] or ["unet", "degr", "traj"]
+    if "unet" in which:
+        gen_unet(models)
+    if "degr" in which:
+        gen_degradations(degr, utils)
+    if "traj" in which:
+        gen_traj(models, degr, utils, pnp)

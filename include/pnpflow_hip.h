@@ -1,0 +1,165 @@
+/* pnpflow_hip.h -- C ABI of libpnpflow_hip.so, the MI355X (gfx950) engine behind the
+ * PnP-Flow restoration hot path.
+ *
+ * The reference (annegnx/PnP-Flow) has no FFI layer: its hot path is Python calling
+ * PyTorch ops.  This ABI is the boundary the build creates *below* the reference's
+ * `pnpflow.methods` / `pnpflow.degradations` / `pnpflow.models.UNet` Python API; each
+ * entry point cites the reference code it replaces (paths relative to the reference
+ * repository root).  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative pf_status otherwise; no C++
+ *     exception crosses the ABI; pf_last_error() gives the message of the last failure
+ *     on that engine (or of pf_engine_create when called with NULL).
+ *   - all tensor arguments are DEVICE pointers to contiguous fp32 NCHW buffers owned by
+ *     the caller (what torch.Tensor.data_ptr() yields), unless named `host_*`.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work
+ *     is enqueued on it, nothing synchronises the device except where stated.
+ *   - one engine per device; an engine is not thread-safe.
+ */
+#ifndef PNPFLOW_HIP_H
+#define PNPFLOW_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_ABI_VERSION 1
+
+typedef enum pf_status {
+    PF_OK = 0,
+    PF_ERR_INVALID = -1,     /* bad argument / unsupported configuration */
+    PF_ERR_HIP = -2,         /* a HIP runtime call failed */
+    PF_ERR_WEIGHTS = -3,     /* unknown / missing / mis-shaped weight tensor */
+    PF_ERR_STATE = -4        /* call made in the wrong state (e.g. forward before finalize) */
+} pf_status;
+
+typedef struct pf_engine pf_engine;
+
+/* Hyper-parameters of pnpflow.models.UNet.__init__ (pnpflow/models.py:302-334);
+ * define_model (pnpflow/utils.py:170-180) uses ch=32, ch_mult=(1,2,4,8),
+ * num_res_blocks=6, attn_resolutions=(16,8). */
+typedef struct pf_unet_cfg {
+    int32_t input_channels;
+    int32_t output_channels;
+    int32_t input_height;      /* square images (the reference assumes it, utils.py:331) */
+    int32_t ch;
+    int32_t num_levels;
+    int32_t ch_mult[8];
+    int32_t num_res_blocks;
+    int32_t num_attn_resolutions;
+    int32_t attn_resolutions[8];
+} pf_unet_cfg;
+
+int pf_abi_version(void);
+
+/* ---- engine life cycle ------------------------------------------------------------ */
+/* replaces UNet.__init__ + .to(device)  (pnpflow/models.py:302-436, methods/pnp_flow.py:15) */
+int pf_engine_create(int device_id, const pf_unet_cfg* cfg, pf_engine** out);
+void pf_engine_destroy(pf_engine* e);
+const char* pf_last_error(const pf_engine* e);
+
+/* replaces model.load_state_dict (pnpflow/utils.py:225): one call per state_dict entry,
+ * `name` = the reference's key (e.g. "down_modules.3.3a_0b_attn.attn_q.weight"),
+ * `host_data` = fp32 values in the reference's layout (OIHW / (out,in) / (C,)).
+ * The engine repacks into its own device layout and owns the copy. */
+int pf_engine_load_weight(pf_engine* e, const char* name, const float* host_data,
+                          const int64_t* shape, int ndim);
+/* checks that every tensor of the architecture was supplied; uploads. */
+int pf_engine_finalize_weights(pf_engine* e);
+/* number of state_dict entries the architecture expects, and the i-th name. */
+int pf_engine_num_weights(const pf_engine* e);
+const char* pf_engine_weight_name(const pf_engine* e, int i);
+
+/* 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  Other values are reserved. */
+int pf_engine_set_precision(pf_engine* e, int mode);
+
+/* ---- velocity field ---------------------------------------------------------------- */
+/* replaces UNet.forward (pnpflow/models.py:442-495) as called by PNP_FLOW.model_forward
+ * (pnpflow/methods/pnp_flow.py:19-21):  v[B,Cout,H,W] = v_theta(x[B,Cin,H,W], t[B]). */
+int pf_unet_forward(pf_engine* e, const float* x, const float* t, float* v, int B, void* stream);
+
+/* debugging / parity localisation: copy an internal NHWC activation (by plan tensor
+ * index) of the last forward to a HOST fp32 buffer in NCHW order; returns C*H*W via
+ * dims[3] = {C,H,W}.  Synchronises the stream. */
+int pf_engine_num_taps(const pf_engine* e);
+const char* pf_engine_tap_name(const pf_engine* e, int i);
+int pf_engine_read_tap(pf_engine* e, int i, float* host_out, int64_t capacity, int32_t dims[3], void* stream);
+
+/* ---- degradation operators (pnpflow/degradations.py) -------------------------------- */
+typedef enum pf_degradation_kind {
+    PF_DEG_DENOISING = 0,       /* Denoising           degradations.py:15-20  */
+    PF_DEG_BOX_INPAINTING = 1,  /* BoxInpainting       degradations.py:23-32, utils.py:327-336 */
+    PF_DEG_MASK_INPAINTING = 2, /* RandomInpainting    degradations.py:35-44 (mask supplied: utils.py:353-361) */
+    PF_DEG_SUPERRESOLUTION = 3, /* Superresolution     degradations.py:92-127, mode=None, utils.py:283-310 */
+    PF_DEG_GAUSSIAN_BLUR = 4    /* GaussianDeblurring  degradations.py:55-89 (circular, separable) */
+} pf_degradation_kind;
+
+typedef struct pf_degradation {
+    int32_t kind;
+    int32_t half_size_mask;     /* BOX */
+    int32_t sf;                 /* SUPERRESOLUTION */
+    int32_t ntaps;              /* GAUSSIAN_BLUR: odd, <= 127 */
+    const uint8_t* mask;        /* MASK: device [B][H][W] bytes, 1 = keep */
+    const float* taps;          /* GAUSSIAN_BLUR: device [ntaps] separable 1-D taps */
+} pf_degradation;
+
+/* y = H(x)      x:[B,C,H,W] -> y:[B,C,Hy,Wy]  (Hy = H/sf for SR, else H) */
+int pf_degradation_H(const pf_degradation* d, const float* x, float* y, int B, int C, int H, int W,
+                     float* scratch, void* stream);
+/* x = H_adj(y) */
+int pf_degradation_H_adj(const pf_degradation* d, const float* y, float* x, int B, int C, int H, int W,
+                         float* scratch, void* stream);
+
+/* ---- PnP-Flow iteration pieces (pnpflow/methods/pnp_flow.py) ------------------------- */
+/* z = x - coef[b] * H_adj(H(x) - y),  coef[b] = lr_t[b] / sigma^2
+ * replaces grad_datafit + the update at pnp_flow.py:39-41, 109-112 (gaussian noise).
+ * scratch: >= 2*B*C*H*W floats for GAUSSIAN_BLUR, may be NULL otherwise. */
+int pf_grad_step(const pf_degradation* d, const float* x, const float* y, const float* coef, float* z,
+                 int B, int C, int H, int W, float* scratch, void* stream);
+/* z_tilde = t[b]*z + (1-t[b])*eps    (interpolation_step, pnp_flow.py:47-48)
+ * eps = `noise` if non-NULL, else Philox4x32-10/Box-Muller (seed, stream_id). */
+int pf_interpolate(const float* z, const float* t, const float* noise, uint64_t seed, uint64_t stream_id,
+                   float* z_tilde, int B, int n_per_image, void* stream);
+/* acc (=|+=) z_tilde + (1-t[b])*v ; final: acc = (acc + ...)*inv_count  (denoiser + average,
+ * pnp_flow.py:50-52, 114-121).  mode: bit0 = first sample (overwrite), bit1 = last (scale). */
+int pf_denoise_accumulate(float* acc, const float* z_tilde, const float* v, const float* t, int mode,
+                          float num_samples, int B, int n_per_image, void* stream);
+/* fills out[n] with engine normals (the same generator pf_interpolate uses). */
+int pf_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
+
+/* per-image PSNR of postprocess(rec) vs postprocess(clean), data_range 1
+ * (pnpflow/utils.py:560-577, 594-611) -> out[B] (device). */
+int pf_psnr(const float* rec, const float* clean, float* out, int B, int n_per_image, void* stream);
+
+/* ---- whole restoration loop --------------------------------------------------------- */
+typedef struct pf_pnp_params {
+    int32_t steps;            /* steps_pnp */
+    int32_t num_samples;
+    const float* host_t;      /* host [steps]  : t value of each iteration (fp32, as the reference computes it) */
+    const float* host_coef;   /* host [steps]  : lr_t / sigma^2 of each iteration */
+    uint64_t seed;            /* Philox key for the interpolation noise */
+    uint64_t stream_base;     /* noise stream id of (iteration it, sample s) = stream_base + it*num_samples + s */
+    const float* noise;       /* optional device [steps*num_samples][B*C*H*W] injected noise (parity runs) */
+    int32_t use_graph;        /* capture one outer iteration in a hipGraph and replay it */
+} pf_pnp_params;
+
+/* Runs pnp_flow.py:93 and 102-121 for one batch:  x0 = H_adj(1);  `steps` iterations.
+ * y: measurement [B,C,Hy,Wy]; x_out: [B,C,H,W].  iter_cb, if non-NULL, is called on the
+ * host after each iteration (stream synchronised) - used for the periodic metrics. */
+typedef void (*pf_iter_callback)(int iteration, void* user);
+int pf_pnp_flow_restore(pf_engine* e, const pf_degradation* d, const pf_pnp_params* prm,
+                        const float* y, float* x_out, int B, void* stream,
+                        pf_iter_callback iter_cb, void* user);
+
+/* kernel-time accounting for bench.py: enables HIP-event timing of the U-Net conv-GEMM
+ * launches on `stream`; read back accumulated (count, milliseconds). */
+int pf_engine_profile(pf_engine* e, int enable);
+int pf_engine_profile_read(pf_engine* e, int64_t* launches, double* ms_conv_gemm, double* flops_conv_gemm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNPFLOW_HIP_H */

@@ -1,0 +1,103 @@
+"""ctypes binding of libpnpflow_hip.so (C ABI: include/pnpflow_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, an
+exception is raised.  The product path never routes through oracle/ or a CPU/eager
+implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpnpflow_hip.so")
+
+PF_ABI_VERSION = 1
+
+PF_DEG_DENOISING, PF_DEG_BOX_INPAINTING, PF_DEG_MASK_INPAINTING, PF_DEG_SUPERRESOLUTION, PF_DEG_GAUSSIAN_BLUR = range(5)
+
+
+class PfUnetCfg(C.Structure):
+    _fields_ = [("input_channels", C.c_int32), ("output_channels", C.c_int32), ("input_height", C.c_int32),
+                ("ch", C.c_int32), ("num_levels", C.c_int32), ("ch_mult", C.c_int32 * 8),
+                ("num_res_blocks", C.c_int32), ("num_attn_resolutions", C.c_int32),
+                ("attn_resolutions", C.c_int32 * 8)]
+
+
+class PfDegradation(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("half_size_mask", C.c_int32), ("sf", C.c_int32), ("ntaps", C.c_int32),
+                ("mask", C.c_void_p), ("taps", C.c_void_p)]
+
+
+class PfPnpParams(C.Structure):
+    _fields_ = [("steps", C.c_int32), ("num_samples", C.c_int32), ("host_t", C.POINTER(C.c_float)),
+                ("host_coef", C.POINTER(C.c_float)), ("seed", C.c_uint64), ("stream_base", C.c_uint64),
+                ("noise", C.c_void_p), ("use_graph", C.c_int32)]
+
+
+ITER_CB = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
+
+# name -> (restype, argtypes); this table is also what tests use to check that every symbol
+# declared in include/pnpflow_hip.h is exported.
+SIGNATURES = {
+    "pf_abi_version": (C.c_int, []),
+    "pf_engine_create": (C.c_int, [C.c_int, C.POINTER(PfUnetCfg), C.POINTER(C.c_void_p)]),
+    "pf_engine_destroy": (None, [C.c_void_p]),
+    "pf_last_error": (C.c_char_p, [C.c_void_p]),
+    "pf_engine_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "pf_engine_finalize_weights": (C.c_int, [C.c_void_p]),
+    "pf_engine_num_weights": (C.c_int, [C.c_void_p]),
+    "pf_engine_weight_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "pf_engine_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "pf_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "pf_engine_num_taps": (C.c_int, [C.c_void_p]),
+    "pf_engine_tap_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "pf_engine_read_tap": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.c_void_p]),
+    "pf_degradation_H": (C.c_int, [C.POINTER(PfDegradation), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pf_degradation_H_adj": (C.c_int, [C.POINTER(PfDegradation), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pf_grad_step": (C.c_int, [C.POINTER(PfDegradation), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pf_interpolate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pf_denoise_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "pf_fill_normal": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "pf_psnr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pf_pnp_flow_restore": (C.c_int, [C.c_void_p, C.POINTER(PfDegradation), C.POINTER(PfPnpParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, ITER_CB, C.c_void_p]),
+    "pf_engine_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "pf_engine_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+class PnpFlowHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpnpflow_hip.so (built by __graft_entry__.build()).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise PnpFlowHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no fallback implementation.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pf_abi_version() != PF_ABI_VERSION:
+        raise PnpFlowHipError("libpnpflow_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, engine=None, what: str = ""):
+    if rc != 0:
+        msg = load().pf_last_error(engine)
+        raise PnpFlowHipError(f"{what} failed (status {rc}): {msg.decode() if msg else '?'}")
+
+
+def current_stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,869 @@
+// Host side of libpnpflow_hip.so: architecture walk, weight repacking, activation
+// planning, kernel sequencing, the PnP-Flow outer loop (optionally as one hipGraph per
+// outer iteration) and the C ABI declared in include/pnpflow_hip.h.
+//
+// Mirrors (file:line relative to the reference repository):
+//   UNet.__init__/forward          pnpflow/models.py:302-495
+//   PNP_FLOW.solve_ip inner loop   pnpflow/methods/pnp_flow.py:93, 102-121
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/pnpflow_hip.h"
+#include "pf_common.h"
+
+using namespace pf;
+
+namespace {
+
+struct HostTensor { std::vector<int64_t> shape; std::vector<float> data; bool loaded = false; };
+
+struct ResDesc {
+    std::string prefix;      // "...a_block."
+    int cin0 = 0, cin1 = 0;  // cin1 > 0: input is cat[h, skip]
+    int cout = 0;
+    bool attn = false;
+    std::string attn_prefix;
+};
+struct LevelDesc { std::vector<ResDesc> blocks; std::string resample; int res_ch = 0; };
+
+struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; double* stats = nullptr; };
+
+enum OpKind { OP_MEMSET, OP_TEMB, OP_BEGIN, OP_CHSTATS, OP_CONV, OP_SOFTMAX, OP_END };
+struct Op {
+    OpKind kind;
+    ConvParams cp; int stride = 1, up = 0;
+    EdgeConvParams ep;
+    TembParams tp;
+    void* ptr = nullptr; size_t bytes = 0;          // memset
+    float* sm = nullptr; int64_t sm_rows = 0; int sm_cols = 0;
+    const float* cs_x = nullptr; double* cs_stats = nullptr; int cs_HW = 0, cs_C = 0;
+    size_t flops = 0;
+};
+
+struct Tap { std::string name; Tensor t; };
+
+struct Plan {
+    int B = 0;
+    std::vector<Op> ops;
+    std::vector<void*> allocs;
+    std::vector<Tap> taps;
+    size_t gemm_flops = 0;
+};
+
+struct SolverBufs {
+    int B = 0; size_t n = 0, ny = 0; int steps = 0;
+    float *x = nullptr, *z = nullptr, *zt = nullptr, *v = nullptr, *scratch = nullptr;
+    float *t_all = nullptr, *coef_all = nullptr, *t_cur = nullptr, *coef_cur = nullptr;
+    int* iter = nullptr;
+};
+
+}  // namespace
+
+struct pf_engine {
+    int device = 0;
+    pf_unet_cfg cfg{};
+    std::string err;
+    std::vector<std::pair<std::string, std::vector<int64_t>>> expected;   // state_dict order
+    std::map<std::string, HostTensor> host;
+    bool finalized = false;
+    // architecture
+    std::vector<LevelDesc> down, up;
+    ResDesc mid0, mid2; std::string mid_attn;
+    int mid_ch = 0;
+    std::vector<std::pair<std::string, int>> res_order;   // every ResidualBlock prefix (+cout), in forward order
+    // device weights
+    std::map<std::string, float*> dev;     // cache of uploaded / packed arrays
+    std::vector<void*> weight_allocs;
+    int temb_total = 0;
+    std::map<std::string, int> temb_off;   // ResBlock prefix -> offset in the stacked temb projection
+    std::map<int, std::unique_ptr<Plan>> plans;
+    SolverBufs sb;
+    // profiling
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    int64_t prof_launches = 0; double prof_ms = 0.0, prof_flops = 0.0;
+};
+
+static thread_local std::string g_create_err;
+
+#define HIPCHK(e, call)                                                                        \
+    do {                                                                                       \
+        hipError_t _r = (call);                                                                \
+        if (_r != hipSuccess) {                                                                \
+            (e)->err = std::string(#call) + ": " + hipGetErrorString(_r);                      \
+            return PF_ERR_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+// --------------------------------------------------------------------------------------
+// architecture walk (models.py:337-436) -> descriptors + expected state_dict entries
+// --------------------------------------------------------------------------------------
+static bool in_attn_res(const pf_unet_cfg& c, int h) {
+    for (int i = 0; i < c.num_attn_resolutions; ++i) if (c.attn_resolutions[i] == h) return true;
+    return false;
+}
+
+static void expect(pf_engine* e, const std::string& n, std::vector<int64_t> s) { e->expected.emplace_back(n, std::move(s)); }
+static void expect_lin(pf_engine* e, const std::string& p, int i, int o) { expect(e, p + "weight", {o, i}); expect(e, p + "bias", {o}); }
+static void expect_conv(pf_engine* e, const std::string& p, int i, int o, int k) { expect(e, p + "weight", {o, i, k, k}); expect(e, p + "bias", {o}); }
+static void expect_gn(pf_engine* e, const std::string& p, int c) { expect(e, p + "weight", {c}); expect(e, p + "bias", {c}); }
+static void expect_res(pf_engine* e, const std::string& p, int i, int o, int tch) {
+    expect_lin(e, p + "temb_proj.", tch, o); expect_gn(e, p + "norm1.", i); expect_conv(e, p + "conv1.", i, o, 3);
+    expect_gn(e, p + "norm2.", o); expect_conv(e, p + "conv2.", o, o, 3);
+    if (i != o) expect_conv(e, p + "shortcut.", i, o, 1);
+}
+static void expect_attn(pf_engine* e, const std::string& p, int c) {
+    expect_conv(e, p + "attn_q.", c, c, 1); expect_conv(e, p + "attn_k.", c, c, 1);
+    expect_conv(e, p + "attn_v.", c, c, 1); expect_conv(e, p + "proj_out.", c, c, 1);
+    expect_gn(e, p + "norm.", c);
+}
+
+static int build_arch(pf_engine* e) {
+    const pf_unet_cfg& c = e->cfg;
+    const int ch = c.ch, nlev = c.num_levels, nres = c.num_res_blocks, tch = 4 * ch;
+    char buf[128];
+    expect_lin(e, "temb_net.main.0.", ch, tch); expect_lin(e, "temb_net.main.2.", tch, tch);
+    expect_conv(e, "begin_conv.", c.input_channels, ch, 3);
+    std::vector<int> chans{ch};
+    int cur = ch, h = c.input_height;
+    for (int lvl = 0; lvl < nlev; ++lvl) {
+        LevelDesc L;
+        const int o = ch * c.ch_mult[lvl];
+        for (int blk = 0; blk < nres; ++blk) {
+            ResDesc r;
+            snprintf(buf, sizeof buf, "down_modules.%d.%da_%da_block.", lvl, lvl, blk); r.prefix = buf;
+            r.cin0 = cur; r.cout = o;
+            expect_res(e, r.prefix, cur, o, tch);
+            if (in_attn_res(c, h)) {
+                r.attn = true;
+                snprintf(buf, sizeof buf, "down_modules.%d.%da_%db_attn.", lvl, lvl, blk); r.attn_prefix = buf;
+                expect_attn(e, r.attn_prefix, o);
+            }
+            L.blocks.push_back(r); chans.push_back(o); cur = o;
+        }
+        if (lvl != nlev - 1) {
+            snprintf(buf, sizeof buf, "down_modules.%d.%db_downsample.", lvl, lvl); L.resample = buf; L.res_ch = o;
+            expect_conv(e, L.resample, o, o, 3);
+            h /= 2; chans.push_back(o);
+        }
+        e->down.push_back(L);
+    }
+    e->mid_ch = cur;
+    e->mid0.prefix = "mid_modules.0."; e->mid0.cin0 = cur; e->mid0.cout = cur;
+    e->mid2.prefix = "mid_modules.2."; e->mid2.cin0 = cur; e->mid2.cout = cur;
+    e->mid_attn = "mid_modules.1.";
+    expect_res(e, e->mid0.prefix, cur, cur, tch); expect_attn(e, e->mid_attn, cur); expect_res(e, e->mid2.prefix, cur, cur, tch);
+    for (int idx = 0; idx < nlev; ++idx) {
+        const int lvl = nlev - 1 - idx;
+        LevelDesc L;
+        const int o = ch * c.ch_mult[lvl];
+        for (int blk = 0; blk < nres + 1; ++blk) {
+            ResDesc r;
+            snprintf(buf, sizeof buf, "up_modules.%d.%da_%da_block.", idx, lvl, blk); r.prefix = buf;
+            r.cin0 = cur; r.cin1 = chans.back(); chans.pop_back(); r.cout = o;
+            expect_res(e, r.prefix, r.cin0 + r.cin1, o, tch);
+            if (in_attn_res(c, h)) {
+                r.attn = true;
+                snprintf(buf, sizeof buf, "up_modules.%d.%da_%db_attn.", idx, lvl, blk); r.attn_prefix = buf;
+                expect_attn(e, r.attn_prefix, o);
+            }
+            L.blocks.push_back(r); cur = o;
+        }
+        if (lvl != 0) {
+            snprintf(buf, sizeof buf, "up_modules.%d.%db_upsample.up_conv.", idx, lvl); L.resample = buf; L.res_ch = o;
+            expect_conv(e, L.resample, o, o, 3);
+            h *= 2;
+        }
+        e->up.push_back(L);
+    }
+    if (!chans.empty()) { e->err = "internal: skip stack not empty"; return PF_ERR_INVALID; }
+    expect_gn(e, "end_conv.0.", cur); expect_conv(e, "end_conv.2.", cur, c.output_channels, 3);
+    if (cur != ch) { e->err = "internal: final width != ch"; return PF_ERR_INVALID; }
+    // forward-order list of residual blocks for the stacked temb projection
+    for (auto& L : e->down) for (auto& r : L.blocks) e->res_order.emplace_back(r.prefix, r.cout);
+    e->res_order.emplace_back(e->mid0.prefix, e->mid0.cout); e->res_order.emplace_back(e->mid2.prefix, e->mid2.cout);
+    for (auto& L : e->up) for (auto& r : L.blocks) e->res_order.emplace_back(r.prefix, r.cout);
+    int off = 0;
+    for (auto& pr : e->res_order) { e->temb_off[pr.first] = off; off += pr.second; }
+    e->temb_total = off;
+    return PF_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// device weights
+// --------------------------------------------------------------------------------------
+static const HostTensor& W(pf_engine* e, const std::string& n) { return e->host.at(n); }
+
+static float* upload(pf_engine* e, const std::string& key, const std::vector<float>& v) {
+    auto it = e->dev.find(key);
+    if (it != e->dev.end()) return it->second;
+    float* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(v.size(), 4) * sizeof(float)) != hipSuccess) return nullptr;
+    hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice);
+    e->weight_allocs.push_back(d);
+    e->dev[key] = d;
+    return d;
+}
+
+// OIHW conv weight, input channels [lo,hi) -> [chunk][tap][Cout][KC] (zero padded K tail)
+static float* packed_conv(pf_engine* e, const std::string& wname, int lo, int hi) {
+    const std::string key = wname + "#" + std::to_string(lo) + ":" + std::to_string(hi);
+    auto it = e->dev.find(key);
+    if (it != e->dev.end()) return it->second;
+    const HostTensor& t = W(e, wname);
+    const int O = (int)t.shape[0], I = (int)t.shape[1], kk = (int)(t.shape[2] * t.shape[3]);
+    const int C = hi - lo, nchunk = (C + CONV_KC - 1) / CONV_KC;
+    std::vector<float> out((size_t)nchunk * kk * O * CONV_KC, 0.f);
+    for (int chn = 0; chn < nchunk; ++chn)
+        for (int tap = 0; tap < kk; ++tap)
+            for (int n = 0; n < O; ++n)
+                for (int k = 0; k < CONV_KC; ++k) {
+                    const int c = chn * CONV_KC + k;
+                    if (c < C) out[(((size_t)chn * kk + tap) * O + n) * CONV_KC + k] = t.data[((size_t)n * I + lo + c) * kk + tap];
+                }
+    return upload(e, key, out);
+}
+
+static void fill_packed_seg(ConvSeg& s, const float* w, int taps, int Cout) {
+    s.w = w; s.w_mode = 0; s.w_bs = 0;
+    s.w_cs = (int64_t)taps * Cout * CONV_KC; s.w_ts = (int64_t)Cout * CONV_KC; s.w_ns = CONV_KC; s.w_ks = 0;
+}
+
+// --------------------------------------------------------------------------------------
+// plan construction
+// --------------------------------------------------------------------------------------
+struct Builder {
+    pf_engine* e; Plan* plan; int B; bool ok = true;
+    std::multimap<size_t, void*> free_list;
+    std::map<void*, size_t> sizes;
+    size_t stats_bytes = 0;
+    std::vector<std::pair<double**, size_t>> stats_fix;   // (where to store, offset) resolved after the walk
+
+    float* acquire(size_t nfloats) {
+        const size_t bytes = ((nfloats * sizeof(float) + 255) / 256) * 256;
+        auto it = free_list.find(bytes);
+        if (it != free_list.end()) { void* p = it->second; free_list.erase(it); return (float*)p; }
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { ok = false; e->err = "hipMalloc failed (activations)"; return nullptr; }
+        plan->allocs.push_back(p); sizes[p] = bytes;
+        return (float*)p;
+    }
+    bool keep = getenv("PNPFLOW_HIP_KEEP_ACTIVATIONS") != nullptr;   // debugging: never reuse, so every tap stays readable
+    void release(float* p) { if (p && !keep) free_list.emplace(sizes[p], p); }
+    Tensor make(int C, int H, int W, bool stats) {
+        Tensor t; t.C = C; t.H = H; t.W = W; t.p = acquire((size_t)B * H * W * C);
+        if (stats) { t.stats = (double*)(uintptr_t)(stats_bytes + 1); stats_bytes += (size_t)B * C * 2 * sizeof(double); }
+        return t;
+    }
+};
+
+static ConvParams base_params(int B, int H, int W, int Hs, int Ws, const Tensor& out) {
+    ConvParams p{};
+    p.B = B; p.H = H; p.W = W; p.Hs = Hs; p.Ws = Ws; p.Cout = out.C; p.out = out.p; p.out_cstride = out.C;
+    p.out_scale = 1.0f; p.stats_out = out.stats; p.gn_eps = 1e-6f;
+    return p;
+}
+
+static void add_seg(ConvParams& p, const Tensor& t, int xform, int taps, int gn_off) {
+    ConvSeg& s = p.seg[p.nseg++];
+    s.src = t.p; s.C = t.C; s.cstride = t.C; s.coff = 0; s.xform = xform; s.taps = taps; s.gn_off = gn_off; s.stats = t.stats;
+}
+
+static void push_conv(Builder& bd, const ConvParams& p, int stride = 1, int up = 0) {
+    Op op{}; op.kind = OP_CONV; op.cp = p; op.stride = stride; op.up = up; op.flops = conv_flops(p);
+    bd.plan->gemm_flops += op.flops;
+    bd.plan->ops.push_back(op);
+}
+
+// ResidualBlock (models.py:94-113).  in1.p != nullptr: input is cat[in0, in1].
+static Tensor res_block(Builder& bd, const ResDesc& r, const Tensor& in0, const Tensor* in1, float* temb_vec) {
+    pf_engine* e = bd.e; const int B = bd.B, H = in0.H, Wd = in0.W;
+    const int cin = in0.C + (in1 ? in1->C : 0);
+    // conv1: GN1+SiLU on the (concatenated) input, + bias + temb projection
+    Tensor h1 = bd.make(r.cout, H, Wd, true);
+    {
+        ConvParams p = base_params(B, H, Wd, H, Wd, h1);
+        add_seg(p, in0, 2, 9, 0);
+        fill_packed_seg(p.seg[0], packed_conv(e, r.prefix + "conv1.weight", 0, in0.C), 9, r.cout);
+        if (in1) {
+            add_seg(p, *in1, 2, 9, in0.C);
+            fill_packed_seg(p.seg[1], packed_conv(e, r.prefix + "conv1.weight", in0.C, cin), 9, r.cout);
+        }
+        p.gn_C = cin; p.gn_cpg = cin / 32;
+        p.gamma = upload(e, r.prefix + "norm1.weight", W(e, r.prefix + "norm1.weight").data);
+        p.beta = upload(e, r.prefix + "norm1.bias", W(e, r.prefix + "norm1.bias").data);
+        p.addvec = temb_vec + e->temb_off.at(r.prefix); p.addvec_bs = e->temb_total;
+        push_conv(bd, p);
+    }
+    // conv2: GN2+SiLU, + bias, + shortcut (identity residual or 1x1 conv folded in as K-segments)
+    Tensor out = bd.make(r.cout, H, Wd, true);
+    {
+        ConvParams p = base_params(B, H, Wd, H, Wd, out);
+        add_seg(p, h1, 2, 9, 0);
+        fill_packed_seg(p.seg[0], packed_conv(e, r.prefix + "conv2.weight", 0, r.cout), 9, r.cout);
+        p.gn_C = r.cout; p.gn_cpg = r.cout / 32;
+        p.gamma = upload(e, r.prefix + "norm2.weight", W(e, r.prefix + "norm2.weight").data);
+        p.beta = upload(e, r.prefix + "norm2.bias", W(e, r.prefix + "norm2.bias").data);
+        std::vector<float> bias = W(e, r.prefix + "conv2.bias").data;
+        if (cin != r.cout) {
+            const std::string sw = r.prefix + "shortcut.weight";
+            add_seg(p, in0, 0, 1, 0);
+            fill_packed_seg(p.seg[p.nseg - 1], packed_conv(e, sw, 0, in0.C), 1, r.cout);
+            if (in1) {
+                add_seg(p, *in1, 0, 1, 0);
+                fill_packed_seg(p.seg[p.nseg - 1], packed_conv(e, sw, in0.C, cin), 1, r.cout);
+            }
+            const auto& sb = W(e, r.prefix + "shortcut.bias").data;
+            for (size_t i = 0; i < bias.size(); ++i) bias[i] += sb[i];
+        } else {
+            p.residual = in0.p; p.res_cstride = in0.C;
+        }
+        p.addvec = upload(e, r.prefix + "conv2.bias+sc", bias); p.addvec_bs = 0;
+        push_conv(bd, p);
+    }
+    bd.release(h1.p);
+    return out;
+}
+
+// SelfAttention (models.py:145-162)
+static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x) {
+    pf_engine* e = bd.e; const int B = bd.B, H = x.H, Wd = x.W, C = x.C, HW = H * Wd;
+    // qkv = 1x1 convs of GroupNorm(x) (no activation), stacked: [B][HW][3C]
+    std::string key = pfx + "qkv";
+    if (!e->dev.count(key + ".w")) {
+        HostTensor cat; cat.shape = {3 * C, C, 1, 1}; cat.data.reserve((size_t)3 * C * C);
+        std::vector<float> bias;
+        for (const char* nm : {"attn_q.", "attn_k.", "attn_v."}) {
+            const auto& w = W(e, pfx + nm + "weight").data; cat.data.insert(cat.data.end(), w.begin(), w.end());
+            const auto& bb = W(e, pfx + nm + "bias").data; bias.insert(bias.end(), bb.begin(), bb.end());
+        }
+        e->host[key + ".w"] = cat; e->host[key + ".w"].loaded = true;
+        upload(e, key + ".b", bias);
+        e->dev[key + ".w"] = packed_conv(e, key + ".w", 0, C);
+    }
+    Tensor qkv = bd.make(3 * C, H, Wd, false);
+    {
+        ConvParams p = base_params(B, H, Wd, H, Wd, qkv);
+        add_seg(p, x, 1, 1, 0);
+        fill_packed_seg(p.seg[0], e->dev.at(key + ".w"), 1, 3 * C);
+        p.gn_C = C; p.gn_cpg = C / 32;
+        p.gamma = upload(e, pfx + "norm.weight", W(e, pfx + "norm.weight").data);
+        p.beta = upload(e, pfx + "norm.bias", W(e, pfx + "norm.bias").data);
+        p.addvec = e->dev.at(key + ".b"); p.addvec_bs = 0;
+        push_conv(bd, p);
+    }
+    // S[b][i][j] = C^-1/2 * sum_c q[i][c] k[j][c]      (a 1-tap "conv" whose weights are k)
+    Tensor S = bd.make(HW, H, Wd, false);
+    {
+        ConvParams p = base_params(B, H, Wd, H, Wd, S);
+        ConvSeg& s = p.seg[p.nseg++];
+        s.src = qkv.p; s.C = C; s.cstride = 3 * C; s.coff = 0; s.xform = 0; s.taps = 1; s.stats = nullptr;
+        s.w = qkv.p + C; s.w_mode = 0; s.w_bs = (int64_t)HW * 3 * C; s.w_cs = CONV_KC; s.w_ts = 0; s.w_ns = 3 * C; s.w_ks = 0;
+        p.out_scale = 1.0f / sqrtf((float)C);
+        push_conv(bd, p);
+    }
+    { Op op{}; op.kind = OP_SOFTMAX; op.sm = S.p; op.sm_rows = (int64_t)B * HW; op.sm_cols = HW; bd.plan->ops.push_back(op); }
+    // O[b][i][c] = sum_j A[i][j] v[j][c]
+    Tensor o = bd.make(C, H, Wd, false);
+    {
+        ConvParams p = base_params(B, H, Wd, H, Wd, o);
+        ConvSeg& s = p.seg[p.nseg++];
+        s.src = S.p; s.C = HW; s.cstride = HW; s.coff = 0; s.xform = 0; s.taps = 1; s.stats = nullptr;
+        s.w = qkv.p + 2 * C; s.w_mode = 1; s.w_bs = (int64_t)HW * 3 * C; s.w_ks = 3 * C; s.w_cs = 0; s.w_ts = 0; s.w_ns = 0;
+        push_conv(bd, p);
+    }
+    // out = x + proj_out(O)
+    Tensor out = bd.make(C, H, Wd, true);
+    {
+        ConvParams p = base_params(B, H, Wd, H, Wd, out);
+        add_seg(p, o, 0, 1, 0);
+        fill_packed_seg(p.seg[0], packed_conv(e, pfx + "proj_out.weight", 0, C), 1, C);
+        p.addvec = upload(e, pfx + "proj_out.bias", W(e, pfx + "proj_out.bias").data); p.addvec_bs = 0;
+        p.residual = x.p; p.res_cstride = C;
+        push_conv(bd, p);
+    }
+    bd.release(qkv.p); bd.release(S.p); bd.release(o.p);
+    return out;
+}
+
+static Tensor resample_conv(Builder& bd, const std::string& pfx, const Tensor& x, bool down) {
+    pf_engine* e = bd.e; const int B = bd.B;
+    const int H = down ? x.H / 2 : x.H * 2, Wd = down ? x.W / 2 : x.W * 2;
+    Tensor out = bd.make(x.C, H, Wd, true);
+    ConvParams p = base_params(B, H, Wd, x.H, x.W, out);
+    add_seg(p, x, 0, 9, 0);
+    fill_packed_seg(p.seg[0], packed_conv(e, pfx + "weight", 0, x.C), 9, x.C);
+    p.addvec = upload(e, pfx + "bias", W(e, pfx + "bias").data); p.addvec_bs = 0;
+    push_conv(bd, p, down ? 2 : 1, down ? 0 : 1);
+    return out;
+}
+
+static void fix_stats(Op& op, double* slab) {
+    auto fx = [&](const double*& p) { if (p) p = (const double*)((char*)slab + ((uintptr_t)p - 1)); };
+    auto fxm = [&](double*& p) { if (p) p = (double*)((char*)slab + ((uintptr_t)p - 1)); };
+    if (op.kind == OP_CONV) { for (int i = 0; i < op.cp.nseg; ++i) fx(op.cp.seg[i].stats); fxm(op.cp.stats_out); }
+    if (op.kind == OP_END) fx(op.ep.stats);
+    if (op.kind == OP_CHSTATS) fxm(op.cs_stats);
+}
+
+static int build_plan(pf_engine* e, int B, Plan** out_plan) {
+    auto it = e->plans.find(B);
+    if (it != e->plans.end()) { *out_plan = it->second.get(); return PF_OK; }
+    auto plan = std::make_unique<Plan>(); plan->B = B;
+    Builder bd{e, plan.get(), B};
+    const pf_unet_cfg& c = e->cfg;
+    const int H0 = c.input_height, ch = c.ch, tch = 4 * ch;
+    // op 0: zero the statistics slab (filled in below); op 1: time embedding
+    { Op op{}; op.kind = OP_MEMSET; plan->ops.push_back(op); }
+    float* temb_vec = bd.acquire((size_t)B * e->temb_total);
+    {
+        // stacked temb projections; bias = temb_proj.bias + conv1.bias
+        if (!e->dev.count("temb.wp")) {
+            std::vector<float> wp, bp;
+            for (auto& pr : e->res_order) {
+                const auto& w = W(e, pr.first + "temb_proj.weight").data; wp.insert(wp.end(), w.begin(), w.end());
+                const auto& b1 = W(e, pr.first + "temb_proj.bias").data; const auto& b2 = W(e, pr.first + "conv1.bias").data;
+                for (size_t i = 0; i < b1.size(); ++i) bp.push_back(b1[i] + b2[i]);
+            }
+            upload(e, "temb.wp", wp); upload(e, "temb.bp", bp);
+        }
+        Op op{}; op.kind = OP_TEMB;
+        op.tp.w0 = upload(e, "temb_net.main.0.weight", W(e, "temb_net.main.0.weight").data);
+        op.tp.b0 = upload(e, "temb_net.main.0.bias", W(e, "temb_net.main.0.bias").data);
+        op.tp.w1 = upload(e, "temb_net.main.2.weight", W(e, "temb_net.main.2.weight").data);
+        op.tp.b1 = upload(e, "temb_net.main.2.bias", W(e, "temb_net.main.2.bias").data);
+        op.tp.wp = e->dev.at("temb.wp"); op.tp.bp = e->dev.at("temb.bp");
+        op.tp.out = temb_vec; op.tp.B = B; op.tp.ch = ch; op.tp.total_out = e->temb_total;
+        (void)tch;
+        plan->ops.push_back(op);
+    }
+    // begin conv (models.py:451) + stand-alone channel statistics of its output
+    std::vector<Tensor> hs;
+    {
+        Tensor t0 = bd.make(ch, H0, H0, true);
+        const HostTensor& w = W(e, "begin_conv.weight");   // [ch][Cimg][3][3] -> [tap][ci][ch]
+        const int ci_n = c.input_channels;
+        std::vector<float> wp((size_t)9 * ci_n * ch);
+        for (int n = 0; n < ch; ++n) for (int ci = 0; ci < ci_n; ++ci) for (int tap = 0; tap < 9; ++tap)
+            wp[((size_t)tap * ci_n + ci) * ch + n] = w.data[((size_t)n * ci_n + ci) * 9 + tap];
+        Op op{}; op.kind = OP_BEGIN;
+        op.ep.out = t0.p; op.ep.w = upload(e, "begin_conv.packed", wp);
+        op.ep.bias = upload(e, "begin_conv.bias", W(e, "begin_conv.bias").data);
+        op.ep.B = B; op.ep.H = H0; op.ep.W = H0; op.ep.Cimg = ci_n; op.ep.C = ch;
+        plan->ops.push_back(op);
+        Op cs{}; cs.kind = OP_CHSTATS; cs.cs_x = t0.p; cs.cs_stats = t0.stats; cs.cs_HW = H0 * H0; cs.cs_C = ch;
+        plan->ops.push_back(cs);
+        hs.push_back(t0);
+        plan->taps.push_back({"begin_conv", t0});
+    }
+    char nm[64];
+    // down path (models.py:452-467)
+    for (size_t lvl = 0; lvl < e->down.size(); ++lvl) {
+        const LevelDesc& L = e->down[lvl];
+        for (size_t blk = 0; blk < L.blocks.size(); ++blk) {
+            Tensor h = res_block(bd, L.blocks[blk], hs.back(), nullptr, temb_vec);
+            if (L.blocks[blk].attn) { Tensor a = attn_block(bd, L.blocks[blk].attn_prefix, h); bd.release(h.p); h = a; }
+            hs.push_back(h);
+            snprintf(nm, sizeof nm, "down%zu_%zu", lvl, blk); plan->taps.push_back({nm, h});
+        }
+        if (!L.resample.empty()) {
+            hs.push_back(resample_conv(bd, L.resample, hs.back(), true));
+            snprintf(nm, sizeof nm, "downsample%zu", lvl); plan->taps.push_back({nm, hs.back()});
+        }
+    }
+    // middle (models.py:470-471)
+    Tensor h = hs.back();
+    bool h_owned = false;   // hs tensors are released when popped
+    {
+        Tensor a = res_block(bd, e->mid0, h, nullptr, temb_vec);
+        Tensor b2 = attn_block(bd, e->mid_attn, a); bd.release(a.p);
+        Tensor c2 = res_block(bd, e->mid2, b2, nullptr, temb_vec); bd.release(b2.p);
+        h = c2; h_owned = true;
+        plan->taps.push_back({"mid", h});
+    }
+    // up path (models.py:474-488)
+    for (size_t idx = 0; idx < e->up.size(); ++idx) {
+        const LevelDesc& L = e->up[idx];
+        const int lvl = (int)e->up.size() - 1 - (int)idx;
+        for (size_t blk = 0; blk < L.blocks.size(); ++blk) {
+            Tensor skip = hs.back(); hs.pop_back();
+            Tensor o = res_block(bd, L.blocks[blk], h, &skip, temb_vec);
+            if (h_owned) bd.release(h.p);
+            bd.release(skip.p);
+            if (L.blocks[blk].attn) { Tensor a = attn_block(bd, L.blocks[blk].attn_prefix, o); bd.release(o.p); o = a; }
+            h = o; h_owned = true;
+            snprintf(nm, sizeof nm, "up%d_%zu", lvl, blk); plan->taps.push_back({nm, h});
+        }
+        if (!L.resample.empty()) {
+            Tensor o = resample_conv(bd, L.resample, h, false);
+            bd.release(h.p); h = o;
+            snprintf(nm, sizeof nm, "upsample%d", lvl); plan->taps.push_back({nm, h});
+        }
+    }
+    // end (models.py:492)
+    {
+        const HostTensor& w = W(e, "end_conv.2.weight");   // [Cimg][ch][3][3] -> [tap][co][ch]
+        const int co_n = c.output_channels;
+        std::vector<float> wp((size_t)9 * co_n * ch);
+        for (int co = 0; co < co_n; ++co) for (int ci = 0; ci < ch; ++ci) for (int tap = 0; tap < 9; ++tap)
+            wp[((size_t)tap * co_n + co) * ch + ci] = w.data[((size_t)co * ch + ci) * 9 + tap];
+        Op op{}; op.kind = OP_END;
+        op.ep.in = h.p; op.ep.w = upload(e, "end_conv.packed", wp);
+        op.ep.bias = upload(e, "end_conv.2.bias", W(e, "end_conv.2.bias").data);
+        op.ep.B = B; op.ep.H = H0; op.ep.W = H0; op.ep.Cimg = co_n; op.ep.C = ch;
+        op.ep.stats = h.stats; op.ep.gamma = upload(e, "end_conv.0.weight", W(e, "end_conv.0.weight").data);
+        op.ep.beta = upload(e, "end_conv.0.bias", W(e, "end_conv.0.bias").data);
+        op.ep.gn_cpg = ch / 32; op.ep.gn_eps = 1e-6f;
+        plan->ops.push_back(op);
+    }
+    if (!bd.ok) return PF_ERR_HIP;
+    for (auto& kv : e->dev) if (kv.second == nullptr) { e->err = "weight upload failed: " + kv.first; return PF_ERR_HIP; }
+    // statistics slab
+    void* slab = nullptr;
+    if (hipMalloc(&slab, std::max<size_t>(bd.stats_bytes, 256)) != hipSuccess) { e->err = "hipMalloc failed (stats)"; return PF_ERR_HIP; }
+    plan->allocs.push_back(slab);
+    for (auto& op : plan->ops) fix_stats(op, (double*)slab);
+    for (auto& tp : plan->taps) if (tp.t.stats) tp.t.stats = (double*)((char*)slab + ((uintptr_t)tp.t.stats - 1));
+    plan->ops[0].ptr = slab; plan->ops[0].bytes = bd.stats_bytes;
+    *out_plan = plan.get();
+    e->plans[B] = std::move(plan);
+    return PF_OK;
+}
+
+static int run_plan(pf_engine* e, Plan* plan, const float* x, const float* t, float* v, hipStream_t s) {
+    for (auto& op : plan->ops) {
+        hipError_t r = hipSuccess;
+        switch (op.kind) {
+            case OP_MEMSET: r = hipMemsetAsync(op.ptr, 0, op.bytes, s); break;
+            case OP_TEMB: { TembParams tp = op.tp; tp.t = t; r = launch_temb(tp, s); break; }
+            case OP_BEGIN: { EdgeConvParams ep = op.ep; ep.in = x; r = launch_begin_conv(ep, s); break; }
+            case OP_CHSTATS: r = launch_channel_stats(op.cs_x, op.cs_stats, plan->B, op.cs_HW, op.cs_C, s); break;
+            case OP_CONV:
+                if (e->profile) {
+                    if (e->ev_used == e->ev_pool.size()) {
+                        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); e->ev_pool.emplace_back(a, b);
+                    }
+                    auto& ev = e->ev_pool[e->ev_used++];
+                    hipEventRecord(ev.first, s);
+                    r = launch_conv(op.cp, op.stride, op.up, s);
+                    hipEventRecord(ev.second, s);
+                    e->prof_flops += (double)op.flops;
+                } else {
+                    r = launch_conv(op.cp, op.stride, op.up, s);
+                }
+                break;
+            case OP_SOFTMAX: r = launch_softmax_rows(op.sm, op.sm_rows, op.sm_cols, s); break;
+            case OP_END: { EdgeConvParams ep = op.ep; ep.out = v; r = launch_end_conv(ep, s); break; }
+        }
+        if (r != hipSuccess) { e->err = std::string("kernel launch failed: ") + hipGetErrorString(r); return PF_ERR_HIP; }
+    }
+    return PF_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// PnP-Flow outer loop helpers
+// --------------------------------------------------------------------------------------
+__global__ void prep_iter_kernel(const int* iter, const float* t_all, const float* coef_all, float* t_cur, float* coef_cur, int B) {
+    const int it = *iter;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) { t_cur[b] = t_all[it]; coef_cur[b] = coef_all[it]; }
+}
+__global__ void bump_iter_kernel(int* iter) { if (threadIdx.x == 0) *iter += 1; }
+
+
+static DegView to_view(const pf_degradation* d) {
+    DegView v{}; v.kind = d->kind; v.half = d->half_size_mask; v.sf = d->sf; v.ntaps = d->ntaps; v.mask = d->mask; v.taps = d->taps;
+    return v;
+}
+
+// --------------------------------------------------------------------------------------
+// C ABI
+// --------------------------------------------------------------------------------------
+extern "C" {
+
+int pf_abi_version(void) { return PF_ABI_VERSION; }
+
+const char* pf_last_error(const pf_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+int pf_engine_create(int device_id, const pf_unet_cfg* cfg, pf_engine** out) {
+    if (!cfg || !out) { g_create_err = "null argument"; return PF_ERR_INVALID; }
+    if (cfg->num_levels < 1 || cfg->num_levels > 8 || cfg->num_attn_resolutions < 0 || cfg->num_attn_resolutions > 8 ||
+        cfg->ch != 32 || cfg->input_channels < 1 || cfg->input_channels > 3 || cfg->output_channels < 1 || cfg->output_channels > 3 ||
+        cfg->num_res_blocks < 1 || cfg->input_height % (1 << (cfg->num_levels - 1)) != 0) {
+        g_create_err = "unsupported UNet configuration (need ch=32, 1..3 image channels, height divisible by 2^(levels-1))";
+        return PF_ERR_INVALID;
+    }
+    int ndev = 0;
+    hipError_t r = hipGetDeviceCount(&ndev);
+    if (r != hipSuccess || ndev <= 0) { g_create_err = std::string("no HIP device: ") + hipGetErrorString(r); return PF_ERR_HIP; }
+    if (device_id < 0 || device_id >= ndev) { g_create_err = "bad device id"; return PF_ERR_INVALID; }
+    if ((r = hipSetDevice(device_id)) != hipSuccess) { g_create_err = hipGetErrorString(r); return PF_ERR_HIP; }
+    auto* e = new pf_engine();
+    e->device = device_id; e->cfg = *cfg;
+    int rc = build_arch(e);
+    if (rc != PF_OK) { g_create_err = e->err; delete e; return rc; }
+    *out = e;
+    return PF_OK;
+}
+
+static void free_solver(pf_engine* e) {
+    SolverBufs& b = e->sb;
+    for (void* p : {(void*)b.x, (void*)b.z, (void*)b.zt, (void*)b.v, (void*)b.scratch, (void*)b.t_all, (void*)b.coef_all,
+                    (void*)b.t_cur, (void*)b.coef_cur, (void*)b.iter})
+        if (p) hipFree(p);
+    b = SolverBufs{};
+}
+
+void pf_engine_destroy(pf_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    for (auto& kv : e->plans) for (void* p : kv.second->allocs) hipFree(p);
+    for (void* p : e->weight_allocs) hipFree(p);
+    for (auto& ev : e->ev_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    free_solver(e);
+    delete e;
+}
+
+int pf_engine_num_weights(const pf_engine* e) { return e ? (int)e->expected.size() : 0; }
+const char* pf_engine_weight_name(const pf_engine* e, int i) {
+    if (!e || i < 0 || i >= (int)e->expected.size()) return nullptr;
+    return e->expected[i].first.c_str();
+}
+
+int pf_engine_load_weight(pf_engine* e, const char* name, const float* host_data, const int64_t* shape, int ndim) {
+    if (!e || !name || !host_data || !shape) return PF_ERR_INVALID;
+    if (e->finalized) { e->err = "weights already finalized"; return PF_ERR_STATE; }
+    for (auto& ex : e->expected) {
+        if (ex.first != name) continue;
+        if ((int)ex.second.size() != ndim) { e->err = std::string("rank mismatch for ") + name; return PF_ERR_WEIGHTS; }
+        size_t n = 1;
+        for (int i = 0; i < ndim; ++i) {
+            if (ex.second[i] != shape[i]) { e->err = std::string("shape mismatch for ") + name; return PF_ERR_WEIGHTS; }
+            n *= (size_t)shape[i];
+        }
+        HostTensor& t = e->host[name];
+        t.shape.assign(shape, shape + ndim); t.data.assign(host_data, host_data + n); t.loaded = true;
+        return PF_OK;
+    }
+    e->err = std::string("unexpected weight: ") + name;
+    return PF_ERR_WEIGHTS;
+}
+
+int pf_engine_finalize_weights(pf_engine* e) {
+    if (!e) return PF_ERR_INVALID;
+    for (auto& ex : e->expected) {
+        auto it = e->host.find(ex.first);
+        if (it == e->host.end() || !it->second.loaded) { e->err = "missing weight: " + ex.first; return PF_ERR_WEIGHTS; }
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    e->finalized = true;
+    return PF_OK;
+}
+
+int pf_engine_set_precision(pf_engine* e, int mode) {
+    if (!e) return PF_ERR_INVALID;
+    if (mode != 0) { e->err = "only precision mode 0 (exact fp32 MFMA) is implemented"; return PF_ERR_INVALID; }
+    return PF_OK;
+}
+
+int pf_unet_forward(pf_engine* e, const float* x, const float* t, float* v, int B, void* stream) {
+    if (!e || !x || !t || !v || B <= 0) return PF_ERR_INVALID;
+    if (!e->finalized) { e->err = "weights not finalized"; return PF_ERR_STATE; }
+    HIPCHK(e, hipSetDevice(e->device));
+    Plan* plan = nullptr;
+    int rc = build_plan(e, B, &plan);
+    if (rc != PF_OK) return rc;
+    return run_plan(e, plan, x, t, v, (hipStream_t)stream);
+}
+
+int pf_engine_num_taps(const pf_engine* e) {
+    if (!e || e->plans.empty()) return 0;
+    return (int)e->plans.rbegin()->second->taps.size();
+}
+const char* pf_engine_tap_name(const pf_engine* e, int i) {
+    if (!e || e->plans.empty()) return nullptr;
+    auto& taps = e->plans.rbegin()->second->taps;
+    return (i >= 0 && i < (int)taps.size()) ? taps[i].name.c_str() : nullptr;
+}
+int pf_engine_read_tap(pf_engine* e, int i, float* host_out, int64_t capacity, int32_t dims[3], void* stream) {
+    if (!e || e->plans.empty() || !host_out || !dims) return PF_ERR_INVALID;
+    Plan* plan = e->plans.rbegin()->second.get();
+    if (i < 0 || i >= (int)plan->taps.size()) return PF_ERR_INVALID;
+    const Tensor& t = plan->taps[i].t;
+    const size_t n = (size_t)plan->B * t.C * t.H * t.W;
+    if ((int64_t)n > capacity) { e->err = "tap buffer too small"; return PF_ERR_INVALID; }
+    std::vector<float> nhwc(n);
+    HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
+    HIPCHK(e, hipMemcpy(nhwc.data(), t.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    const size_t HW = (size_t)t.H * t.W;
+    for (int b = 0; b < plan->B; ++b)
+        for (size_t p = 0; p < HW; ++p)
+            for (int c = 0; c < t.C; ++c) host_out[((size_t)b * t.C + c) * HW + p] = nhwc[((size_t)b * HW + p) * t.C + c];
+    dims[0] = t.C; dims[1] = t.H; dims[2] = t.W;
+    return PF_OK;
+}
+
+#define LAUNCHCHK(call)                                                        \
+    do { hipError_t _r = (call); if (_r != hipSuccess) return _r == hipErrorInvalidValue ? PF_ERR_INVALID : PF_ERR_HIP; } while (0)
+
+int pf_degradation_H(const pf_degradation* d, const float* x, float* y, int B, int C, int H, int W, float* scratch, void* stream) {
+    if (!d || !x || !y) return PF_ERR_INVALID;
+    LAUNCHCHK(launch_deg_H(to_view(d), x, y, B, C, H, W, scratch, (hipStream_t)stream));
+    return PF_OK;
+}
+int pf_degradation_H_adj(const pf_degradation* d, const float* y, float* x, int B, int C, int H, int W, float* scratch, void* stream) {
+    if (!d || !x || !y) return PF_ERR_INVALID;
+    LAUNCHCHK(launch_deg_Hadj(to_view(d), y, x, B, C, H, W, scratch, (hipStream_t)stream));
+    return PF_OK;
+}
+int pf_grad_step(const pf_degradation* d, const float* x, const float* y, const float* coef, float* z, int B, int C, int H, int W,
+                 float* scratch, void* stream) {
+    if (!d || !x || !y || !coef || !z) return PF_ERR_INVALID;
+    LAUNCHCHK(launch_grad_step(to_view(d), x, y, coef, z, B, C, H, W, scratch, (hipStream_t)stream));
+    return PF_OK;
+}
+int pf_interpolate(const float* z, const float* t, const float* noise, uint64_t seed, uint64_t stream_id, float* z_tilde, int B,
+                   int n_per_image, void* stream) {
+    if (!z || !t || !z_tilde) return PF_ERR_INVALID;
+    LAUNCHCHK(launch_interpolate(z, t, noise, seed, stream_id, z_tilde, B, n_per_image, (hipStream_t)stream));
+    return PF_OK;
+}
+int pf_denoise_accumulate(float* acc, const float* z_tilde, const float* v, const float* t, int mode, float num_samples, int B,
+                          int n_per_image, void* stream) {
+    if (!acc || !z_tilde || !v || !t) return PF_ERR_INVALID;
+    LAUNCHCHK(launch_denoise_accum(acc, z_tilde, v, t, mode, num_samples, B, n_per_image, (hipStream_t)stream));
+    return PF_OK;
+}
+int pf_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream) {
+    if (!out || n < 0) return PF_ERR_INVALID;
+    LAUNCHCHK(launch_fill_normal(out, n, seed, stream_id, (hipStream_t)stream));
+    return PF_OK;
+}
+int pf_psnr(const float* rec, const float* clean, float* out, int B, int n_per_image, void* stream) {
+    if (!rec || !clean || !out) return PF_ERR_INVALID;
+    LAUNCHCHK(launch_psnr(rec, clean, out, B, n_per_image, (hipStream_t)stream));
+    return PF_OK;
+}
+
+static int ensure_solver(pf_engine* e, int B, size_t n, size_t ny, int steps) {
+    SolverBufs& b = e->sb;
+    if (b.B == B && b.n == n && b.ny == ny && b.steps >= steps) return PF_OK;
+    free_solver(e);
+    const size_t tot = (size_t)B * n;
+    HIPCHK(e, hipMalloc(&b.x, tot * 4)); HIPCHK(e, hipMalloc(&b.z, tot * 4)); HIPCHK(e, hipMalloc(&b.zt, tot * 4));
+    HIPCHK(e, hipMalloc(&b.v, tot * 4)); HIPCHK(e, hipMalloc(&b.scratch, 2 * tot * 4));
+    HIPCHK(e, hipMalloc(&b.t_all, (size_t)steps * 4)); HIPCHK(e, hipMalloc(&b.coef_all, (size_t)steps * 4));
+    HIPCHK(e, hipMalloc(&b.t_cur, (size_t)B * 4)); HIPCHK(e, hipMalloc(&b.coef_cur, (size_t)B * 4));
+    HIPCHK(e, hipMalloc(&b.iter, 64));
+    b.B = B; b.n = n; b.ny = ny; b.steps = steps;
+    return PF_OK;
+}
+
+static int enqueue_iteration(pf_engine* e, Plan* plan, const DegView& dv, const pf_pnp_params* prm, const float* y, int B, int C,
+                             int H, hipStream_t s) {
+    SolverBufs& b = e->sb;
+    const int n = C * H * H;
+    hipLaunchKernelGGL(prep_iter_kernel, dim3(1), dim3(64), 0, s, (const int*)b.iter, (const float*)b.t_all, (const float*)b.coef_all,
+                       b.t_cur, b.coef_cur, B);
+    hipError_t r = launch_grad_step(dv, b.x, y, b.coef_cur, b.z, B, C, H, H, b.scratch, s);
+    if (r != hipSuccess) { e->err = std::string("grad_step: ") + hipGetErrorString(r); return PF_ERR_HIP; }
+    for (int smp = 0; smp < prm->num_samples; ++smp) {
+        r = launch_interp_iter(b.z, b.t_cur, prm->noise, prm->seed, prm->stream_base, b.iter, prm->num_samples, smp, b.zt, B, n, s);
+        if (r != hipSuccess) { e->err = std::string("interpolate: ") + hipGetErrorString(r); return PF_ERR_HIP; }
+        int rc = run_plan(e, plan, b.zt, b.t_cur, b.v, s);
+        if (rc != PF_OK) return rc;
+        const int mode = (smp == 0 ? 1 : 0) | (smp == prm->num_samples - 1 ? 2 : 0);
+        r = launch_denoise_accum(b.x, b.zt, b.v, b.t_cur, mode, (float)prm->num_samples, B, n, s);
+        if (r != hipSuccess) { e->err = std::string("denoise_accum: ") + hipGetErrorString(r); return PF_ERR_HIP; }
+    }
+    hipLaunchKernelGGL(bump_iter_kernel, dim3(1), dim3(64), 0, s, b.iter);
+    r = hipGetLastError();
+    if (r != hipSuccess) { e->err = std::string("iteration: ") + hipGetErrorString(r); return PF_ERR_HIP; }
+    return PF_OK;
+}
+
+int pf_pnp_flow_restore(pf_engine* e, const pf_degradation* d, const pf_pnp_params* prm, const float* y, float* x_out, int B,
+                        void* stream, pf_iter_callback iter_cb, void* user) {
+    if (!e || !d || !prm || !y || !x_out || B <= 0 || prm->steps <= 0 || prm->num_samples <= 0 || !prm->host_t || !prm->host_coef)
+        return PF_ERR_INVALID;
+    if (!e->finalized) { e->err = "weights not finalized"; return PF_ERR_STATE; }
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int C = e->cfg.input_channels, H = e->cfg.input_height;
+    if (e->cfg.output_channels != C) { e->err = "restoration needs output_channels == input_channels"; return PF_ERR_INVALID; }
+    const size_t n = (size_t)C * H * H;
+    const int Hy = d->kind == PF_DEG_SUPERRESOLUTION ? H / std::max(1, d->sf) : H;
+    const size_t ny = (size_t)C * Hy * Hy;
+    int rc = ensure_solver(e, B, n, ny, prm->steps);
+    if (rc != PF_OK) return rc;
+    SolverBufs& b = e->sb;
+    Plan* plan = nullptr;
+    if ((rc = build_plan(e, B, &plan)) != PF_OK) return rc;
+    const DegView dv = to_view(d);
+    HIPCHK(e, hipMemcpyAsync(b.t_all, prm->host_t, (size_t)prm->steps * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(b.coef_all, prm->host_coef, (size_t)prm->steps * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemsetAsync(b.iter, 0, 64, s));
+    // x0 = H_adj(ones_like(y))   (pnp_flow.py:93)
+    HIPCHK(e, launch_fill(b.zt, (int64_t)B * ny, 1.0f, s));
+    HIPCHK(e, launch_deg_Hadj(dv, b.zt, b.x, B, C, H, H, b.scratch, s));
+    HIPCHK(e, hipStreamSynchronize(s));   // host_t/host_coef may be freed by the caller after return; also orders the memcpys
+
+    hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
+    for (int it = 0; it < prm->steps; ++it) {
+        const bool can_graph = prm->use_graph && !e->profile;
+        if (can_graph && it >= 1) {
+            if (!gexec) {
+                // iteration 0 ran eagerly (all lazy initialisation done); capture one iteration and replay it
+                HIPCHK(e, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                rc = enqueue_iteration(e, plan, dv, prm, y, B, C, H, s);
+                hipError_t ce = hipStreamEndCapture(s, &graph);
+                if (rc != PF_OK) return rc;
+                if (ce != hipSuccess) { e->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(ce); return PF_ERR_HIP; }
+                HIPCHK(e, hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+            }
+            HIPCHK(e, hipGraphLaunch(gexec, s));
+        } else {
+            if ((rc = enqueue_iteration(e, plan, dv, prm, y, B, C, H, s)) != PF_OK) return rc;
+        }
+        if (iter_cb) {
+            HIPCHK(e, hipMemcpyAsync(x_out, b.x, (size_t)B * n * 4, hipMemcpyDeviceToDevice, s));
+            HIPCHK(e, hipStreamSynchronize(s));
+            iter_cb(it, user);
+        }
+    }
+    HIPCHK(e, hipMemcpyAsync(x_out, b.x, (size_t)B * n * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(e, hipStreamSynchronize(s));
+    if (gexec) hipGraphExecDestroy(gexec);
+    if (graph) hipGraphDestroy(graph);
+    return PF_OK;
+}
+
+int pf_engine_profile(pf_engine* e, int enable) {
+    if (!e) return PF_ERR_INVALID;
+    e->profile = enable != 0;
+    e->ev_used = 0; e->prof_launches = 0; e->prof_ms = 0.0; e->prof_flops = 0.0;
+    return PF_OK;
+}
+
+int pf_engine_profile_read(pf_engine* e, int64_t* launches, double* ms_conv_gemm, double* flops_conv_gemm) {
+    if (!e) return PF_ERR_INVALID;
+    HIPCHK(e, hipDeviceSynchronize());
+    for (size_t i = 0; i < e->ev_used; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e->ev_pool[i].first, e->ev_pool[i].second) == hipSuccess) { e->prof_ms += ms; e->prof_launches += 1; }
+    }
+    e->ev_used = 0;
+    if (launches) *launches = e->prof_launches;
+    if (ms_conv_gemm) *ms_conv_gemm = e->prof_ms;
+    if (flops_conv_gemm) *flops_conv_gemm = e->prof_flops;
+    return PF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// Internal declarations shared by the engine (host) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pf {
+
+// One K-segment of the implicit GEMM: a source activation tensor (NHWC) plus the
+// slice of the weights that multiplies it.
+struct ConvSeg {
+    const float* src;     // NHWC [B][Hs][Ws][cstride], channels [coff, coff+C) are used
+    int C;                // channels contributed by this segment (GEMM K = taps*C)
+    int cstride;          // floats per pixel in src
+    int coff;             // first channel inside the pixel vector
+    int xform;            // 0 raw, 1 GroupNorm, 2 GroupNorm+SiLU  (applied while staging)
+    int taps;             // 9 (3x3, pad 1) or 1 (1x1 / plain GEMM)
+    int gn_off;           // index of this segment's channel 0 in the GroupNorm channel space
+    const double* stats;  // [B][C][2] per-channel (sum, sumsq) of src, or nullptr
+    const float* w;       // weights
+    int w_mode;           // 0: k-contiguous  addr = b*w_bs + chunk*w_cs + tap*w_ts + n*w_ns + kk
+                          // 1: n-contiguous  addr = b*w_bs + k*w_ks + n      (k = chunk*KC+kk)
+    int64_t w_bs, w_cs, w_ts, w_ns, w_ks;
+};
+
+struct ConvParams {
+    ConvSeg seg[3];
+    int nseg;
+    int B, H, W;          // output spatial size
+    int Hs, Ws;           // source spatial size (H*2 for stride 2; H/2 for fused nearest-up)
+    int Cout;
+    float* out;           // NHWC [B][H][W][out_cstride]
+    int out_cstride;
+    const float* addvec;  // bias (+ time-embedding projection): [b*addvec_bs + n], or nullptr
+    int addvec_bs;
+    const float* residual;  // NHWC, added in the epilogue, or nullptr
+    int res_cstride;
+    double* stats_out;    // [B][Cout][2] += per-channel (sum, sumsq) of the result, or nullptr
+    float out_scale;      // applied to the accumulator before bias/residual
+    // GroupNorm of the (concatenated) transformed segments
+    int gn_C;             // total normalised channels (0 = no GN)
+    int gn_cpg;           // channels per group
+    float gn_eps;
+    const float* gamma;   // [gn_C]
+    const float* beta;
+};
+
+constexpr int CONV_KC = 16;   // channels per K-chunk staged in LDS
+
+// direct (VALU) convolutions at the image boundary of the network
+struct EdgeConvParams {
+    const float* in;      // begin: NCHW image [B][Cimg][H][W];   end: NHWC [B][H][W][C]
+    float* out;           // begin: NHWC [B][H][W][C];            end: NCHW image
+    const float* w;       // begin: [tap][cimg][C]  end: [tap][cimg][C]  (C innermost)
+    const float* bias;
+    int B, H, W, Cimg, C;
+    // end conv only: GroupNorm+SiLU of the input
+    const double* stats; const float* gamma; const float* beta; int gn_cpg; float gn_eps;
+    double* stats_out;    // begin conv: per-channel stats of the output
+};
+
+struct TembParams {
+    const float* t;         // [B]
+    const float* w0; const float* b0;   // Linear(ch -> 4ch)     (out,in)
+    const float* w1; const float* b1;   // Linear(4ch -> 4ch)
+    const float* wp;        // all temb_proj weights stacked: [total_out][4ch]
+    const float* bp;        // stacked (temb_proj.bias + conv1.bias): [total_out]
+    float* out;             // [B][total_out]
+    int B, ch, total_out;
+};
+
+hipError_t launch_conv(const ConvParams& p, int stride, int up, hipStream_t s);
+size_t conv_flops(const ConvParams& p);
+hipError_t launch_begin_conv(const EdgeConvParams& p, hipStream_t s);
+hipError_t launch_end_conv(const EdgeConvParams& p, hipStream_t s);
+hipError_t launch_temb(const TembParams& p, hipStream_t s);
+hipError_t launch_softmax_rows(float* data, int64_t rows, int cols, hipStream_t s);
+hipError_t launch_channel_stats(const float* x, double* stats, int B, int HW, int C, hipStream_t s);
+
+// pointwise / operator kernels (NCHW fp32 images)
+struct DegView {       // device-side view of pf_degradation
+    int kind, half, sf, ntaps;
+    const uint8_t* mask;
+    const float* taps;
+};
+hipError_t launch_deg_H(const DegView& d, const float* x, float* y, int B, int C, int H, int W, float* scratch, hipStream_t s);
+hipError_t launch_deg_Hadj(const DegView& d, const float* y, float* x, int B, int C, int H, int W, float* scratch, hipStream_t s);
+hipError_t launch_grad_step(const DegView& d, const float* x, const float* y, const float* coef, float* z,
+                            int B, int C, int H, int W, float* scratch, hipStream_t s);
+hipError_t launch_interpolate(const float* z, const float* t, const float* noise, uint64_t seed, uint64_t stream_id,
+                              float* zt, int B, int n, hipStream_t s);
+hipError_t launch_interp_iter(const float* z, const float* t, const float* noise, uint64_t seed, uint64_t stream_base,
+                              const int* iter, int num_samples, int sample, float* zt, int B, int n, hipStream_t s);
+hipError_t launch_denoise_accum(float* acc, const float* zt, const float* v, const float* t, int mode, float ns,
+                                int B, int n, hipStream_t s);
+hipError_t launch_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, hipStream_t s);
+hipError_t launch_psnr(const float* rec, const float* clean, float* out, int B, int n, hipStream_t s);
+hipError_t launch_fill(float* out, int64_t n, float v, hipStream_t s);
+
+}  // namespace pf

@@ -1,0 +1,359 @@
+// HBM-bound per-pixel kernels of the PnP-Flow iteration and of the degradation
+// operators (NCHW fp32 images).  Reference: pnpflow/methods/pnp_flow.py:39-52,109-121,
+// pnpflow/degradations.py:15-127, pnpflow/utils.py:283-361, 560-611.
+#include <algorithm>
+#include "pf_common.h"
+
+namespace pf {
+
+enum { DEG_DENOISE = 0, DEG_BOX = 1, DEG_MASK = 2, DEG_SR = 3, DEG_BLUR = 4 };
+
+// ---- mask value of the inpainting family at (b, y, x) -----------------------------------
+__device__ __forceinline__ float mask_at(const DegView& d, int b, int y, int x, int H, int W) {
+    if (d.kind == DEG_BOX) {
+        const int c = H / 2;   // square_mask uses x.shape[2]//2 for both axes (utils.py:331)
+        return (y >= c - d.half && y < c + d.half && x >= c - d.half && x < c + d.half) ? 0.f : 1.f;
+    }
+    if (d.kind == DEG_MASK) return (float)d.mask[((size_t)b * H + y) * W + x];
+    return 1.f;
+}
+
+// y = M*x (H and H_adj of the mask family, identity for denoising)
+__global__ __launch_bounds__(256) void mask_apply_kernel(DegView d, const float* x, float* y, int C, int H, int W) {
+    const int b = blockIdx.y;
+    const int n = C * H * W;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int px = i % W, py = (i / W) % H;
+        y[(size_t)b * n + i] = mask_at(d, b, py, px, H, W) * x[(size_t)b * n + i];
+    }
+}
+
+// Superresolution H: y[.., i, j] = x[.., sf*i, sf*j]   (utils.py:302-310)
+__global__ __launch_bounds__(256) void decimate_kernel(const float* x, float* y, int planes, int H, int W, int sf) {
+    const int Hy = H / sf, Wy = W / sf;
+    const size_t n = (size_t)planes * Hy * Wy;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int j = i % Wy, r = (i / Wy) % Hy;
+        const size_t pl = i / ((size_t)Wy * Hy);
+        y[i] = x[(pl * H + (size_t)r * sf) * W + (size_t)j * sf];
+    }
+}
+
+// Superresolution H_adj: zero-fill upsample (utils.py:283-299)
+__global__ __launch_bounds__(256) void zerofill_kernel(const float* y, float* x, int planes, int H, int W, int sf) {
+    const int Wy = W / sf, Hy = H / sf;
+    const size_t n = (size_t)planes * H * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int px = i % W, py = (i / W) % H;
+        const size_t pl = i / ((size_t)W * H);
+        float v = 0.f;
+        if (py % sf == 0 && px % sf == 0) v = y[(pl * Hy + py / sf) * Wy + px / sf];
+        x[i] = v;
+    }
+}
+
+// One pass of the separable circular Gaussian (degradations.py:55-89: the FFT product
+// with the rolled 61x61 filter is a circular convolution with outer(g,g)).
+//   dir 0: along x, dir 1: along y;  sign +1: convolution (H), -1: correlation (H_adj)
+//   mode 0: out = val;  1: out = val - aux[i];  2: out = aux[i] - coef[b]*val
+__global__ __launch_bounds__(256) void blur_pass_kernel(const float* in, float* out, const float* taps, int ntaps,
+                                                        int C, int H, int W, int dir, int sign, int mode,
+                                                        const float* aux, const float* coef) {
+    __shared__ float s_g[128];
+    if (threadIdx.x < ntaps) s_g[threadIdx.x] = taps[threadIdx.x];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int n = C * H * W;
+    const int r = (ntaps - 1) / 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int px = i % W, py = (i / W) % H, pl = i / (W * H);
+        const float* src = in + ((size_t)b * C + pl) * H * W;
+        float acc = 0.f;
+        if (dir == 0) {
+            const float* row = src + (size_t)py * W;
+            for (int k = 0; k < ntaps; ++k) {
+                int xx = (px - sign * (k - r)) % W;
+                xx += xx < 0 ? W : 0;
+                acc = fmaf(s_g[k], row[xx], acc);
+            }
+        } else {
+            for (int k = 0; k < ntaps; ++k) {
+                int yy = (py - sign * (k - r)) % H;
+                yy += yy < 0 ? H : 0;
+                acc = fmaf(s_g[k], src[(size_t)yy * W + px], acc);
+            }
+        }
+        const size_t o = (size_t)b * n + i;
+        if (mode == 1) acc = acc - aux[o];
+        else if (mode == 2) acc = aux[o] - coef[b] * acc;
+        out[o] = acc;
+    }
+}
+
+static inline dim3 grid_for(int n_per_image, int B) {
+    int gx = (n_per_image + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    return dim3(gx, B);
+}
+
+static hipError_t blur2(const DegView& d, const float* in, float* tmp, float* out, int B, int C, int H, int W, int sign,
+                        int mode, const float* aux, const float* coef, hipStream_t s) {
+    dim3 g = grid_for(C * H * W, B);
+    hipLaunchKernelGGL(blur_pass_kernel, g, dim3(256), 0, s, in, tmp, d.taps, d.ntaps, C, H, W, 0, sign, 0, (const float*)nullptr, (const float*)nullptr);
+    hipLaunchKernelGGL(blur_pass_kernel, g, dim3(256), 0, s, (const float*)tmp, out, d.taps, d.ntaps, C, H, W, 1, sign, mode, aux, coef);
+    return hipGetLastError();
+}
+
+hipError_t launch_deg_H(const DegView& d, const float* x, float* y, int B, int C, int H, int W, float* scratch, hipStream_t s) {
+    switch (d.kind) {
+        case DEG_DENOISE: case DEG_BOX: case DEG_MASK:
+            hipLaunchKernelGGL(mask_apply_kernel, grid_for(C * H * W, B), dim3(256), 0, s, d, x, y, C, H, W);
+            return hipGetLastError();
+        case DEG_SR: {
+            if (d.sf <= 0 || H % d.sf || W % d.sf) return hipErrorInvalidValue;
+            const size_t n = (size_t)B * C * (H / d.sf) * (W / d.sf);
+            hipLaunchKernelGGL(decimate_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, s, x, y, B * C, H, W, d.sf);
+            return hipGetLastError();
+        }
+        case DEG_BLUR:
+            if (!scratch || d.ntaps > 127 || !(d.ntaps & 1)) return hipErrorInvalidValue;
+            return blur2(d, x, scratch, y, B, C, H, W, +1, 0, nullptr, nullptr, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_deg_Hadj(const DegView& d, const float* y, float* x, int B, int C, int H, int W, float* scratch, hipStream_t s) {
+    switch (d.kind) {
+        case DEG_DENOISE: case DEG_BOX: case DEG_MASK:
+            hipLaunchKernelGGL(mask_apply_kernel, grid_for(C * H * W, B), dim3(256), 0, s, d, y, x, C, H, W);
+            return hipGetLastError();
+        case DEG_SR: {
+            if (d.sf <= 0 || H % d.sf || W % d.sf) return hipErrorInvalidValue;
+            const size_t n = (size_t)B * C * H * W;
+            hipLaunchKernelGGL(zerofill_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, s, y, x, B * C, H, W, d.sf);
+            return hipGetLastError();
+        }
+        case DEG_BLUR:
+            if (!scratch || d.ntaps > 127 || !(d.ntaps & 1)) return hipErrorInvalidValue;
+            return blur2(d, y, scratch, x, B, C, H, W, -1, 0, nullptr, nullptr, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---- fused data-fidelity gradient step: z = x - coef[b] * H_adj(H x - y) -------------------
+// (pnp_flow.py:39-41 with lr = sigma^2*lr_pnp, :109-112; sigma^2 is folded into coef.)
+__global__ __launch_bounds__(256) void grad_step_mask_kernel(DegView d, const float* x, const float* y, const float* coef,
+                                                             float* z, int C, int H, int W) {
+    const int b = blockIdx.y;
+    const int n = C * H * W;
+    const float cf = coef[b];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int px = i % W, py = (i / W) % H;
+        const float m = mask_at(d, b, py, px, H, W);
+        const size_t o = (size_t)b * n + i;
+        const float xv = x[o];
+        z[o] = xv - cf * (m * (m * xv - y[o]));
+    }
+}
+
+__global__ __launch_bounds__(256) void grad_step_sr_kernel(const float* x, const float* y, const float* coef, float* z,
+                                                           int C, int H, int W, int sf) {
+    const int b = blockIdx.y;
+    const int n = C * H * W, Hy = H / sf, Wy = W / sf;
+    const float cf = coef[b];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int px = i % W, py = (i / W) % H, pl = i / (W * H);
+        const size_t o = (size_t)b * n + i;
+        const float xv = x[o];
+        float g = 0.f;
+        if (py % sf == 0 && px % sf == 0) g = xv - y[(((size_t)b * C + pl) * Hy + py / sf) * Wy + px / sf];
+        z[o] = xv - cf * g;
+    }
+}
+
+hipError_t launch_grad_step(const DegView& d, const float* x, const float* y, const float* coef, float* z,
+                            int B, int C, int H, int W, float* scratch, hipStream_t s) {
+    dim3 g = grid_for(C * H * W, B);
+    switch (d.kind) {
+        case DEG_DENOISE: case DEG_BOX: case DEG_MASK:
+            hipLaunchKernelGGL(grad_step_mask_kernel, g, dim3(256), 0, s, d, x, y, coef, z, C, H, W);
+            return hipGetLastError();
+        case DEG_SR:
+            if (d.sf <= 0 || H % d.sf || W % d.sf) return hipErrorInvalidValue;
+            hipLaunchKernelGGL(grad_step_sr_kernel, g, dim3(256), 0, s, x, y, coef, z, C, H, W, d.sf);
+            return hipGetLastError();
+        case DEG_BLUR: {
+            if (!scratch || d.ntaps > 127 || !(d.ntaps & 1)) return hipErrorInvalidValue;
+            float* s0 = scratch;
+            float* s1 = scratch + (size_t)B * C * H * W;
+            hipError_t e = blur2(d, x, s0, s1, B, C, H, W, +1, 1, y, nullptr, s);     // s1 = Hx - y
+            if (e != hipSuccess) return e;
+            return blur2(d, s1, s0, z, B, C, H, W, -1, 2, x, coef, s);                 // z = x - coef*H_adj(s1)
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---- engine RNG: Philox4x32-10 + Box-Muller (restated in oracle/pnpflow_oracle.py) ----------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                               uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float4 normal4(uint32_t q, uint64_t seed, uint64_t stream) {
+    uint32_t r[4];
+    philox4x32_10(q, 0u, (uint32_t)stream, (uint32_t)(stream >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const float k = 2.3283064365386963e-10f;  // 2^-32
+    const float u0 = ((float)r[0] + 0.5f) * k, u1 = ((float)r[1] + 0.5f) * k;
+    const float u2 = ((float)r[2] + 0.5f) * k, u3 = ((float)r[3] + 0.5f) * k;
+    const float rad0 = sqrtf(-2.0f * logf(u0)), rad1 = sqrtf(-2.0f * logf(u2));
+    float s0, c0, s1, c1;
+    sincosf(6.283185307179586f * u1, &s0, &c0);
+    sincosf(6.283185307179586f * u3, &s1, &c1);
+    return make_float4(rad0 * c0, rad0 * s0, rad1 * c1, rad1 * s1);
+}
+
+__global__ __launch_bounds__(256) void fill_normal_kernel(float* out, int64_t n, uint64_t seed, uint64_t stream) {
+    const int64_t nq = (n + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
+        const float4 z = normal4((uint32_t)q, seed, stream);
+        const float zz[4] = {z.x, z.y, z.z, z.w};
+        for (int j = 0; j < 4; ++j)
+            if (q * 4 + j < n) out[q * 4 + j] = zz[j];
+    }
+}
+
+hipError_t launch_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, hipStream_t s) {
+    const int64_t nq = (n + 3) / 4;
+    hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)std::min<int64_t>((nq + 255) / 256, 4096)), dim3(256), 0, s, out, n, seed, stream_id);
+    return hipGetLastError();
+}
+
+// z_tilde = t*z + (1-t)*eps   (pnp_flow.py:47-48).  The batch is one flat noise stream:
+// element e of the [B*n] tensor uses normal number e of stream `stream_id`.
+__global__ __launch_bounds__(256) void interpolate_kernel(const float* z, const float* t, const float* noise, uint64_t seed,
+                                                          uint64_t stream, float* zt, int n, int64_t total) {
+    const int64_t nq = (total + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
+        float e[4];
+        if (noise != nullptr) {
+            for (int j = 0; j < 4; ++j) e[j] = (q * 4 + j < total) ? noise[q * 4 + j] : 0.f;
+        } else {
+            const float4 zz = normal4((uint32_t)q, seed, stream);
+            e[0] = zz.x; e[1] = zz.y; e[2] = zz.z; e[3] = zz.w;
+        }
+        for (int j = 0; j < 4; ++j) {
+            const int64_t i = q * 4 + j;
+            if (i < total) {
+                const float tb = t[i / n];
+                zt[i] = tb * z[i] + e[j] * (1.0f - tb);
+            }
+        }
+    }
+}
+
+hipError_t launch_interpolate(const float* z, const float* t, const float* noise, uint64_t seed, uint64_t stream_id,
+                              float* zt, int B, int n, hipStream_t s) {
+    const int64_t total = (int64_t)B * n, nq = (total + 3) / 4;
+    hipLaunchKernelGGL(interpolate_kernel, dim3((unsigned)std::min<int64_t>((nq + 255) / 256, 4096)), dim3(256), 0, s,
+                       z, t, noise, seed, stream_id, zt, n, total);
+    return hipGetLastError();
+}
+
+// Same, with the noise stream / injected-noise slice of (iteration, sample) resolved from a
+// device-side iteration counter, so one captured hipGraph serves every outer iteration.
+__global__ __launch_bounds__(256) void interp_iter_kernel(const float* z, const float* t, const float* noise, uint64_t seed,
+                                                          uint64_t stream_base, const int* iter, int num_samples, int sample,
+                                                          float* zt, int n, int64_t total) {
+    const int64_t slot = (int64_t)(*iter) * num_samples + sample;
+    const uint64_t stream = stream_base + (uint64_t)slot;
+    const float* nz = noise != nullptr ? noise + slot * total : nullptr;
+    const int64_t nq = (total + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
+        float e[4];
+        if (nz != nullptr) {
+            for (int j = 0; j < 4; ++j) e[j] = (q * 4 + j < total) ? nz[q * 4 + j] : 0.f;
+        } else {
+            const float4 zz = normal4((uint32_t)q, seed, stream);
+            e[0] = zz.x; e[1] = zz.y; e[2] = zz.z; e[3] = zz.w;
+        }
+        for (int j = 0; j < 4; ++j) {
+            const int64_t i = q * 4 + j;
+            if (i < total) {
+                const float tb = t[i / n];
+                zt[i] = tb * z[i] + e[j] * (1.0f - tb);
+            }
+        }
+    }
+}
+
+hipError_t launch_interp_iter(const float* z, const float* t, const float* noise, uint64_t seed, uint64_t stream_base,
+                              const int* iter, int num_samples, int sample, float* zt, int B, int n, hipStream_t s) {
+    const int64_t total = (int64_t)B * n, nq = (total + 3) / 4;
+    hipLaunchKernelGGL(interp_iter_kernel, dim3((unsigned)std::min<int64_t>((nq + 255) / 256, 4096)), dim3(256), 0, s,
+                       z, t, noise, seed, stream_base, iter, num_samples, sample, zt, n, total);
+    return hipGetLastError();
+}
+
+// acc (=|+=) z_tilde + (1-t)*v ; last sample: acc /= num_samples  (pnp_flow.py:50-52,114-121)
+__global__ __launch_bounds__(256) void denoise_accum_kernel(float* acc, const float* zt, const float* v, const float* t,
+                                                            int mode, float ns, int n, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const float tb = t[i / n];
+        float val = zt[i] + (1.0f - tb) * v[i];
+        if (!(mode & 1)) val = acc[i] + val;
+        if (mode & 2) val = val / ns;
+        acc[i] = val;
+    }
+}
+
+hipError_t launch_denoise_accum(float* acc, const float* zt, const float* v, const float* t, int mode, float ns,
+                                int B, int n, hipStream_t s) {
+    const int64_t total = (int64_t)B * n;
+    hipLaunchKernelGGL(denoise_accum_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s,
+                       acc, zt, v, t, mode, ns, n, total);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* out, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = v;
+}
+
+hipError_t launch_fill(float* out, int64_t n, float v, hipStream_t s) {
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, out, n, v);
+    return hipGetLastError();
+}
+
+// per-image PSNR, data range 1, after postprocess (x+1)/2 (utils.py:560-577, 610)
+__global__ __launch_bounds__(1024) void psnr_kernel(const float* rec, const float* clean, float* out, int n) {
+    __shared__ double s_red[1024];
+    const int b = blockIdx.x;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float a = (rec[(size_t)b * n + i] + 1.0f) * 0.5f, c = (clean[(size_t)b * n + i] + 1.0f) * 0.5f;
+        const float dlt = a - c;
+        acc += (double)(dlt * dlt);
+    }
+    s_red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[b] = (float)(10.0 * log10(1.0 / (s_red[0] / (double)n)));
+}
+
+hipError_t launch_psnr(const float* rec, const float* clean, float* out, int B, int n, hipStream_t s) {
+    hipLaunchKernelGGL(psnr_kernel, dim3(B), dim3(1024), 0, s, rec, clean, out, n);
+    return hipGetLastError();
+}
+
+}  // namespace pf

@@ -1,0 +1,173 @@
+"""Degradation operators with the API of pnpflow/degradations.py (reference :6-127):
+`Degradation.H(x)`, `.H_adj(x)` on (B,C,H,W) fp32 GPU tensors, executed by the HIP
+kernels in csrc/pointwise.hip.  Each operator also exposes `descriptor(B, H, W, device)`,
+the pf_degradation record the fused solver kernels consume.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _scratch(x):
+    return torch.empty_like(x)
+
+
+class Degradation:
+    kind = None
+
+    def H(self, x):
+        raise NotImplementedError()
+
+    def H_adj(self, x):
+        raise NotImplementedError()
+
+    # -- engine side -----------------------------------------------------------------------
+    def descriptor(self, B, H, W, device):
+        raise NotImplementedError()
+
+    def _apply(self, x, adjoint: bool, out_hw=None):
+        if not x.is_cuda:
+            raise _lib.PnpFlowHipError("degradation operators need GPU tensors (there is no CPU path)")
+        lib = _lib.load()
+        x = x.contiguous().float()
+        B, Cc = x.shape[0], x.shape[1]
+        Hf, Wf = out_hw if out_hw is not None else (x.shape[2], x.shape[3])   # full-resolution size
+        d = self.descriptor(B, Hf, Wf, x.device)
+        if adjoint:
+            out = torch.empty((B, Cc, Hf, Wf), dtype=torch.float32, device=x.device)
+        else:
+            sf = getattr(self, "sf", 1) if self.kind == _lib.PF_DEG_SUPERRESOLUTION else 1
+            out = torch.empty((B, Cc, Hf // sf, Wf // sf), dtype=torch.float32, device=x.device)
+        scratch = torch.empty((B, Cc, Hf, Wf), dtype=torch.float32, device=x.device) if self.kind == _lib.PF_DEG_GAUSSIAN_BLUR else None
+        fn = lib.pf_degradation_H_adj if adjoint else lib.pf_degradation_H
+        _lib.check(fn(C.byref(d), x.data_ptr(), out.data_ptr(), B, Cc, Hf, Wf,
+                      scratch.data_ptr() if scratch is not None else None, _lib.current_stream_ptr()), None, fn.__name__)
+        return out
+
+
+class Denoising(Degradation):
+    """reference pnpflow/degradations.py:15-20"""
+    kind = _lib.PF_DEG_DENOISING
+
+    def descriptor(self, B, H, W, device):
+        d = _lib.PfDegradation(); d.kind = self.kind
+        return d
+
+    def H(self, x):
+        return x
+
+    def H_adj(self, x):
+        return x
+
+
+class BoxInpainting(Degradation):
+    """reference pnpflow/degradations.py:23-32 (mask: utils.py:327-336)"""
+    kind = _lib.PF_DEG_BOX_INPAINTING
+
+    def __init__(self, half_size_mask):
+        super().__init__()
+        self.half_size_mask = half_size_mask
+
+    def descriptor(self, B, H, W, device):
+        d = _lib.PfDegradation(); d.kind = self.kind; d.half_size_mask = int(self.half_size_mask)
+        return d
+
+    def H(self, x):
+        return self._apply(x, False)
+
+    def H_adj(self, x):
+        return self._apply(x, True)
+
+
+class RandomInpainting(Degradation):
+    """reference pnpflow/degradations.py:35-44.  The mask is the reference's
+    np.random.seed(42); binomial(1, 1-p, (B,H,W)) bit pattern (utils.py:357-359),
+    generated ONCE per (global batch, H, W) instead of on every H/H_adj call and, for
+    multi-GPU shards, sliced [offset, offset+B) out of the global-batch draw (the draw is
+    prefix-consistent in B)."""
+    kind = _lib.PF_DEG_MASK_INPAINTING
+
+    def __init__(self, p, global_batch=None, batch_offset=0):
+        super().__init__()
+        self.p = p
+        self.global_batch, self.batch_offset = global_batch, batch_offset
+        self._cache = {}
+
+    def mask(self, B, H, W, device):
+        key = (B, H, W, str(device))
+        if key not in self._cache:
+            G = self.global_batch if self.global_batch is not None else B + self.batch_offset
+            m = np.random.RandomState(42).binomial(n=1, p=1 - self.p, size=(G, H, W))
+            m = m[self.batch_offset:self.batch_offset + B].astype(np.uint8)
+            self._cache[key] = torch.from_numpy(np.ascontiguousarray(m)).to(device)
+        return self._cache[key]
+
+    def descriptor(self, B, H, W, device):
+        d = _lib.PfDegradation(); d.kind = self.kind
+        d.mask = self.mask(B, H, W, device).data_ptr()
+        return d
+
+    def H(self, x):
+        return self._apply(x, False)
+
+    def H_adj(self, x):
+        return self._apply(x, True)
+
+
+class GaussianDeblurring(Degradation):
+    """reference pnpflow/degradations.py:55-89, mode 'fft': circular convolution with the
+    61x61 normalised Gaussian (utils.py:273-280).  The kernel is exactly separable, so the
+    engine runs two 1-D circular passes instead of three FFTs per call."""
+    kind = _lib.PF_DEG_GAUSSIAN_BLUR
+
+    def __init__(self, sigma_blur, kernel_size, mode="fft", num_channels=3, dim_image=128, device="cuda"):
+        super().__init__()
+        if mode != "fft":
+            raise NotImplementedError("only the circular ('fft') mode used by main.py is implemented")
+        self.mode, self.sigma, self.kernel_size = mode, sigma_blur, kernel_size
+        ax = np.arange(-kernel_size // 2 + 1.0, kernel_size // 2 + 1.0)
+        g = np.exp(-(ax ** 2) / (2 * sigma_blur ** 2))
+        self.taps_host = (g / g.sum()).astype(np.float32)
+        self._taps = {}
+
+    def descriptor(self, B, H, W, device):
+        key = str(device)
+        if key not in self._taps:
+            self._taps[key] = torch.from_numpy(self.taps_host).to(device)
+        d = _lib.PfDegradation(); d.kind = self.kind; d.ntaps = int(self.kernel_size)
+        d.taps = self._taps[key].data_ptr()
+        return d
+
+    def H(self, x):
+        return self._apply(x, False)
+
+    def H_adj(self, x):
+        return self._apply(x, True)
+
+
+class Superresolution(Degradation):
+    """reference pnpflow/degradations.py:92-127 with mode=None (main.py:165):
+    H = x[..., ::sf, ::sf], H_adj = zero-fill.  The dense (HW/sf^2, HW) matrix the reference
+    builds in the constructor is only read by ot_ode and is not materialised here."""
+    kind = _lib.PF_DEG_SUPERRESOLUTION
+
+    def __init__(self, sf, dim_image, mode=None, device="cuda"):
+        super().__init__()
+        if mode is not None:
+            raise NotImplementedError("bicubic superresolution is not implemented (main.py uses mode=None)")
+        self.sf, self.dim_image, self.mode = sf, dim_image, mode
+
+    def descriptor(self, B, H, W, device):
+        d = _lib.PfDegradation(); d.kind = self.kind; d.sf = int(self.sf)
+        return d
+
+    def H(self, x):
+        return self._apply(x, False)
+
+    def H_adj(self, x):
+        return self._apply(x, True, out_hw=(x.shape[2] * self.sf, x.shape[3] * self.sf))

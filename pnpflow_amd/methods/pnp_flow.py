@@ -1,0 +1,172 @@
+"""PNP_FLOW solver with the API of pnpflow/methods/pnp_flow.py (reference :10-188).
+
+`solve_ip` keeps the reference's control flow (loader protocol, seeds, args mutation,
+metric cadence) and hands each batch's inner loop (pnp_flow.py:93, 102-121) to the HIP
+engine: pf_pnp_flow_restore runs gradient step -> interpolate -> U-Net -> average for
+all iterations, one hipGraph replay per outer iteration.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from time import perf_counter
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .. import utils
+
+
+class PNP_FLOW(object):
+
+    def __init__(self, model, device, args):
+        self.device = device
+        self.args = args
+        self.model = model.to(device)
+        self.method = args.method
+        self.coupling = self.args.model
+        self.lib = _lib.load()
+        # engine options (not in the reference): injected interpolation noise for parity runs,
+        # Philox seed for throughput runs, hipGraph on/off
+        self.noise = None          # optional (steps*num_samples, B, C, H, W) GPU tensor
+        self.noise_seed = 0
+        self.use_graph = True
+        self.last_restored = None  # the final x of the last batch (the reference only writes it to disk)
+        self.measurement_noise = None   # optional override of the torch.manual_seed(batch) draw (multi-GPU shards)
+
+    # ---- the reference's small methods, kept for API parity ---------------------------------
+    def model_forward(self, x, t):
+        if self.coupling in {"ot", "indep"}:
+            return self.model(x, t)
+        raise NotImplementedError("only the 'ot'/'indep' U-Net is implemented")
+
+    def learning_rate_strat(self, lr, t):
+        t = t.view(-1, 1, 1, 1)
+        style = self.args.gamma_style
+        if style == '1_minus_t':
+            return lr * (1 - t)
+        if style == 'sqrt_1_minus_t':
+            return lr * torch.sqrt(1 - t)
+        if style == 'alpha_1_minus_t':
+            return lr * (1 - t) ** self.args.alpha
+        return lr * torch.ones_like(t) if style == 'constant' else lr
+
+    def grad_datafit(self, x, y, H, H_adj):
+        if self.args.noise_type == 'gaussian':
+            return H_adj(H(x) - y) / (self.args.sigma_noise ** 2)
+        raise ValueError('Noise type not supported')
+
+    def interpolation_step(self, x, t):
+        eps = torch.empty_like(x)
+        _lib.check(self.lib.pf_fill_normal(eps.data_ptr(), eps.numel(), self.noise_seed, 0, _lib.current_stream_ptr()), None, "pf_fill_normal")
+        return t * x + eps * (1 - t)
+
+    def denoiser(self, x, t):
+        v = self.model_forward(x, t)
+        return x + (1 - t.view(-1, 1, 1, 1)) * v
+
+    # ---- schedule scalars, computed with the reference's own fp32 expressions ------------------
+    def _schedule(self, steps, lr, sigma_noise):
+        delta = 1 / steps
+        t_vals = np.empty(steps, dtype=np.float32)
+        coef = np.empty(steps, dtype=np.float32)
+        for it in range(int(steps)):
+            t1 = torch.ones(1) * delta * it                          # pnp_flow.py:107-108
+            lr_t = self.learning_rate_strat(lr, t1)                  # :109
+            if not torch.is_tensor(lr_t):
+                lr_t = torch.tensor([float(lr_t)])
+            t_vals[it] = float(t1[0])
+            coef[it] = float(lr_t.reshape(-1)[0]) / (sigma_noise ** 2)
+        return t_vals, coef
+
+    def restore_batch(self, noisy_img, degradation, sigma_noise, lr, iter_cb=None):
+        """Inner loop of solve_ip for one batch on the engine.  Returns x (B,C,H,W)."""
+        args = self.args
+        steps, ns = int(args.steps_pnp), int(args.num_samples)
+        B = noisy_img.shape[0]
+        Cc, Hh = self.model.input_channels, self.model.input_height
+        t_vals, coef = self._schedule(steps, lr, sigma_noise)
+        d = degradation.descriptor(B, Hh, Hh, noisy_img.device)
+        prm = _lib.PfPnpParams()
+        prm.steps, prm.num_samples = steps, ns
+        prm.host_t = t_vals.ctypes.data_as(C.POINTER(C.c_float))
+        prm.host_coef = coef.ctypes.data_as(C.POINTER(C.c_float))
+        prm.seed = int(self.noise_seed)
+        prm.stream_base = 1 + (int(getattr(args, "batch", 0)) << 32)
+        if self.noise is not None:
+            nz = self.noise.contiguous().float()
+            assert nz.numel() == steps * ns * B * Cc * Hh * Hh
+            prm.noise = nz.data_ptr()
+        prm.use_graph = 1 if self.use_graph else 0
+        x = torch.empty((B, Cc, Hh, Hh), dtype=torch.float32, device=noisy_img.device)
+        y = noisy_img.contiguous().float()
+        holder = {}
+        if iter_cb is not None:
+            def _cb(it, user):
+                iter_cb(it, x)
+            cb = _lib.ITER_CB(_cb)
+        else:
+            cb = C.cast(None, _lib.ITER_CB)
+        holder["cb"] = cb
+        _lib.check(self.lib.pf_pnp_flow_restore(self.model.handle, C.byref(d), C.byref(prm), y.data_ptr(), x.data_ptr(), B,
+                                                _lib.current_stream_ptr(), cb, None), self.model.handle, "pf_pnp_flow_restore")
+        return x
+
+    def solve_ip(self, test_loader, degradation, sigma_noise, H_funcs=None):
+        H = degradation.H
+        H_adj = degradation.H_adj
+        self.args.sigma_noise = sigma_noise
+        steps = self.args.steps_pnp
+        if self.args.noise_type == 'gaussian':
+            self.args.lr_pnp = sigma_noise ** 2 * self.args.lr_pnp      # in place, as the reference (pnp_flow.py:61)
+            lr = self.args.lr_pnp
+        else:
+            raise ValueError('Noise type not supported')
+
+        loader = iter(test_loader)
+        for batch in range(self.args.max_batch):
+            (clean_img, labels) = next(loader)
+            self.args.batch = batch
+            noisy_img = H(clean_img.clone().to(self.device))
+            if self.measurement_noise is not None:
+                noise = self.measurement_noise(batch, noisy_img)
+            else:
+                # the reference draws on the device generator after torch.manual_seed(batch)
+                # (pnp_flow.py:79-80); here the draw is made on the CPU generator so that it is
+                # reproducible on any device, then moved.
+                torch.manual_seed(batch)
+                noise = torch.randn(noisy_img.shape, dtype=torch.float32).to(self.device)
+            noisy_img = noisy_img + noise * sigma_noise
+            clean_img = clean_img.to('cpu')
+
+            if self.args.compute_time:
+                torch.cuda.synchronize()
+                t0 = perf_counter()
+
+            def on_iter(iteration, x):
+                if self.args.save_results and (iteration % 50 == 0 or self.should_save_image(iteration, steps)):
+                    utils.compute_psnr(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=iteration)
+
+            x = self.restore_batch(noisy_img, degradation, sigma_noise, lr,
+                                   iter_cb=on_iter if self.args.save_results else None)
+            self.last_restored = x
+
+            if self.args.compute_time:
+                torch.cuda.synchronize()
+                utils.save_time_use({"batch": batch, "time_per_batch": perf_counter() - t0}, self.args)
+
+            if self.args.save_results:
+                utils.compute_psnr(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=int(steps) - 1)
+
+        if self.args.save_results:
+            utils.compute_average_psnr(self.args)
+
+    def should_save_image(self, iteration, steps):
+        return iteration % (steps // 10) == 0
+
+    def run_method(self, data_loaders, degradation, sigma_noise, H_funcs=None):
+        folder = utils.get_save_path_ip(self.args.dict_cfg_method)
+        self.args.save_path_ip = os.path.join(self.args.save_path, folder)
+        os.makedirs(self.args.save_path_ip, exist_ok=True)
+        self.solve_ip(data_loaders[self.args.eval_split], degradation, sigma_noise, H_funcs)

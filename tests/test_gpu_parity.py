@@ -1,0 +1,305 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the committed golden
+vectors.  Needs a real MI355X:  python -m pytest tests -m gpu
+
+Tolerances (fp32 compute everywhere, differences come from summation order and 1-ulp
+transcendental differences only):
+  pointwise / operator kernels : 1e-5 absolute on O(1) data (mask family: bit exact)
+  U-Net forward                : 2e-4 absolute on outputs of magnitude ~0.5 (4e-4 relative)
+  10-step x 2-sample trajectory: 5e-4 absolute;  PSNR within 0.05 dB (north_star bound)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import CFGS, checksums, det_image, det_normal
+from oracle import pnpflow_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import pnpflow_amd._lib as L
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    L.load()                      # raises if libpnpflow_hip.so is missing - no fallback
+    return L
+
+
+def build_model(name):
+    from pnpflow_amd.models import UNet
+    c = CFGS[name]
+    cfg = O.unet_config(**c)
+    sd = O.synthetic_state_dict(cfg, 0)
+    m = UNet(c["input_channels"], c["input_height"], c["ch"], ch_mult=c["ch_mult"], num_res_blocks=c["num_res_blocks"],
+             attn_resolutions=c["attn_resolutions"])
+    m.load_state_dict(sd)
+    return m, cfg, sd
+
+
+_MODELS = {}
+
+
+def model_for(name):
+    if name not in _MODELS:
+        _MODELS[name] = build_model(name)
+    return _MODELS[name]
+
+
+# ---------------------------------------------------------------------------------------------
+# operators
+# ---------------------------------------------------------------------------------------------
+def deg_pairs(S):
+    import pnpflow_amd.degradations as D
+    return [("denoising", D.Denoising(), O.Denoising()),
+            ("box", D.BoxInpainting(S // 6), O.BoxInpainting(S // 6)),
+            ("random", D.RandomInpainting(0.7), O.RandomInpainting(0.7)),
+            ("sr2", D.Superresolution(2, S), O.Superresolution(2, S)),
+            ("sr4", D.Superresolution(4, S), O.Superresolution(4, S)),
+            ("blur1", D.GaussianDeblurring(1.0, 61, "fft", 3, S), O.GaussianDeblurring(1.0, 61, "fft", 3, S)),
+            ("blur3", D.GaussianDeblurring(3.0, 61, "fft", 3, S), O.GaussianDeblurring(3.0, 61, "fft", 3, S))]
+
+
+@pytest.mark.parametrize("S,B", [(64, 2), (128, 3)])
+def test_degradations_match_oracle(hip, S, B):
+    x = det_normal((B, 3, S, S), 21)
+    for name, dg, do in deg_pairs(S):
+        y_ref = do.H(x)
+        y = dg.H(x.cuda()).cpu()
+        exact = not name.startswith("blur")
+        if exact:
+            assert torch.equal(y, y_ref.contiguous()), name
+        else:
+            np.testing.assert_allclose(y.numpy(), y_ref.numpy(), atol=1e-5, err_msg=name)
+        w = det_normal(tuple(y_ref.shape), 22)
+        a_ref = do.H_adj(w)
+        a = dg.H_adj(w.cuda()).cpu()
+        if exact:
+            assert torch.equal(a, a_ref.contiguous()), name + " adj"
+        else:
+            np.testing.assert_allclose(a.numpy(), a_ref.numpy(), atol=1e-5, err_msg=name + " adj")
+
+
+def test_degradations_match_golden(hip, golden):
+    import pnpflow_amd.degradations as D
+    g = golden("degradations")
+    x64 = det_normal((2, 3, 64, 64), 21).cuda()
+    for half in (10, 20):
+        np.testing.assert_array_equal(D.BoxInpainting(half).H(x64).cpu().numpy(), g[f"box{half}_H"])
+    np.testing.assert_array_equal(D.RandomInpainting(0.7).H(x64).cpu().numpy(), g["rand_H"])
+    for sf in (2, 4):
+        d = D.Superresolution(sf, 64)
+        y = d.H(x64)
+        np.testing.assert_array_equal(y.cpu().numpy(), g[f"sr{sf}_H"])
+        np.testing.assert_array_equal(d.H_adj(y).cpu().numpy(), g[f"sr{sf}_Hadj"])
+    for sig in (1.0, 3.0):
+        d = D.GaussianDeblurring(sig, 61, "fft", 3, 64)
+        np.testing.assert_allclose(d.H(x64).cpu().numpy(), g[f"blur{sig}_H"], atol=1e-5)
+        np.testing.assert_allclose(d.H_adj(x64).cpu().numpy(), g[f"blur{sig}_Hadj"], atol=1e-5)
+    # the reference's known-answer test (pnpflow/tests/test_unit.py:14-20)
+    y = D.BoxInpainting(32).H(torch.ones(1, 3, 128, 128).cuda()).cpu()
+    torch.testing.assert_close(y[:, :, 32:64, 32:64], torch.zeros(1, 3, 32, 32))
+
+
+def test_adjoint_identity_full_size(hip):
+    # size-independent property at BASELINE sizes (C3: 64x3x128^2, C4 shard: 16x3x256^2)
+    for S, B in ((128, 64), (256, 16)):
+        x = det_normal((B, 3, S, S), 5).cuda()
+        for name, dg, _ in deg_pairs(S):
+            hx = dg.H(x)
+            w = det_normal(tuple(hx.shape), 6).cuda()
+            a = (hx.double() * w.double()).sum().item()
+            b = (x.double() * dg.H_adj(w).double()).sum().item()
+            assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (name, S, a, b)
+
+
+@pytest.mark.parametrize("S", [64, 128])
+def test_grad_step_matches_oracle(hip, S):
+    B = 2
+    x = det_normal((B, 3, S, S), 31)
+    coef = torch.tensor([0.7, 0.25])
+    for name, dg, do in deg_pairs(S):
+        y = det_normal(tuple(do.H(x).shape), 32)
+        ref = x - coef.view(-1, 1, 1, 1) * do.H_adj(do.H(x) - y)
+        d = dg.descriptor(B, S, S, torch.device("cuda"))
+        xd, yd, cd = x.cuda(), y.cuda(), coef.cuda()
+        z = torch.empty_like(xd)
+        scratch = torch.empty((2,) + tuple(xd.shape), device="cuda")
+        rc = hip.load().pf_grad_step(C.byref(d), xd.data_ptr(), yd.data_ptr(), cd.data_ptr(), z.data_ptr(), B, 3, S, S,
+                                     scratch.data_ptr(), hip.current_stream_ptr())
+        assert rc == 0, name
+        np.testing.assert_allclose(z.cpu().numpy(), ref.numpy(), atol=2e-5, err_msg=name)
+
+
+def test_interpolate_and_accumulate(hip):
+    lib = hip.load()
+    B, n = 3, 3 * 32 * 32
+    z = det_normal((B, n), 41); eps = det_normal((B, n), 42); v = det_normal((B, n), 43)
+    t = torch.tensor([0.0, 0.31, 0.99])
+    zd, ed, vd, td = z.cuda(), eps.cuda(), v.cuda(), t.cuda()
+    zt = torch.empty_like(zd)
+    assert lib.pf_interpolate(zd.data_ptr(), td.data_ptr(), ed.data_ptr(), 0, 0, zt.data_ptr(), B, n, hip.current_stream_ptr()) == 0
+    ref = t[:, None] * z + eps * (1 - t[:, None])
+    np.testing.assert_allclose(zt.cpu().numpy(), ref.numpy(), atol=1e-6)
+    # engine RNG: Philox4x32-10 / Box-Muller against the numpy restatement
+    assert lib.pf_interpolate(zd.data_ptr(), td.data_ptr(), None, 1234, 77, zt.data_ptr(), B, n, hip.current_stream_ptr()) == 0
+    e_ref = torch.from_numpy(O.engine_normal(B * n, 1234, 77)).view(B, n)
+    ref = t[:, None] * z + e_ref * (1 - t[:, None])
+    np.testing.assert_allclose(zt.cpu().numpy(), ref.numpy(), atol=2e-5)
+    out = torch.empty(1001, device="cuda")
+    assert lib.pf_fill_normal(out.data_ptr(), 1001, 99, 5, hip.current_stream_ptr()) == 0
+    np.testing.assert_allclose(out.cpu().numpy(), O.engine_normal(1001, 99, 5), atol=2e-5)
+    # accumulate: first / middle / last
+    acc = torch.full((B, n), 123.0, device="cuda")
+    ztr = ref.cuda()
+    assert lib.pf_denoise_accumulate(acc.data_ptr(), ztr.data_ptr(), vd.data_ptr(), td.data_ptr(), 1, 3.0, B, n, hip.current_stream_ptr()) == 0
+    assert lib.pf_denoise_accumulate(acc.data_ptr(), ztr.data_ptr(), vd.data_ptr(), td.data_ptr(), 0, 3.0, B, n, hip.current_stream_ptr()) == 0
+    assert lib.pf_denoise_accumulate(acc.data_ptr(), ztr.data_ptr(), vd.data_ptr(), td.data_ptr(), 2, 3.0, B, n, hip.current_stream_ptr()) == 0
+    one = ref + (1 - t[:, None]) * v
+    np.testing.assert_allclose(acc.cpu().numpy(), ((one + one + one) / 3.0).numpy(), atol=2e-6)
+
+
+def test_psnr_matches_oracle(hip):
+    from pnpflow_amd.utils import psnr_per_image
+    a = det_image((4, 3, 64, 64), 51); b = a + 0.05 * det_normal((4, 3, 64, 64), 52)
+    p = psnr_per_image(b.cuda(), a.cuda()).cpu()
+    np.testing.assert_allclose(p.numpy(), O.psnr_per_image(b, a).numpy(), atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+# U-Net velocity field
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,B", [("mnist", 3), ("tiny4", 2), ("celeba128", 1), ("afhq256", 1)])
+def test_unet_forward_matches_oracle_and_golden(hip, golden, name, B):
+    g = golden("unet_" + name)
+    m, cfg, sd = model_for(name)
+    shape = tuple(int(v) for v in g["shape"])
+    x = det_normal(shape, 11)
+    t = torch.from_numpy(g["t"])
+    out = m(x.cuda(), t.cuda()).cpu()
+    assert torch.isfinite(out).all()
+    with torch.no_grad():
+        ref = O.unet_forward(sd, cfg, x, t)
+    np.testing.assert_allclose(out.numpy(), ref.numpy(), atol=2e-4)
+    if "out" in g:     # the real reference's output, committed
+        np.testing.assert_allclose(out.numpy(), g["out"], atol=2e-4)
+    else:
+        H = shape[2]
+        np.testing.assert_allclose(out[:, :, H // 2 - 16:H // 2 + 16, H // 2 - 16:H // 2 + 16].numpy(), g["out_crop"], atol=2e-4)
+        np.testing.assert_allclose(out[:, :, :8, :8].numpy(), g["out_corner"], atol=2e-4)
+        np.testing.assert_allclose(checksums(out), g["out_checksum"], rtol=2e-4)
+
+
+def test_unet_batch_independence_full_size(hip):
+    # size-independent property at the C2 batch (32 x 3 x 128^2): every sample's velocity depends
+    # only on its own input (GroupNorm is per-sample), so a batched forward equals single forwards.
+    m, cfg, sd = model_for("celeba128")
+    x = det_normal((32, 3, 128, 128), 61).cuda()
+    t = torch.linspace(0, 0.99, 32).cuda()
+    full = m(x, t)
+    for i in (0, 13, 31):
+        one = m(x[i:i + 1].contiguous(), t[i:i + 1].contiguous())
+        np.testing.assert_allclose(one.cpu().numpy(), full[i:i + 1].cpu().numpy(), atol=1e-5)
+    # and sample 0 against the oracle
+    with torch.no_grad():
+        ref = O.unet_forward(sd, cfg, x[:1].cpu(), t[:1].cpu())
+    np.testing.assert_allclose(full[:1].cpu().numpy(), ref.numpy(), atol=2e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+# PnP-Flow trajectories against the real reference's iterates (golden) and the oracle
+# ---------------------------------------------------------------------------------------------
+def traj_cases():
+    import pnpflow_amd.degradations as D
+    return [("mnist_denoising", "mnist", "denoising", lambda S: D.Denoising(), 0.2),
+            ("tiny4_inpainting", "tiny4", "inpainting", lambda S: D.BoxInpainting(10), 0.05),
+            ("tiny4_superresolution", "tiny4", "superresolution", lambda S: D.Superresolution(2, S), 0.05),
+            ("tiny4_deblurring", "tiny4", "gaussian_deblurring_FFT", lambda S: D.GaussianDeblurring(1.0, 61, "fft", 3, S), 0.05),
+            ("tiny4_random_inpainting", "tiny4", "random_inpainting", lambda S: D.RandomInpainting(0.7), 0.01)]
+
+
+@pytest.mark.parametrize("idx", range(5))
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_pnp_flow_trajectory_matches_reference(hip, golden, idx, use_graph):
+    from pnpflow_amd.methods.pnp_flow import PNP_FLOW
+    from pnpflow_amd.utils import CfgNode, psnr_per_image
+    tag, net, problem, mk, sigma = traj_cases()[idx]
+    g = golden("pnp_traj_" + tag)
+    m, cfg, sd = model_for(net)
+    S, Cc = cfg["input_height"], cfg["input_channels"]
+    steps, ns = int(g["steps"]), int(g["num_samples"])
+    B = 2
+    args = CfgNode(dict(method="pnp_flow", model="ot", problem=problem, noise_type="gaussian", num_samples=ns, steps_pnp=steps,
+                        lr_pnp=1.0, gamma_style="alpha_1_minus_t", alpha=float(g["alpha"]), max_batch=1, compute_time=False,
+                        compute_memory=False, save_results=False, batch=0))
+    solver = PNP_FLOW(m, torch.device("cuda"), args)
+    solver.use_graph = use_graph
+    solver.noise = torch.stack([det_normal((B, Cc, S, S), 41, 1 + i) for i in range(steps * ns)]).cuda()
+    degradation = mk(S)
+    y = torch.from_numpy(g["noisy"]).cuda()
+    its = {}
+    args.sigma_noise = sigma
+    x = solver.restore_batch(y, degradation, sigma, lr=sigma ** 2 * 1.0, iter_cb=lambda it, xx: its.__setitem__(it, xx.clone().cpu()))
+    for it in (0, 1, 4, 9):
+        np.testing.assert_allclose(its[it].numpy(), g[f"x_it{it}"], atol=5e-4, err_msg=f"{tag} iterate {it}")
+    np.testing.assert_allclose(x.cpu().numpy(), g["x_it9"], atol=5e-4)
+    clean = det_image((B, Cc, S, S), 31)
+    p_hip = psnr_per_image(x, clean.cuda()).cpu()
+    p_ref = O.psnr_per_image(torch.from_numpy(g["x_it9"]), clean)
+    assert float((p_hip - p_ref).abs().max()) <= 0.05      # north_star: PSNR within +-0.05 dB of the reference
+
+
+def test_solve_ip_api_and_files(hip, tmp_path):
+    """Drop-in surface: PNP_FLOW(model, device, args).run_method(loaders, degradation, sigma)."""
+    from pnpflow_amd.methods.pnp_flow import PNP_FLOW
+    from pnpflow_amd.utils import CfgNode
+    import pnpflow_amd.degradations as D
+    m, cfg, sd = model_for("tiny4")
+    args = CfgNode(dict(method="pnp_flow", model="ot", dataset="celeba", problem="inpainting", noise_type="gaussian", num_samples=2,
+                        steps_pnp=10, lr_pnp=1.0, gamma_style="alpha_1_minus_t", alpha=0.5, max_batch=2, compute_time=False,
+                        compute_memory=False, save_results=True, eval_split="test", save_path=str(tmp_path),
+                        dict_cfg_method=dict(steps_pnp=10, lr_pnp=1.0, gamma_style="alpha_1_minus_t", num_samples=2, alpha=0.5)))
+    clean = det_image((2, 3, 64, 64), 31)
+    loaders = {"test": [(clean, torch.zeros(2)), (clean.flip(0), torch.zeros(2))]}
+    solver = PNP_FLOW(m, torch.device("cuda"), args)
+    solver.run_method(loaders, D.BoxInpainting(10), 0.05)
+    assert abs(args.lr_pnp - 0.05 ** 2) < 1e-12          # in-place scaling quirk kept (pnp_flow.py:61)
+    ip = args.save_path_ip
+    assert ip.endswith("steps_pnp=10/lr_pnp=1.0/gamma_style=alpha_1_minus_t/num_samples=2/alpha=0.5")
+    import os
+    lines = open(os.path.join(ip, "psnr_rec_batch0.txt")).read().strip().splitlines()
+    assert [int(l.split()[0]) for l in lines] == list(range(10)) + [9]     # steps//10 == 1 -> every iteration, + final
+    assert os.path.isfile(os.path.join(ip, "psnr_rec_average.txt"))
+    assert os.path.isfile(os.path.join(str(tmp_path), "final_psnr.txt"))
+    assert solver.last_restored.shape == (2, 3, 64, 64) and torch.isfinite(solver.last_restored).all()
+
+
+def test_philox_path_is_deterministic_and_graph_equals_eager(hip):
+    from pnpflow_amd.methods.pnp_flow import PNP_FLOW
+    from pnpflow_amd.utils import CfgNode
+    import pnpflow_amd.degradations as D
+    m, cfg, sd = model_for("tiny4")
+    outs = []
+    for use_graph in (True, False, True):
+        args = CfgNode(dict(method="pnp_flow", model="ot", problem="superresolution", noise_type="gaussian", num_samples=3, steps_pnp=6,
+                            lr_pnp=1.0, gamma_style="alpha_1_minus_t", alpha=0.3, max_batch=1, compute_time=False,
+                            compute_memory=False, save_results=False, batch=0, sigma_noise=0.05))
+        solver = PNP_FLOW(m, torch.device("cuda"), args)
+        solver.use_graph = use_graph; solver.noise_seed = 4242
+        y = det_normal((2, 3, 32, 32), 71).cuda()
+        outs.append(solver.restore_batch(y, D.Superresolution(2, 64), 0.05, lr=0.05 ** 2).cpu())
+    # atomics in the statistics reduction make the last bits order dependent -> tolerance, not equality
+    np.testing.assert_allclose(outs[0].numpy(), outs[1].numpy(), atol=1e-5)
+    np.testing.assert_allclose(outs[0].numpy(), outs[2].numpy(), atol=1e-5)
+
+
+def test_errors_are_loud(hip):
+    from pnpflow_amd.models import UNet
+    with pytest.raises(hip.PnpFlowHipError):
+        UNet(3, 100, 32, ch_mult=(1, 2, 4, 8), num_res_blocks=1, attn_resolutions=())   # 100 % 8 != 0
+    m = UNet(3, 64, 32, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=())
+    with pytest.raises(hip.PnpFlowHipError):
+        m(torch.zeros(1, 3, 64, 64).cuda(), torch.zeros(1).cuda())                       # weights not loaded
+    with pytest.raises(hip.PnpFlowHipError):
+        m(torch.zeros(1, 3, 64, 64), torch.zeros(1))                                    # CPU tensor: no CPU path

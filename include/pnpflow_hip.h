@@ -72,6 +72,8 @@ int pf_engine_finalize_weights(pf_engine* e);
 /* number of state_dict entries the architecture expects, and the i-th name. */
 int pf_engine_num_weights(const pf_engine* e);
 const char* pf_engine_weight_name(const pf_engine* e, int i);
+/* shape of the i-th entry (reference layout); returns the rank (<= 4) or a negative status. */
+int pf_engine_weight_shape(const pf_engine* e, int i, int64_t shape[4]);
 
 /* 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  Other values are reserved. */
 int pf_engine_set_precision(pf_engine* e, int mode);

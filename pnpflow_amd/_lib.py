@@ -48,6 +48,7 @@ SIGNATURES = {
     "pf_engine_finalize_weights": (C.c_int, [C.c_void_p]),
     "pf_engine_num_weights": (C.c_int, [C.c_void_p]),
     "pf_engine_weight_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "pf_engine_weight_shape": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     "pf_engine_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "pf_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pf_engine_num_taps": (C.c_int, [C.c_void_p]),

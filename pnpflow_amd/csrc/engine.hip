@@ -85,6 +85,7 @@ struct pf_engine {
     std::map<std::string, int> temb_off;   // ResBlock prefix -> offset in the stacked temb projection
     std::map<int, std::unique_ptr<Plan>> plans;
     SolverBufs sb;
+    hipStream_t work_stream = nullptr;   // used when the caller passes the NULL stream and asks for graph replay
     // profiling
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -628,6 +629,7 @@ void pf_engine_destroy(pf_engine* e) {
     for (void* p : e->weight_allocs) hipFree(p);
     for (auto& ev : e->ev_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     free_solver(e);
+    if (e->work_stream) hipStreamDestroy(e->work_stream);
     delete e;
 }
 
@@ -635,6 +637,13 @@ int pf_engine_num_weights(const pf_engine* e) { return e ? (int)e->expected.size
 const char* pf_engine_weight_name(const pf_engine* e, int i) {
     if (!e || i < 0 || i >= (int)e->expected.size()) return nullptr;
     return e->expected[i].first.c_str();
+}
+
+int pf_engine_weight_shape(const pf_engine* e, int i, int64_t shape[4]) {
+    if (!e || !shape || i < 0 || i >= (int)e->expected.size()) return PF_ERR_INVALID;
+    const auto& s = e->expected[i].second;
+    for (size_t k = 0; k < s.size() && k < 4; ++k) shape[k] = s[k];
+    return (int)s.size();
 }
 
 int pf_engine_load_weight(pf_engine* e, const char* name, const float* host_data, const int64_t* shape, int ndim) {
@@ -796,6 +805,13 @@ int pf_pnp_flow_restore(pf_engine* e, const pf_degradation* d, const pf_pnp_para
     if (!e->finalized) { e->err = "weights not finalized"; return PF_ERR_STATE; }
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
+    if (prm->use_graph && s == nullptr) {
+        // the legacy NULL stream cannot be captured: run on an engine-owned stream, ordered after
+        // everything already enqueued on the NULL stream (the function synchronises before returning)
+        if (!e->work_stream) HIPCHK(e, hipStreamCreateWithFlags(&e->work_stream, hipStreamNonBlocking));
+        HIPCHK(e, hipStreamSynchronize(nullptr));
+        s = e->work_stream;
+    }
     const int C = e->cfg.input_channels, H = e->cfg.input_height;
     if (e->cfg.output_channels != C) { e->err = "restoration needs output_channels == input_channels"; return PF_ERR_INVALID; }
     const size_t n = (size_t)C * H * H;

@@ -60,6 +60,14 @@ class UNet:
         n = self._lib.pf_engine_num_weights(self._h)
         return [self._lib.pf_engine_weight_name(self._h, i).decode() for i in range(n)]
 
+    def state_dict_shapes(self):
+        out = {}
+        for i, k in enumerate(self.state_dict_keys()):
+            shp = (C.c_int64 * 4)()
+            nd = self._lib.pf_engine_weight_shape(self._h, i, shp)
+            out[k] = tuple(int(shp[j]) for j in range(nd))
+        return out
+
     def load_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True):
         keys = self.state_dict_keys()
         missing = [k for k in keys if k not in state_dict]

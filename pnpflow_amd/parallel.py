@@ -1,0 +1,55 @@
+"""Multi-GPU sharding of the restoration path (one process per GPU, RCCL via
+torch.distributed).  The reference has no distributed code; images are
+independent units (GroupNorm is per-sample, pnpflow/models.py:33-38; batches are
+independent, pnpflow/methods/pnp_flow.py:71), so the global batch is split contiguously,
+weights are replicated, and the ONLY collective on the data path is the final all_gather
+of per-image PSNR (reproducing the reference's averaging order, pnpflow/utils.py:628-656).
+
+To stay equal to a single-device run at the global batch size, the three batch-shaped
+random draws of the reference are taken for the GLOBAL batch and sliced:
+  measurement noise  torch.manual_seed(batch); randn(global shape)   (pnp_flow.py:79-80)
+  random mask        RandomState(42).binomial(global B, H, W)          (utils.py:357-359)
+  interpolation noise  one flat Philox stream per (iteration, sample); shard s uses the
+                       elements [lo*n, hi*n) of it (see `noise_offset`).
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+
+
+def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of rank `rank`; the first (global_batch % world) ranks get one extra image."""
+    base, rem = divmod(global_batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def global_measurement_noise(batch: int, global_shape, lo: int, hi: int) -> torch.Tensor:
+    """Rows [lo, hi) of the reference's measurement-noise draw for batch index `batch`
+    (CPU generator, so every rank reproduces the same global tensor)."""
+    g = torch.Generator().manual_seed(batch)
+    return torch.randn(tuple(global_shape), generator=g, dtype=torch.float32)[lo:hi].contiguous()
+
+
+def gather_in_image_order(local: torch.Tensor, group=None) -> torch.Tensor:
+    """all_gather of a per-image vector; equal shard sizes are not required."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    n = torch.tensor([local.numel()], device=local.device, dtype=torch.int64)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    m = int(max(int(s.item()) for s in sizes))
+    pad = torch.zeros(m, device=local.device, dtype=local.dtype)
+    pad[: local.numel()] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return torch.cat([b[: int(s.item())] for b, s in zip(bufs, sizes)])
+
+
+def mean_psnr(local_psnr: torch.Tensor, group=None) -> float:
+    """Mean over the global batch, summed in global image order."""
+    return float(gather_in_image_order(local_psnr, group).double().mean())

@@ -1,0 +1,98 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol declared in
+include/pnpflow_hip.h (no compute calls), the config surface, the schedule scalars."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import pnpflow_amd._lib as L
+    lib = L.load()
+    hdr = open(os.path.join(ROOT, "include", "pnpflow_hip.h")).read()
+    declared = set(re.findall(r"\b(pf_[a-z_A-Z0-9]+)\s*\(", hdr))
+    declared -= {"pf_iter_callback"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+        assert name in L.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(L.SIGNATURES) <= declared
+    assert lib.pf_abi_version() == L.PF_ABI_VERSION
+
+
+def test_engine_create_fails_loudly_without_gpu_or_bad_cfg():
+    import pnpflow_amd._lib as L
+    from pnpflow_amd.models import UNet
+    with pytest.raises(L.PnpFlowHipError):
+        UNet(3, 100, 32, ch_mult=(1, 2, 4, 8), num_res_blocks=1, attn_resolutions=())   # invalid height on any box
+    if not torch.cuda.is_available():
+        with pytest.raises(L.PnpFlowHipError):
+            UNet(3, 64, 32, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=())       # no device: no silent fallback
+
+
+def test_config_surface(tmp_path):
+    from pnpflow_amd.utils import CfgNode, get_save_path_ip, load_cfg_from_cfg_file, merge_cfg_from_list
+    cfg = load_cfg_from_cfg_file(os.path.join(ROOT, "config", "main_config.yaml"))
+    assert cfg.method == "pnp_flow" and cfg.batch_size_ip == 4 and cfg.save_results is True
+    cfg = merge_cfg_from_list(cfg, ["dataset", "celeba", "max_batch", "25", "new_key", "[1,2]", "noise_type", "gaussian"])
+    assert cfg.dataset == "celeba" and cfg.max_batch == 25 and cfg.new_key == [1, 2]
+    with pytest.raises(ValueError):
+        merge_cfg_from_list(cfg, ["max_batch", "abc"])          # type mismatch is an error, as in the reference
+    cfg.update(load_cfg_from_cfg_file(os.path.join(ROOT, "config", "dataset_config", "celeba.yaml")))
+    m = load_cfg_from_cfg_file(os.path.join(ROOT, "config", "method_config", "pnp_flow.yaml"))
+    assert cfg.dim_image == 128 and list(m.keys()) == ["steps_pnp", "lr_pnp", "gamma_style", "num_samples", "alpha"]
+    assert get_save_path_ip(dict(a=1, b="x")) == "a=1/b=x"
+    c = CfgNode(dict(a=1)); c.b = 2
+    assert c["b"] == 2 and c.a == 1
+
+
+def test_main_parse_args_and_problem_table(monkeypatch):
+    import sys
+    monkeypatch.chdir(ROOT)
+    monkeypatch.setattr(sys, "argv", ["main.py", "--opts", "dataset", "celeba", "problem", "inpainting", "alpha", "0.5", "steps_pnp", "20"])
+    import main as M
+    cfg = M.parse_args()
+    assert cfg.dim_image == 128 and cfg.alpha == 0.5 and cfg.steps_pnp == 20
+    assert cfg.dict_cfg_method == dict(steps_pnp=20, lr_pnp=1.0, gamma_style="alpha_1_minus_t", num_samples=5, alpha=0.5)
+    for problem, dim, kind, sig in (("denoising", 128, "Denoising", 0.2), ("inpainting", 128, "BoxInpainting", 0.05),
+                                    ("inpainting", 256, "BoxInpainting", 0.05), ("random_inpainting", 256, "RandomInpainting", 0.01),
+                                    ("superresolution", 256, "Superresolution", 0.05), ("gaussian_deblurring_FFT", 128, "GaussianDeblurring", 0.05)):
+        d, s = M.make_degradation(problem, dim, 3, "gaussian", "cpu")
+        assert type(d).__name__ == kind and s == sig
+    d, _ = M.make_degradation("inpainting", 256, 3, "gaussian", "cpu"); assert d.half_size_mask == 40
+    d, _ = M.make_degradation("superresolution", 128, 3, "gaussian", "cpu"); assert d.sf == 2
+    d, _ = M.make_degradation("gaussian_deblurring_FFT", 256, 3, "gaussian", "cpu"); assert d.sigma == 3.0 and d.kernel_size == 61
+    with pytest.raises(ValueError):
+        M.make_degradation("nope", 128, 3, "gaussian", "cpu")
+
+
+def test_schedule_scalars_match_reference_expressions():
+    """t and lr_t are computed on the host with the reference's own fp32 expressions
+    (pnp_flow.py:107-109, 29-37)."""
+    from oracle import pnpflow_oracle as O
+    from pnpflow_amd.methods.pnp_flow import PNP_FLOW
+    from pnpflow_amd.utils import CfgNode
+
+    class Dummy:
+        def to(self, d):
+            return self
+    args = CfgNode(dict(method="pnp_flow", model="ot", gamma_style="alpha_1_minus_t", alpha=0.3))
+    s = PNP_FLOW.__new__(PNP_FLOW); s.args = args
+    sigma, steps = 0.05, 100
+    t_vals, coef = s._schedule(steps, sigma ** 2 * 1.0, sigma)
+    for it in (0, 1, 37, 99):
+        t1 = torch.ones(1) * (1 / steps) * it
+        assert t_vals[it] == float(t1[0])
+        lr_t = O.learning_rate_strat(sigma ** 2, t1, "alpha_1_minus_t", 0.3)
+        assert abs(coef[it] - float(lr_t.reshape(-1)[0]) / sigma ** 2) < 1e-6
+    assert coef[0] == pytest.approx(1.0, abs=1e-6)
+    taps = None
+    import pnpflow_amd.degradations as D
+    g = D.GaussianDeblurring(3.0, 61, "fft", 3, 256, "cpu")
+    np.testing.assert_allclose(g.taps_host, O.gaussian_1d_taps(3.0, 61).astype(np.float32), rtol=1e-6)
+    m = D.RandomInpainting(0.7, global_batch=8, batch_offset=4).mask(4, 16, 16, "cpu").numpy()
+    np.testing.assert_array_equal(m, O.random_mask_array(8, 16, 16, 0.7)[4:8].astype(np.uint8))

@@ -50,40 +50,43 @@ def make_problem(D, problem, dim):
     raise ValueError(problem)
 
 
-def cpu_baseline(wl, sd, cfg):
-    """The oracle (CPU restatement of the reference path, torch fp32, all host cores) timed on a
-    bounded sample of the same workload: B=2 images, `s` outer iterations instead of 100;
-    cost is linear in iterations x images, the extrapolation is stated in `sample`."""
+def usable_cores():
+    """Host threads this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(wl, sd, cfg, budget_s=20.0):
+    """The oracle (CPU restatement of the reference path, torch fp32, all usable host cores) timed on
+    a bounded sample of the same workload: B=2 images and as many U-Net evaluations of the first
+    outer iterations as fit in ~budget_s seconds.  Cost is linear in (evaluations x images); the
+    extrapolation to steps_pnp x num_samples evaluations is stated in `sample`."""
     from oracle import pnpflow_oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
-    Bc = 2
-    s_iters = 2 if wl["dim"] >= 128 else wl["steps"]
-    deg, sigma = O.make_degradation(wl["problem"], wl["dim"]) if wl["dim"] in (128, 256) else (O.BoxInpainting(10), 0.05)
-    clean = det_image((Bc, 3, wl["dim"], wl["dim"]), 31)
+    Bc, dim = 2, wl["dim"]
+    deg, sigma = O.make_degradation(wl["problem"], dim) if dim in (128, 256) else (O.BoxInpainting(10), 0.05)
+    clean = det_image((Bc, 3, dim, dim), 31)
     y = O.make_measurement(clean, deg, sigma, 0)
     model = lambda a, t: O.unet_forward(sd, cfg, a, t)
     with torch.no_grad():
         model(clean, torch.zeros(Bc))                      # warm the thread pool / allocator
-    t0 = time.perf_counter()
-    O.pnp_flow_restore(model, deg, y, sigma, steps=wl["steps"], num_samples=wl["ns"], alpha=wl["alpha"])  if s_iters == wl["steps"] else \
-        _partial_restore(O, model, deg, y, sigma, wl, s_iters)
-    dt = time.perf_counter() - t0
-    per_image_full = dt / Bc * (wl["steps"] / s_iters)
-    return dict(value=1.0 / per_image_full, unit="images/s", cores=cores, kind="port",
-                sample=f"oracle pnp_flow_restore, B={Bc}, first {s_iters} of {wl['steps']} outer iterations x {wl['ns']} samples "
-                       f"in {dt:.1f}s, scaled linearly to {wl['steps']} iterations")
-
-
-def _partial_restore(O, model, deg, y, sigma, wl, s_iters):
-    # same loop as O.pnp_flow_restore but stopped after s_iters iterations (t-schedule of the full run)
-    import torch
+        t0 = time.perf_counter(); model(clean, torch.zeros(Bc)); tf = time.perf_counter() - t0
+    total_fw = wl["steps"] * wl["ns"]
+    n_fw = int(max(1, min(total_fw, budget_s / max(tf, 1e-6))))
     H, H_adj = deg.H, deg.H_adj
-    lr = sigma ** 2
-    delta = 1.0 / wl["steps"]
+    lr, delta = sigma ** 2, 1.0 / wl["steps"]
+    done = 0
+    t0 = time.perf_counter()
     x = H_adj(torch.ones_like(y))
     with torch.no_grad():
-        for it in range(s_iters):
+        for it in range(wl["steps"]):
             t1 = torch.ones(len(x)) * delta * it
             lr_t = O.learning_rate_strat(lr, t1, "alpha_1_minus_t", wl["alpha"])
             z = x - lr_t * (H_adj(H(x) - y) / sigma ** 2)
@@ -92,8 +95,17 @@ def _partial_restore(O, model, deg, y, sigma, wl, s_iters):
             for _ in range(wl["ns"]):
                 zt = tv * z + torch.randn_like(z) * (1 - tv)
                 x_new += zt + (1 - tv) * model(zt, t1)
+                done += 1
+                if done >= n_fw:
+                    break
             x = x_new / wl["ns"]
-    return x
+            if done >= n_fw:
+                break
+    dt = time.perf_counter() - t0
+    per_image_full = dt / done * total_fw / Bc
+    return dict(value=1.0 / per_image_full, unit="images/s", cores=cores, kind="port",
+                sample=f"oracle PnP-Flow loop, B={Bc}, first {done} of {total_fw} U-Net evaluations (+ their pointwise steps) "
+                       f"in {dt:.1f}s on {cores} threads, scaled linearly to {total_fw} evaluations")
 
 
 def main():

@@ -11,13 +11,20 @@
 // The epilogue also emits per-channel (sum, sumsq) of the produced tensor so that the
 // next GroupNorm never re-reads it from HBM.
 //
-// Tiling (wave64, 4 waves / workgroup):  output tile = (2*MW rows x 16 cols) pixels x
-// (NW*NT*32) channels; wave (wm, wn) owns 2 rows x 16 cols = 32 pixels (the M of a
-// 32x32x2 MFMA) x NT*32 channels.  K is walked in chunks of KC=16 input channels: the
-// (halo) input patch of the chunk and the 9 (or 1) weight taps are staged once in LDS
-// ([pixel][KC+4] / [tap][n][KC+4] fp32, the +4 pad makes the ds_read_b128 fragment
-// reads bank-conflict free) and reused by all taps; the next chunk's global loads are
-// in flight (registers) while the MFMAs of the current chunk issue.
+// Tiling (wave64, 4 waves = WM x WN per workgroup): workgroup tile = (2*MT*WM rows x 16
+// cols) pixels x (WN*NT*32) output channels; wave (wm, wn) owns MT x NT MFMA tiles of
+// 32 pixels (2 rows x 16 cols) x 32 channels, i.e. MT*NT independent fp32 accumulators.
+// K is walked in chunks of KC=16 input channels:
+//   A (activations): the halo patch of the chunk is normalised/activated once and staged
+//      in LDS as [pixel][KC+4] fp32 (the +4 pad makes the ds_read_b128 fragment reads
+//      conflict free); all 9 taps re-read it with shifted addresses.  The next chunk's
+//      global loads are in flight (registers) while the MFMAs of the current chunk issue.
+//   B (weights): fragments are read straight from L1/L2 into registers, two k-steps ahead
+//      of their use, from a fragment-major repack [chunk][tap][kstep][Cout][8] in which
+//      one wave-level fragment (32 channels x 8 k) is one contiguous 1 KiB line group.
+//      (fp32 MFMA consumes 2 KiB of operands per 1024 MFMA cycles per wave: the weights
+//      stay L2/L1 resident and need no LDS staging, which leaves LDS to the patch and
+//      lets 3-6 workgroups share a CU.)
 #include "pf_common.h"
 
 namespace pf {
@@ -26,20 +33,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float silu_fast(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
 
-template <int MW, int NW, int NT, int S, int UP>
+template <int MT, int NT, int WM, int WN, int S, int UP, int BM>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     constexpr int KC = CONV_KC, KCP = KC + 4, KQ = KC / 4;
-    constexpr int TH = 2 * MW, TW = 16;
+    constexpr int TH = 2 * MT * WM, TW = 16;
     constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PP = PH * PW;
-    constexpr int BN = NW * NT * 32;
+    constexpr int BN = WN * NT * 32;
     constexpr int A_F4 = PP * KQ, A_PER = (A_F4 + 255) / 256;
-    constexpr int W_F4 = 9 * BN * KQ, W_PER = (W_F4 + 255) / 256;
-    static_assert(MW * NW == 4, "4 waves per workgroup");
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(PP * KCP >= WM * BN * 2, "statistics scratch must fit in the patch buffer");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* s_patch = reinterpret_cast<float*>(smem_raw);   // [PP][KCP]
-    float* s_w = s_patch + PP * KCP;                        // [9][BN][KCP]
-    float* s_sc = s_w + 9 * BN * KCP;                       // [gn_C] GroupNorm scale
+    float* s_sc = s_patch + PP * KCP;                       // [gn_C] GroupNorm scale
     float* s_sh = s_sc + ((p.gn_C + 3) & ~3);               // [gn_C] GroupNorm shift
 
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
@@ -49,8 +55,69 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     const int b = bid / tiles_y;
     const int oy0 = ty * TH, ox0 = tx * TW, n0 = blockIdx.y * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-    const int wm = wave % MW, wn = wave / MW;
+    const int wm = wave % WM, wn = wave / WM;
     const int Hv = UP ? 2 * p.Hs : p.Hs, Wv = UP ? 2 * p.Ws : p.Ws;
+    const int q4 = (tid % KQ) * 4;      // channel offset of this thread's float4 inside a chunk
+
+    // ---- per-thread staging descriptors, identical for every K-chunk ----------------------
+    int a_pix[A_PER];    // source pixel index (b*Hs+sy)*Ws+sx, or -1: zero padding / outside
+    int a_lds[A_PER];    // float offset of the float4 in s_patch, or -1: nothing to store
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+        const int idx = tid + i * 256;
+        a_pix[i] = -1; a_lds[i] = -1;
+        if (idx < A_F4) {
+            const int pix = idx / KQ;
+            const int py = pix / PW, px = pix % PW;
+            const int gy = oy0 * S - 1 + py, gx = ox0 * S - 1 + px;
+            a_lds[i] = pix * KCP + q4;
+            if (gy >= 0 && gy < Hv && gx >= 0 && gx < Wv) {
+                const int sy = UP ? (gy >> 1) : gy, sx = UP ? (gx >> 1) : gx;
+                a_pix[i] = (b * p.Hs + sy) * p.Ws + sx;
+            }
+        }
+    }
+
+    // All global loads below are unconditional (indices are clamped into the tensor and the zero
+    // padding is applied when the value is consumed): a load inside a divergent branch makes hipcc
+    // wait for it right away, which would serialise the software pipeline.
+    float4 ra[A_PER];
+    auto prefetch = [&](int si, int ch) {
+        const ConvSeg& sg = p.seg[si];
+        const int c = min(ch * KC + q4, sg.C - 4);
+        const float* base = sg.src + sg.coff + c;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i)
+            ra[i] = *reinterpret_cast<const float4*>(base + (size_t)max(a_pix[i], 0) * sg.cstride);
+    };
+    auto store_lds = [&](int si, int ch) {
+        const ConvSeg& sg = p.seg[si];
+        const int c = ch * KC + q4;
+        const bool cok = c < sg.C;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sg.xform != 0 && cok) {
+            sc = *reinterpret_cast<const float4*>(s_sc + sg.gn_off + c);
+            sh = *reinterpret_cast<const float4*>(s_sh + sg.gn_off + c);
+        }
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            if (a_lds[i] >= 0) {
+                float4 v = ra[i];
+                if (sg.xform != 0) {
+                    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
+                    v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                    if (sg.xform == 2) {
+                        v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w);
+                    }
+                }
+                if (!(cok && a_pix[i] >= 0)) v = make_float4(0.f, 0.f, 0.f, 0.f);   // zero padding applies AFTER norm+activation
+                *reinterpret_cast<float4*>(s_patch + a_lds[i]) = v;
+            }
+        }
+    };
+
+    // first chunk's activations go in flight before anything else
+    prefetch(0, 0);
 
     // ---- GroupNorm scale/shift of this sample from the producers' per-channel stats ----
     for (int c = tid; c < p.gn_C; c += 256) {
@@ -75,193 +142,155 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         s_sh[c] = p.beta[c] - (float)mean * sc;
     }
 
-    float4 ra[A_PER];
-    float4 rw[W_PER];
-
-    auto prefetch = [&](int si, int ch) {
-        const ConvSeg& sg = p.seg[si];
-        const int c0 = ch * KC;
+    f32x16 acc[MT][NT];
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-            const int idx = tid + i * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < A_F4) {
-                const int pix = idx / KQ, q = idx % KQ;
-                const int py = pix / PW, px = pix % PW;
-                const int gy = oy0 * S - 1 + py, gx = ox0 * S - 1 + px;
-                const int c = c0 + q * 4;
-                if (gy >= 0 && gy < Hv && gx >= 0 && gx < Wv && c < sg.C) {
-                    const int sy = UP ? (gy >> 1) : gy, sx = UP ? (gx >> 1) : gx;
-                    v = *reinterpret_cast<const float4*>(sg.src + ((size_t)(b * p.Hs + sy) * p.Ws + sx) * sg.cstride + sg.coff + c);
-                }
-            }
-            ra[i] = v;
-        }
-        const float* wb = sg.w + (size_t)b * sg.w_bs;
-        if (sg.w_mode == 0) {
-            const int total = sg.taps * BN * KQ;
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int i = 0; i < W_PER; ++i) {
-                const int idx = tid + i * 256;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < total) {
-                    const int tap = idx / (BN * KQ), rem = idx % (BN * KQ);
-                    const int n = n0 + rem / KQ, q = rem % KQ;
-                    if (n < p.Cout && c0 + q * 4 < sg.C)
-                        v = *reinterpret_cast<const float4*>(wb + (size_t)ch * sg.w_cs + (size_t)tap * sg.w_ts + (size_t)n * sg.w_ns + q * 4);
-                }
-                rw[i] = v;
-            }
-        } else {
-            constexpr int total = KC * (BN / 4);
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int i = 0; i < W_PER; ++i) {
-                const int idx = tid + i * 256;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < total) {
-                    const int kk = idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
-                    if (n < p.Cout && c0 + kk < sg.C)
-                        v = *reinterpret_cast<const float4*>(wb + (size_t)(c0 + kk) * sg.w_ks + n);
-                }
-                rw[i] = v;
-            }
-        }
-    };
-
-    auto store_lds = [&](int si, int ch) {
-        const ConvSeg& sg = p.seg[si];
-        const int c0 = ch * KC;
-#pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < A_F4) {
-                const int pix = idx / KQ, q = idx % KQ;
-                float4 v = ra[i];
-                if (sg.xform != 0) {
-                    const int py = pix / PW, px = pix % PW;
-                    const int gy = oy0 * S - 1 + py, gx = ox0 * S - 1 + px;
-                    const int c = c0 + q * 4;
-                    if (gy >= 0 && gy < Hv && gx >= 0 && gx < Wv && c < sg.C) {
-                        const float4 sc = *reinterpret_cast<const float4*>(s_sc + sg.gn_off + c);
-                        const float4 sh = *reinterpret_cast<const float4*>(s_sh + sg.gn_off + c);
-                        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
-                        v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-                        if (sg.xform == 2) {
-                            v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w);
-                        }
-                    }
-                }
-                *reinterpret_cast<float4*>(s_patch + pix * KCP + q * 4) = v;
-            }
-        }
-        if (sg.w_mode == 0) {
-            const int total = sg.taps * BN * KQ;
-#pragma unroll
-            for (int i = 0; i < W_PER; ++i) {
-                const int idx = tid + i * 256;
-                if (idx < total) {
-                    const int row = idx / KQ, q = idx % KQ;   // row = tap*BN + n
-                    *reinterpret_cast<float4*>(s_w + row * KCP + q * 4) = rw[i];
-                }
-            }
-        } else {
-            constexpr int total = KC * (BN / 4);
-#pragma unroll
-            for (int i = 0; i < W_PER; ++i) {
-                const int idx = tid + i * 256;
-                if (idx < total) {
-                    const int kk = idx / (BN / 4), n = (idx % (BN / 4)) * 4;
-                    s_w[(n + 0) * KCP + kk] = rw[i].x; s_w[(n + 1) * KCP + kk] = rw[i].y;
-                    s_w[(n + 2) * KCP + kk] = rw[i].z; s_w[(n + 3) * KCP + kk] = rw[i].w;
-                }
-            }
-        }
-    };
-
-    f32x16 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
     const int prow = l31 >> 4, pcol = l31 & 15;
+    const int nbase = n0 + wn * NT * 32 + l31;      // this lane's output channel in N-tile 0
+
+    // B fragment (one float4 = 4 consecutive k of one output channel) for k-step `s` of a chunk.
+    // Out-of-range channels / k are clamped to valid addresses: such columns are masked in the
+    // epilogue and such k meet zeros in the A operand.
+    int nclamp[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) nclamp[nt] = min(nbase + nt * 32, p.Cout - 1);
+    auto load_b = [&](const ConvSeg& sg, int ch, int s, float4 (&dst)[NT]) {
+        const int tap = s >> 1, ks = s & 1;
+        if constexpr (BM == 0) {
+            const float* wp = sg.w + ((size_t)(ch * sg.taps + tap) * 2 + ks) * ((size_t)p.Cout * 8) + hi * 4;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) dst[nt] = *reinterpret_cast<const float4*>(wp + (size_t)nclamp[nt] * 8);
+        } else {   // generic strided operand (attention): element (n, k) at w + b*w_bs + n*w_ns + k*w_ks
+            const int k0 = ch * KC + ks * 8 + hi * 4;
+            const float* wp = sg.w + (size_t)b * sg.w_bs;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float* wn_ = wp + (size_t)nclamp[nt] * sg.w_ns;
+                dst[nt] = make_float4(wn_[(size_t)min(k0 + 0, sg.C - 1) * sg.w_ks], wn_[(size_t)min(k0 + 1, sg.C - 1) * sg.w_ks],
+                                      wn_[(size_t)min(k0 + 2, sg.C - 1) * sg.w_ks], wn_[(size_t)min(k0 + 3, sg.C - 1) * sg.w_ks]);
+            }
+        }
+    };
+
     int si = 0, ch = 0;
-    prefetch(0, 0);
     while (true) {
-        __syncthreads();          // all waves finished reading the previous chunk (and s_sc is written)
-        store_lds(si, ch);
+        const ConvSeg& sg = p.seg[si];
+        const bool first = (si == 0 && ch == 0);
+        __syncthreads();          // every wave finished reading the previous chunk (and s_sc is written)
+        if (!(p.dbg & 2) || first) store_lds(si, ch);
         __syncthreads();
         int nsi = si, nch = ch + 1;
-        if (nch * KC >= p.seg[si].C) { nsi = si + 1; nch = 0; }
+        if (nch * KC >= sg.C) { nsi = si + 1; nch = 0; }
         const bool more = nsi < p.nseg;
-        if (more) prefetch(nsi, nch);
 
-        const int ntaps = p.seg[si].taps;
-        for (int tap = 0; tap < ntaps; ++tap) {
-            const int ky = ntaps == 9 ? tap / 3 : 1, kx = ntaps == 9 ? tap % 3 : 1;
-            const int ppix = ((wm * 2 + prow) * S + ky) * PW + pcol * S + kx;
-            const float* ap = s_patch + ppix * KCP + hi * 4;
-            const float* bp = s_w + (tap * BN + wn * NT * 32 + l31) * KCP + hi * 4;
+        const int nsteps = (p.dbg & 1) ? 0 : sg.taps * 2;
+        float4 b0[NT], b1[NT], b2[NT];
+        if (nsteps > 0) { load_b(sg, ch, 0, b0); load_b(sg, ch, 1, b1); }
+        if (more && !(p.dbg & 2)) prefetch(nsi, nch);   // issued after the first two B fragments: the
+                                                        // in-order vmcnt wait for them does not drag these along
+        // one k-step: 8 input channels of one tap.  `bc` holds this step's B fragments, `bl` receives
+        // the fragments of step s+2 (register ring b0->b1->b2 with static names: a rotating copy would
+        // make the compiler wait for the load it has just issued).
+        auto k_step = [&](int s, float4 (&bc)[NT], float4 (&bl)[NT]) {
+            load_b(sg, ch, min(s + 2, nsteps - 1), bl);
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch two k-steps ahead of its use (hipcc sinks it otherwise)
+            const int tap = s >> 1, ks = s & 1;
+            const int ky = sg.taps == 9 ? tap / 3 : 1, kx = sg.taps == 9 ? tap % 3 : 1;
+            float4 a[MT];
 #pragma unroll
-            for (int ks = 0; ks < KC / 8; ++ks) {
-                const float4 a = *reinterpret_cast<const float4*>(ap + ks * 8);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float4 bv = *reinterpret_cast<const float4*>(bp + nt * 32 * KCP + ks * 8);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bv.x, acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bv.y, acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bv.z, acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bv.w, acc[nt], 0, 0, 0);
-                }
+            for (int mt = 0; mt < MT; ++mt) {
+                const int ppix = (((wm * MT + mt) * 2 + prow) * S + ky) * PW + pcol * S + kx;
+                a[mt] = *reinterpret_cast<const float4*>(s_patch + ppix * KCP + ks * 8 + hi * 4);
             }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bc[nt].x, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, bc[nt].y, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bc[nt].z, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bc[nt].w, acc[mt][nt], 0, 0, 0);
+        };
+        if (nsteps == 18) {
+            for (int s = 0; s < 18; s += 3) { k_step(s, b0, b2); k_step(s + 1, b1, b0); k_step(s + 2, b2, b1); }
+        } else if (nsteps == 2) {
+            k_step(0, b0, b2); k_step(1, b1, b0);
         }
         if (!more) break;
         si = nsi; ch = nch;
     }
 
     // ---- epilogue: scale, bias(+temb), residual, store NHWC, per-channel statistics ----
+    float* s_red = s_patch;                       // [WM][BN][2], reuses the patch buffer
+    if (p.stats_out != nullptr) __syncthreads();  // all waves are done reading the patch
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + (wn * NT + nt) * 32 + l31;
+        const int n = nbase + nt * 32;
         const bool nok = n < p.Cout;
         const float add = (p.addvec != nullptr && nok) ? p.addvec[(size_t)b * p.addvec_bs + n] : 0.f;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const int oy = oy0 + wm * 2 + (row >> 4), ox = ox0 + (row & 15);
-            if (nok && oy < p.H && ox < p.W) {
-                const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
-                float v = acc[nt][r] * p.out_scale + add;
-                if (p.residual != nullptr) v += p.residual[pix * p.res_cstride + n];
-                p.out[pix * p.out_cstride + n] = v;
-                s1 += v; s2 += v * v;
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int oy = oy0 + (wm * MT + mt) * 2 + (row >> 4), ox = ox0 + (row & 15);
+                if (nok && oy < p.H && ox < p.W) {
+                    const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
+                    float v = acc[mt][nt][r] * p.out_scale + add;
+                    if (p.residual != nullptr) v += p.residual[pix * p.res_cstride + n];
+                    p.out[pix * p.out_cstride + n] = v;
+                    s1 += v; s2 += v * v;
+                }
             }
         }
         if (p.stats_out != nullptr) {
             s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-            if (hi == 0 && nok) {
-                double* st = p.stats_out + ((size_t)b * p.Cout + n) * 2;
-                unsafeAtomicAdd(st, (double)s1);
-                unsafeAtomicAdd(st + 1, (double)s2);
+            if (hi == 0) {
+                const int col = (wn * NT + nt) * 32 + l31;
+                s_red[(wm * BN + col) * 2] = s1; s_red[(wm * BN + col) * 2 + 1] = s2;
             }
+        }
+    }
+    if (p.stats_out != nullptr) {
+        __syncthreads();
+        if (tid < BN * 2) {
+            const int col = tid >> 1, which = tid & 1;
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) tot += s_red[(w * BN + col) * 2 + which];
+            const int n = n0 + col;
+            if (n < p.Cout) unsafeAtomicAdd(p.stats_out + ((size_t)b * p.Cout + n) * 2 + which, (double)tot);
         }
     }
 }
 
-template <int MW, int NW, int NT, int S, int UP>
+template <int MT, int NT, int WM, int WN, int S, int UP, int BM>
 static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     constexpr int KCP = CONV_KC + 4;
-    constexpr int TH = 2 * MW, TW = 16;
+    constexpr int TH = 2 * MT * WM, TW = 16;
     constexpr int PP = ((TH - 1) * S + 3) * ((TW - 1) * S + 3);
-    constexpr int BN = NW * NT * 32;
-    const size_t lds = (size_t)(PP * KCP + 9 * BN * KCP + 2 * ((p.gn_C + 3) & ~3)) * sizeof(float);
-    static size_t lds_set = 0;
-    auto kern = conv_mfma_kernel<MW, NW, NT, S, UP>;
-    if (lds > lds_set) {
+    constexpr int BN = WN * NT * 32;
+    const size_t lds = (size_t)(PP * KCP + 2 * ((p.gn_C + 3) & ~3)) * sizeof(float);
+    static bool attr_set = false;
+    auto kern = conv_mfma_kernel<MT, NT, WM, WN, S, UP, BM>;
+    if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        lds_set = 160 * 1024;
+        attr_set = true;
     }
     const int tiles = p.B * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
     dim3 grid(tiles, (p.Cout + BN - 1) / BN);
@@ -269,19 +298,38 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int S, int UP>
+static long wg_count(const ConvParams& p, int TH, int BN) {
+    return (long)p.B * ((p.H + TH - 1) / TH) * ((p.W + 15) / 16) * ((p.Cout + BN - 1) / BN);
+}
+
+template <int S, int UP, int BM>
 static hipError_t launch_sel(const ConvParams& p, hipStream_t stream) {
-    if (p.Cout <= 32) return launch_cfg<4, 1, 1, S, UP>(p, stream);
-    if (p.Cout <= 64) return launch_cfg<4, 1, 2, S, UP>(p, stream);
-    const long wgs128 = (long)p.B * ((p.H + 3) / 4) * ((p.W + 15) / 16) * ((p.Cout + 127) / 128);
-    if (wgs128 >= 1024) return launch_cfg<2, 2, 2, S, UP>(p, stream);
-    return launch_cfg<2, 2, 1, S, UP>(p, stream);
+    constexpr long MIN_WGS = 512;     // >= 2 workgroups per CU
+    if (S == 1) {
+        if (p.Cout <= 32) return launch_cfg<2, 1, 4, 1, S, UP, BM>(p, stream);                                    // 16x16 px x 32
+        if (p.Cout <= 64 && wg_count(p, 16, 64) >= MIN_WGS) return launch_cfg<2, 2, 4, 1, S, UP, BM>(p, stream);  // 16x16 px x 64
+        if (p.Cout > 64 && wg_count(p, 8, 128) >= MIN_WGS) return launch_cfg<2, 2, 2, 2, S, UP, BM>(p, stream);   // 8x16 px x 128
+        if (p.Cout > 64 && wg_count(p, 4, 128) >= MIN_WGS) return launch_cfg<1, 2, 2, 2, S, UP, BM>(p, stream);   // 4x16 px x 128
+        if (wg_count(p, 8, 64) >= MIN_WGS) return launch_cfg<1, 2, 4, 1, S, UP, BM>(p, stream);                   // 8x16 px x 64
+        return launch_cfg<1, 1, 2, 2, S, UP, BM>(p, stream);                                                      // 4x16 px x 64
+    } else {
+        if (p.Cout <= 32) return launch_cfg<1, 1, 4, 1, S, UP, BM>(p, stream);                                    // 8x16 px x 32
+        if (p.Cout <= 64) return launch_cfg<1, 2, 4, 1, S, UP, BM>(p, stream);                                    // 8x16 px x 64
+        return launch_cfg<1, 1, 2, 2, S, UP, BM>(p, stream);                                                      // 4x16 px x 64
+    }
 }
 
 hipError_t launch_conv(const ConvParams& p, int stride, int up, hipStream_t stream) {
-    if (stride == 2) return launch_sel<2, 0>(p, stream);
-    if (up) return launch_sel<1, 1>(p, stream);
-    return launch_sel<1, 0>(p, stream);
+    bool generic = false;
+    for (int i = 0; i < p.nseg; ++i) generic |= p.seg[i].w_mode != 0;
+    if (generic) {
+        for (int i = 0; i < p.nseg; ++i) if (p.seg[i].w_mode == 0) return hipErrorInvalidValue;   // not mixed
+        if (stride != 1 || up) return hipErrorInvalidValue;
+        return launch_sel<1, 0, 1>(p, stream);
+    }
+    if (stride == 2) return launch_sel<2, 0, 0>(p, stream);
+    if (up) return launch_sel<1, 1, 0>(p, stream);
+    return launch_sel<1, 0, 0>(p, stream);
 }
 
 size_t conv_flops(const ConvParams& p) {

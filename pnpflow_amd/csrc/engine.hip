@@ -214,7 +214,8 @@ static float* upload(pf_engine* e, const std::string& key, const std::vector<flo
     return d;
 }
 
-// OIHW conv weight, input channels [lo,hi) -> [chunk][tap][Cout][KC] (zero padded K tail)
+// OIHW conv weight, input channels [lo,hi) -> fragment-major [chunk][tap][kstep(2)][Cout][8]
+// (zero padded K tail): the B fragment of one wave (32 channels x 8 k) is contiguous.
 static float* packed_conv(pf_engine* e, const std::string& wname, int lo, int hi) {
     const std::string key = wname + "#" + std::to_string(lo) + ":" + std::to_string(hi);
     auto it = e->dev.find(key);
@@ -228,14 +229,15 @@ static float* packed_conv(pf_engine* e, const std::string& wname, int lo, int hi
             for (int n = 0; n < O; ++n)
                 for (int k = 0; k < CONV_KC; ++k) {
                     const int c = chn * CONV_KC + k;
-                    if (c < C) out[(((size_t)chn * kk + tap) * O + n) * CONV_KC + k] = t.data[((size_t)n * I + lo + c) * kk + tap];
+                    if (c < C)
+                        out[((((size_t)chn * kk + tap) * 2 + k / 8) * O + n) * 8 + k % 8] = t.data[((size_t)n * I + lo + c) * kk + tap];
                 }
     return upload(e, key, out);
 }
 
 static void fill_packed_seg(ConvSeg& s, const float* w, int taps, int Cout) {
-    s.w = w; s.w_mode = 0; s.w_bs = 0;
-    s.w_cs = (int64_t)taps * Cout * CONV_KC; s.w_ts = (int64_t)Cout * CONV_KC; s.w_ns = CONV_KC; s.w_ks = 0;
+    (void)taps; (void)Cout;
+    s.w = w; s.w_mode = 0; s.w_bs = 0; s.w_cs = 0; s.w_ts = 0; s.w_ns = 0; s.w_ks = 0;
 }
 
 // --------------------------------------------------------------------------------------
@@ -270,6 +272,7 @@ static ConvParams base_params(int B, int H, int W, int Hs, int Ws, const Tensor&
     ConvParams p{};
     p.B = B; p.H = H; p.W = W; p.Hs = Hs; p.Ws = Ws; p.Cout = out.C; p.out = out.p; p.out_cstride = out.C;
     p.out_scale = 1.0f; p.stats_out = out.stats; p.gn_eps = 1e-6f;
+    { const char* d = getenv("PNPFLOW_HIP_DBG"); p.dbg = d ? atoi(d) : 0; }
     return p;
 }
 
@@ -367,7 +370,7 @@ static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x) {
         ConvParams p = base_params(B, H, Wd, H, Wd, S);
         ConvSeg& s = p.seg[p.nseg++];
         s.src = qkv.p; s.C = C; s.cstride = 3 * C; s.coff = 0; s.xform = 0; s.taps = 1; s.stats = nullptr;
-        s.w = qkv.p + C; s.w_mode = 0; s.w_bs = (int64_t)HW * 3 * C; s.w_cs = CONV_KC; s.w_ts = 0; s.w_ns = 3 * C; s.w_ks = 0;
+        s.w = qkv.p + C; s.w_mode = 1; s.w_bs = (int64_t)HW * 3 * C; s.w_cs = 0; s.w_ts = 0; s.w_ns = 3 * C; s.w_ks = 1;
         p.out_scale = 1.0f / sqrtf((float)C);
         push_conv(bd, p);
     }
@@ -378,7 +381,7 @@ static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x) {
         ConvParams p = base_params(B, H, Wd, H, Wd, o);
         ConvSeg& s = p.seg[p.nseg++];
         s.src = S.p; s.C = HW; s.cstride = HW; s.coff = 0; s.xform = 0; s.taps = 1; s.stats = nullptr;
-        s.w = qkv.p + 2 * C; s.w_mode = 1; s.w_bs = (int64_t)HW * 3 * C; s.w_ks = 3 * C; s.w_cs = 0; s.w_ts = 0; s.w_ns = 0;
+        s.w = qkv.p + 2 * C; s.w_mode = 1; s.w_bs = (int64_t)HW * 3 * C; s.w_ks = 3 * C; s.w_cs = 0; s.w_ts = 0; s.w_ns = 1;
         push_conv(bd, p);
     }
     // out = x + proj_out(O)

@@ -17,8 +17,8 @@ struct ConvSeg {
     int gn_off;           // index of this segment's channel 0 in the GroupNorm channel space
     const double* stats;  // [B][C][2] per-channel (sum, sumsq) of src, or nullptr
     const float* w;       // weights
-    int w_mode;           // 0: k-contiguous  addr = b*w_bs + chunk*w_cs + tap*w_ts + n*w_ns + kk
-                          // 1: n-contiguous  addr = b*w_bs + k*w_ks + n      (k = chunk*KC+kk)
+    int w_mode;           // 0: fragment-major repack [chunk][tap][kstep(2)][Cout][8] (see packed_conv)
+                          // 1: generic strided operand: element (n,k) at b*w_bs + n*w_ns + k*w_ks
     int64_t w_bs, w_cs, w_ts, w_ns, w_ks;
 };
 
@@ -42,6 +42,7 @@ struct ConvParams {
     float gn_eps;
     const float* gamma;   // [gn_C]
     const float* beta;
+    int dbg;              // ablation switches for profiling (0 in production): 1 skip MFMAs, 2 skip re-staging
 };
 
 constexpr int CONV_KC = 16;   // channels per K-chunk staged in LDS

@@ -136,6 +136,24 @@ int pf_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, voi
  * (pnpflow/utils.py:560-577, 594-611) -> out[B] (device). */
 int pf_psnr(const float* rec, const float* clean, float* out, int B, int n_per_image, void* stream);
 
+/* ---- vector-Jacobian product (OT-ODE) ------------------------------------------------ */
+/* replaces torch.autograd.functional.vjp(lambda z: model(z, t), x, vec) at
+ * pnpflow/methods/ot_ode.py:137-138.  pf_unet_forward_retain = a forward that keeps every
+ * activation; pf_unet_backward = J^T vec at the last retained forward (input gradient only);
+ * pf_unet_vjp = both (v: the forward output, g: J^T vec). */
+int pf_unet_forward_retain(pf_engine* e, const float* x, const float* t, float* v, int B, void* stream);
+int pf_unet_backward(pf_engine* e, const float* vec, float* g, int B, void* stream);
+int pf_unet_vjp(pf_engine* e, const float* x, const float* t, const float* vec, float* v, float* g, int B, void* stream);
+
+/* OT-ODE per-pixel steps (pnpflow/methods/ot_ode.py:72-130 and 141-147), for the operators whose
+ * H H^T is diagonal (denoising, masks, decimation); GAUSSIAN_BLUR returns PF_ERR_INVALID.
+ *   vec = H_adj( (rt2[b] H H^T + sigma2)^-1 (y - H(x + one_minus_t[b]*vt)) )
+ *   x  += delta * (vt + coef[b] * (vec + one_minus_t[b]*g)),  coef = ((1-t)/t)*gamma */
+int pf_ot_ode_vec(const pf_degradation* d, const float* x, const float* vt, const float* y, const float* one_minus_t,
+                  const float* rt2, float sigma2, float* vec, int B, int C, int H, int W, void* stream);
+int pf_ot_ode_update(float* x, const float* vt, const float* vec, const float* g, const float* one_minus_t,
+                     const float* coef, float delta, int B, int n_per_image, void* stream);
+
 /* ---- whole restoration loop --------------------------------------------------------- */
 typedef struct pf_pnp_params {
     int32_t steps;            /* steps_pnp */

@@ -99,6 +99,9 @@ def main():
         os.makedirs(args.save_path, exist_ok=True)
         if args.method == 'pnp_flow':
             method = PNP_FLOW(model, device, args)
+        elif args.method == 'ot_ode':
+            from pnpflow_amd.methods.ot_ode import OT_ODE
+            method = OT_ODE(model, device, args)
         else:
             raise ValueError("The method your entered does not exist")
         method.run_method(loaders, degradation, sigma_noise)

@@ -488,3 +488,66 @@ def engine_normal(n: int, seed: int, stream: int) -> np.ndarray:
     a0, a1 = 2.0 * np.pi * u[:, 1], 2.0 * np.pi * u[:, 3]
     z = np.stack([rad0 * np.cos(a0), rad0 * np.sin(a0), rad1 * np.cos(a1), rad1 * np.sin(a1)], axis=1)
     return z.reshape(-1)[:n].astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# OT-ODE solver                                   (pnpflow/methods/ot_ode.py:9-213)
+# --------------------------------------------------------------------------------------
+
+def unet_vjp(sd: Dict[str, torch.Tensor], cfg: dict, x: torch.Tensor, t: torch.Tensor, vec: torch.Tensor) -> torch.Tensor:
+    """J^T vec of z -> v_theta(z, t) at z = x, as torch.autograd.functional.vjp computes it
+    (pnpflow/methods/ot_ode.py:137-138)."""
+    xx = x.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        out = unet_forward(sd, cfg, xx, t)
+        (g,) = torch.autograd.grad(out, xx, grad_outputs=vec)
+    return g.detach()
+
+
+def ot_ode_solution(problem: str, d: torch.Tensor, degradation: Degradation, x_like: torch.Tensor, t1: torch.Tensor,
+                    sigma_noise: float, delta: float, iteration: int) -> torch.Tensor:
+    """Closed-form solve of (r_t^2 H H^T + sigma^2 I) sol = d  (pnpflow/methods/ot_ode.py:72, 81-106).
+    The superresolution branch reproduces the reference's operator-precedence quirk
+    `delta * iteration**2` (ot_ode.py:96)."""
+    rt_squared = ((1 - t1) ** 2 / ((1 - t1) ** 2 + t1 ** 2)).view(-1, 1, 1, 1)
+    if problem in ("inpainting", "random_inpainting", "paintbrush_inpainting"):
+        mask = degradation.H(torch.ones_like(x_like))
+        return 1 / (mask * rt_squared + sigma_noise ** 2) * d          # reciprocal-then-multiply, as ot_ode.py:84-86
+    if problem == "denoising":
+        return d / (rt_squared + sigma_noise ** 2)
+    if problem == "superresolution":
+        rt2 = torch.tensor((1 - delta * iteration) ** 2 / ((1 - delta * iteration) ** 2 + delta * iteration ** 2))
+        # diag(D D^T) = 1 for the decimation matrix (utils.py:1124-1146)
+        return (1 / (rt2 + torch.tensor(sigma_noise) ** 2)) * d
+    raise NotImplementedError(problem)
+
+
+def ot_ode_restore(model: Callable, vjp: Callable, degradation: Degradation, problem: str, noisy_img: torch.Tensor,
+                   sigma_noise: float, *, steps: int, start_time: float, gamma: str = "constant",
+                   init_noise: Optional[torch.Tensor] = None, record: Optional[Callable] = None) -> torch.Tensor:
+    """Loop of OT_ODE.solve_ip for one batch (pnpflow/methods/ot_ode.py:49-52, 63-147).
+    model(x,t)->v; vjp(x,t,vec)->J^T vec; init_noise replaces the randn_like of `initialization` (:27-28)."""
+    H, H_adj = degradation.H, degradation.H_adj
+    hy = H_adj(noisy_img.clone())
+    if init_noise is None:
+        init_noise = torch.randn_like(hy)
+    x = start_time * hy + (1 - start_time) * init_noise                       # :27-28, :50-52
+    delta = 1 / steps
+    for iteration in range(int(steps * start_time), int(steps)):             # :63
+        with torch.no_grad():
+            t1 = torch.ones(len(x)) * delta * iteration                      # :69-70
+            vt = model(x, t1)                                                # :71
+            x1_hat = x + (1 - t1.view(-1, 1, 1, 1)) * vt                     # :74
+            d = noisy_img - H(x1_hat)                                        # :77
+            sol = ot_ode_solution(problem, d, degradation, x, t1, sigma_noise, delta, iteration)
+            vec = H_adj(sol)                                                 # :130
+        t = t1.view(-1, 1, 1, 1)
+        gam = 1 if gamma == "constant" else torch.sqrt(t / (t ** 2 + (1 - t) ** 2))   # :133-136
+        g = vjp(x, t1, vec)                                                  # :137-138
+        with torch.no_grad():
+            g = vec + (1 - t) * g                                            # :141
+            ratio = (1 - t) / t                                              # :143
+            x = x + delta * (vt + ratio * gam * g)                           # :144-147
+        if record is not None:
+            record(iteration, x)
+    return x

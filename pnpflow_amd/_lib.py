@@ -51,6 +51,11 @@ SIGNATURES = {
     "pf_engine_weight_shape": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     "pf_engine_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "pf_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "pf_unet_forward_retain": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "pf_unet_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "pf_unet_vjp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "pf_ot_ode_vec": (C.c_int, [C.POINTER(PfDegradation), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pf_ot_ode_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "pf_engine_num_taps": (C.c_int, [C.c_void_p]),
     "pf_engine_tap_name": (C.c_char_p, [C.c_void_p, C.c_int]),
     "pf_engine_read_tap": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.c_void_p]),

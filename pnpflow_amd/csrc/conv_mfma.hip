@@ -25,6 +25,7 @@
 //      (fp32 MFMA consumes 2 KiB of operands per 1024 MFMA cycles per wave: the weights
 //      stay L2/L1 resident and need no LDS staging, which leaves LDS to the patch and
 //      lets 3-6 workgroups share a CU.)
+#include <cstdlib>
 #include "pf_common.h"
 
 namespace pf {
@@ -39,6 +40,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     constexpr int TH = 2 * MT * WM, TW = 16;
     constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PP = PH * PW;
     constexpr int BN = WN * NT * 32;
+    constexpr bool A_PREFETCH = false;   // measured: prefetching the LDS fragments one k-step ahead costs 8 % (more VGPRs, clumped ds_reads)
     constexpr int A_F4 = PP * KQ, A_PER = (A_F4 + 255) / 256;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(PP * KCP >= WM * BN * 2, "statistics scratch must fit in the patch buffer");
@@ -71,7 +73,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
             const int py = pix / PW, px = pix % PW;
             const int gy = oy0 * S - 1 + py, gx = ox0 * S - 1 + px;
             a_lds[i] = pix * KCP + q4;
-            if (gy >= 0 && gy < Hv && gx >= 0 && gx < Wv) {
+            // UP == 1: nearest x2 upsample of the source; UP == 2: zero-insertion x2 (adjoint of a stride-2 conv)
+            if (gy >= 0 && gy < Hv && gx >= 0 && gx < Wv && !(UP == 2 && ((gy | gx) & 1))) {
                 const int sy = UP ? (gy >> 1) : gy, sx = UP ? (gx >> 1) : gx;
                 a_pix[i] = (b * p.Hs + sy) * p.Ws + sx;
             }
@@ -193,41 +196,48 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         if (nsteps > 0) { load_b(sg, ch, 0, b0); load_b(sg, ch, 1, b1); }
         if (more && !(p.dbg & 2)) prefetch(nsi, nch);   // issued after the first two B fragments: the
                                                         // in-order vmcnt wait for them does not drag these along
-        // one k-step: 8 input channels of one tap.  `bc` holds this step's B fragments, `bl` receives
-        // the fragments of step s+2 (register ring b0->b1->b2 with static names: a rotating copy would
-        // make the compiler wait for the load it has just issued).
-        auto k_step = [&](int s, float4 (&bc)[NT], float4 (&bl)[NT]) {
-            load_b(sg, ch, min(s + 2, nsteps - 1), bl);
-            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch two k-steps ahead of its use (hipcc sinks it otherwise)
+        // one k-step: 8 input channels of one tap.  `bc`/`ac` hold this step's B / A fragments, `bl`
+        // receives the B fragments of step s+2 and `al` the A fragments of step s+1 (register rings
+        // with static names: a rotating copy would make the compiler wait for what it just issued).
+        auto load_a = [&](int s, float4 (&dst)[MT]) {
             const int tap = s >> 1, ks = s & 1;
             const int ky = sg.taps == 9 ? tap / 3 : 1, kx = sg.taps == 9 ? tap % 3 : 1;
-            float4 a[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int ppix = (((wm * MT + mt) * 2 + prow) * S + ky) * PW + pcol * S + kx;
-                a[mt] = *reinterpret_cast<const float4*>(s_patch + ppix * KCP + ks * 8 + hi * 4);
+                dst[mt] = *reinterpret_cast<const float4*>(s_patch + ppix * KCP + ks * 8 + hi * 4);
             }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, bc[nt].x, acc[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, bc[nt].y, acc[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].z, bc[nt].z, acc[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].w, bc[nt].w, acc[mt][nt], 0, 0, 0);
         };
+        auto k_step = [&](int s, float4 (&bc)[NT], float4 (&bl)[NT], float4 (&ac)[MT], float4 (&al)[MT]) {
+            load_b(sg, ch, min(s + 2, nsteps - 1), bl);
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of its use (hipcc sinks it otherwise)
+            if (A_PREFETCH) load_a(min(s + 1, nsteps - 1), al); else load_a(s, ac);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[mt].x, bc[nt].x, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[mt].y, bc[nt].y, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[mt].z, bc[nt].z, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[mt].w, bc[nt].w, acc[mt][nt], 0, 0, 0);
+        };
+        float4 a0[MT], a1[MT];
+        if (A_PREFETCH && nsteps > 0) load_a(0, a0);
         if (nsteps == 18) {
-            for (int s = 0; s < 18; s += 3) { k_step(s, b0, b2); k_step(s + 1, b1, b0); k_step(s + 2, b2, b1); }
+            for (int s = 0; s < 18; s += 6) {
+                k_step(s, b0, b2, a0, a1);     k_step(s + 1, b1, b0, a1, a0); k_step(s + 2, b2, b1, a0, a1);
+                k_step(s + 3, b0, b2, a1, a0); k_step(s + 4, b1, b0, a0, a1); k_step(s + 5, b2, b1, a1, a0);
+            }
         } else if (nsteps == 2) {
-            k_step(0, b0, b2); k_step(1, b1, b0);
+            k_step(0, b0, b2, a0, a1); k_step(1, b1, b0, a1, a0);
         }
         if (!more) break;
         si = nsi; ch = nch;
@@ -304,7 +314,7 @@ static long wg_count(const ConvParams& p, int TH, int BN) {
 
 template <int S, int UP, int BM>
 static hipError_t launch_sel(const ConvParams& p, hipStream_t stream) {
-    constexpr long MIN_WGS = 512;     // >= 2 workgroups per CU
+    static const long MIN_WGS = getenv("PNPFLOW_HIP_MIN_WGS") ? atol(getenv("PNPFLOW_HIP_MIN_WGS")) : 512;   // >= 2 workgroups per CU
     if (S == 1) {
         if (p.Cout <= 32) return launch_cfg<2, 1, 4, 1, S, UP, BM>(p, stream);                                    // 16x16 px x 32
         if (p.Cout <= 64 && wg_count(p, 16, 64) >= MIN_WGS) return launch_cfg<2, 2, 4, 1, S, UP, BM>(p, stream);  // 16x16 px x 64
@@ -328,6 +338,7 @@ hipError_t launch_conv(const ConvParams& p, int stride, int up, hipStream_t stre
         return launch_sel<1, 0, 1>(p, stream);
     }
     if (stride == 2) return launch_sel<2, 0, 0>(p, stream);
+    if (up == 2) return launch_sel<1, 2, 0>(p, stream);
     if (up) return launch_sel<1, 1, 0>(p, stream);
     return launch_sel<1, 0, 0>(p, stream);
 }

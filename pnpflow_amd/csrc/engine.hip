@@ -35,7 +35,9 @@ struct LevelDesc { std::vector<ResDesc> blocks; std::string resample; int res_ch
 
 struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; double* stats = nullptr; };
 
-enum OpKind { OP_MEMSET, OP_TEMB, OP_BEGIN, OP_CHSTATS, OP_CONV, OP_SOFTMAX, OP_END };
+enum OpKind { OP_MEMSET, OP_TEMB, OP_BEGIN, OP_CHSTATS, OP_CONV, OP_SOFTMAX, OP_END,
+              // backward-only
+              OP_GN_FWD_COEF, OP_GN_BWD_PRE, OP_GN_BWD_COEF, OP_GN_BWD_POST, OP_TRANSPOSE, OP_SOFTMAX_BWD, OP_SUMPOOL };
 struct Op {
     OpKind kind;
     ConvParams cp; int stride = 1, up = 0;
@@ -45,6 +47,20 @@ struct Op {
     float* sm = nullptr; int64_t sm_rows = 0; int sm_cols = 0;
     const float* cs_x = nullptr; double* cs_stats = nullptr; int cs_HW = 0, cs_C = 0;
     size_t flops = 0;
+    // generic slots of the backward helper ops
+    const void* P[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void* O = nullptr;
+    int I[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float F = 0.f;
+};
+
+enum TapeKind { TP_RES, TP_ATTN, TP_DOWN, TP_UP };
+struct TapeRec {
+    TapeKind kind;
+    const ResDesc* r = nullptr;
+    std::string pfx;
+    Tensor in0, in1, h1, out, qkv, S, o;
+    bool has_in1 = false;
 };
 
 struct Tap { std::string name; Tensor t; };
@@ -55,6 +71,12 @@ struct Plan {
     std::vector<void*> allocs;
     std::vector<Tap> taps;
     size_t gemm_flops = 0;
+    // retained-activation plans (VJP): forward tape + backward op list
+    bool retain = false;
+    std::vector<TapeRec> tape;
+    Tensor t_begin, t_last;
+    std::vector<Op> bops;
+    size_t bwd_flops = 0;
 };
 
 struct SolverBufs {
@@ -84,6 +106,7 @@ struct pf_engine {
     int temb_total = 0;
     std::map<std::string, int> temb_off;   // ResBlock prefix -> offset in the stacked temb projection
     std::map<int, std::unique_ptr<Plan>> plans;
+    int retained_B = 0;
     SolverBufs sb;
     hipStream_t work_stream = nullptr;   // used when the caller passes the NULL stream and asks for graph replay
     // profiling
@@ -94,6 +117,10 @@ struct pf_engine {
 };
 
 static thread_local std::string g_create_err;
+
+#define LAUNCHCHK(call)                                                        \
+    do { hipError_t _r = (call); if (_r != hipSuccess) return _r == hipErrorInvalidValue ? PF_ERR_INVALID : PF_ERR_HIP; } while (0)
+
 
 #define HIPCHK(e, call)                                                                        \
     do {                                                                                       \
@@ -259,8 +286,9 @@ struct Builder {
         plan->allocs.push_back(p); sizes[p] = bytes;
         return (float*)p;
     }
-    bool keep = getenv("PNPFLOW_HIP_KEEP_ACTIVATIONS") != nullptr;   // debugging: never reuse, so every tap stays readable
+    bool keep = getenv("PNPFLOW_HIP_KEEP_ACTIVATIONS") != nullptr;   // never reuse: taps stay readable / activations retained for the VJP
     void release(float* p) { if (p && !keep) free_list.emplace(sizes[p], p); }
+    void recycle(float* p) { if (p) free_list.emplace(sizes[p], p); }   // backward temporaries are always recycled
     Tensor make(int C, int H, int W, bool stats) {
         Tensor t; t.C = C; t.H = H; t.W = W; t.p = acquire((size_t)B * H * W * C);
         if (stats) { t.stats = (double*)(uintptr_t)(stats_bytes + 1); stats_bytes += (size_t)B * C * 2 * sizeof(double); }
@@ -334,6 +362,10 @@ static Tensor res_block(Builder& bd, const ResDesc& r, const Tensor& in0, const 
         push_conv(bd, p);
     }
     bd.release(h1.p);
+    if (bd.plan->retain) {
+        TapeRec tr; tr.kind = TP_RES; tr.r = &r; tr.in0 = in0; tr.has_in1 = in1 != nullptr; if (in1) tr.in1 = *in1; tr.h1 = h1; tr.out = out;
+        bd.plan->tape.push_back(tr);
+    }
     return out;
 }
 
@@ -395,6 +427,10 @@ static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x) {
         push_conv(bd, p);
     }
     bd.release(qkv.p); bd.release(S.p); bd.release(o.p);
+    if (bd.plan->retain) {
+        TapeRec tr; tr.kind = TP_ATTN; tr.pfx = pfx; tr.in0 = x; tr.qkv = qkv; tr.S = S; tr.o = o; tr.out = out;
+        bd.plan->tape.push_back(tr);
+    }
     return out;
 }
 
@@ -407,6 +443,10 @@ static Tensor resample_conv(Builder& bd, const std::string& pfx, const Tensor& x
     fill_packed_seg(p.seg[0], packed_conv(e, pfx + "weight", 0, x.C), 9, x.C);
     p.addvec = upload(e, pfx + "bias", W(e, pfx + "bias").data); p.addvec_bs = 0;
     push_conv(bd, p, down ? 2 : 1, down ? 0 : 1);
+    if (bd.plan->retain) {
+        TapeRec tr; tr.kind = down ? TP_DOWN : TP_UP; tr.pfx = pfx; tr.in0 = x; tr.out = out;
+        bd.plan->tape.push_back(tr);
+    }
     return out;
 }
 
@@ -416,13 +456,19 @@ static void fix_stats(Op& op, double* slab) {
     if (op.kind == OP_CONV) { for (int i = 0; i < op.cp.nseg; ++i) fx(op.cp.seg[i].stats); fxm(op.cp.stats_out); }
     if (op.kind == OP_END) fx(op.ep.stats);
     if (op.kind == OP_CHSTATS) fxm(op.cs_stats);
+    if (op.kind == OP_GN_FWD_COEF) { const double* a = (const double*)op.P[0]; const double* b2 = (const double*)op.P[1]; fx(a); fx(b2); op.P[0] = a; op.P[1] = b2; }
+    if (op.kind == OP_GN_BWD_PRE || op.kind == OP_GN_BWD_COEF) { const double* a = (const double*)op.P[6]; fx(a); op.P[6] = a; }
 }
 
-static int build_plan(pf_engine* e, int B, Plan** out_plan) {
-    auto it = e->plans.find(B);
+static int build_backward(pf_engine* e, Plan* plan, struct Builder& bd);
+
+static int build_plan(pf_engine* e, int B, bool retain, Plan** out_plan) {
+    const int key = B * 2 + (retain ? 1 : 0);
+    auto it = e->plans.find(key);
     if (it != e->plans.end()) { *out_plan = it->second.get(); return PF_OK; }
-    auto plan = std::make_unique<Plan>(); plan->B = B;
+    auto plan = std::make_unique<Plan>(); plan->B = B; plan->retain = retain;
     Builder bd{e, plan.get(), B};
+    if (retain) bd.keep = true;
     const pf_unet_cfg& c = e->cfg;
     const int H0 = c.input_height, ch = c.ch, tch = 4 * ch;
     // op 0: zero the statistics slab (filled in below); op 1: time embedding
@@ -466,6 +512,7 @@ static int build_plan(pf_engine* e, int B, Plan** out_plan) {
         Op cs{}; cs.kind = OP_CHSTATS; cs.cs_x = t0.p; cs.cs_stats = t0.stats; cs.cs_HW = H0 * H0; cs.cs_C = ch;
         plan->ops.push_back(cs);
         hs.push_back(t0);
+        plan->t_begin = t0;
         plan->taps.push_back({"begin_conv", t0});
     }
     char nm[64];
@@ -527,7 +574,9 @@ static int build_plan(pf_engine* e, int B, Plan** out_plan) {
         op.ep.beta = upload(e, "end_conv.0.bias", W(e, "end_conv.0.bias").data);
         op.ep.gn_cpg = ch / 32; op.ep.gn_eps = 1e-6f;
         plan->ops.push_back(op);
+        plan->t_last = h;
     }
+    if (retain) { int rc = build_backward(e, plan.get(), bd); if (rc != PF_OK) return rc; }
     if (!bd.ok) return PF_ERR_HIP;
     for (auto& kv : e->dev) if (kv.second == nullptr) { e->err = "weight upload failed: " + kv.first; return PF_ERR_HIP; }
     // statistics slab
@@ -535,10 +584,276 @@ static int build_plan(pf_engine* e, int B, Plan** out_plan) {
     if (hipMalloc(&slab, std::max<size_t>(bd.stats_bytes, 256)) != hipSuccess) { e->err = "hipMalloc failed (stats)"; return PF_ERR_HIP; }
     plan->allocs.push_back(slab);
     for (auto& op : plan->ops) fix_stats(op, (double*)slab);
+    for (auto& op : plan->bops) fix_stats(op, (double*)slab);
     for (auto& tp : plan->taps) if (tp.t.stats) tp.t.stats = (double*)((char*)slab + ((uintptr_t)tp.t.stats - 1));
     plan->ops[0].ptr = slab; plan->ops[0].bytes = bd.stats_bytes;
+    if (!plan->bops.empty()) plan->bops[0].ptr = (char*)slab + ((uintptr_t)plan->bops[0].ptr - 1);
     *out_plan = plan.get();
-    e->plans[B] = std::move(plan);
+    e->plans[key] = std::move(plan);
+    return PF_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// backward plan: J^T vec with respect to the network input (time embedding path has no input
+// gradient).  Walks the forward tape in reverse; every dense step reuses conv_mfma_kernel with
+// transposed (and spatially flipped) weight repacks.
+// --------------------------------------------------------------------------------------
+// OIHW weight, input channels [lo,hi)  ->  adjoint conv weight  W'[ci][co][ky][kx] = W[co][lo+ci][K-1-ky][K-1-kx]
+static float* packed_conv_T(pf_engine* e, const std::string& wname, int lo, int hi) {
+    const std::string key = wname + "#T" + std::to_string(lo) + ":" + std::to_string(hi);
+    if (!e->host.count(key)) {
+        const HostTensor& t = W(e, wname);
+        const int O = (int)t.shape[0], I = (int)t.shape[1], K = (int)t.shape[2], kk = K * K, C = hi - lo;
+        HostTensor tt; tt.shape = {C, O, K, K}; tt.data.resize((size_t)C * O * kk); tt.loaded = true;
+        for (int ci = 0; ci < C; ++ci) for (int co = 0; co < O; ++co) for (int tap = 0; tap < kk; ++tap)
+            tt.data[((size_t)ci * O + co) * kk + tap] = t.data[((size_t)co * I + lo + ci) * kk + (kk - 1 - tap)];
+        e->host[key] = std::move(tt);
+    }
+    return packed_conv(e, key, 0, (int)e->host.at(key).shape[1]);
+}
+
+struct GradEntry { Tensor t; bool has = false; };
+
+struct BwdCtx {
+    pf_engine* e; Plan* plan; Builder* bd; int B;
+    std::map<float*, GradEntry> grads;
+    GradEntry& G(const Tensor& fwd) {
+        auto it = grads.find(fwd.p);
+        if (it == grads.end()) {
+            GradEntry g; g.t.C = fwd.C; g.t.H = fwd.H; g.t.W = fwd.W; g.t.p = bd->acquire((size_t)B * fwd.H * fwd.W * fwd.C);
+            it = grads.emplace(fwd.p, g).first;
+        }
+        return it->second;
+    }
+    Tensor tmp(int C, int H, int W) { Tensor t; t.C = C; t.H = H; t.W = W; t.p = bd->acquire((size_t)B * H * W * C); return t; }
+    float* fvec(size_t n) { return bd->acquire(n); }
+    double* dsum(size_t n_doubles) { double* p = (double*)(uintptr_t)(bd->stats_bytes + 1); bd->stats_bytes += n_doubles * sizeof(double); return p; }
+    void push(const Op& op) { plan->bops.push_back(op); }
+    // dst (=|+=) conv(src; weights)   (raw input, no bias)
+    void conv_to(ConvParams p, GradEntry& dst, int stride = 1, int up = 0) {
+        p.out = dst.t.p; p.out_cstride = dst.t.C;
+        if (dst.has) { p.residual = dst.t.p; p.res_cstride = dst.t.C; }
+        dst.has = true;
+        Op op{}; op.kind = OP_CONV; op.cp = p; op.stride = stride; op.up = up; op.flops = conv_flops(p);
+        plan->bwd_flops += op.flops;
+        push(op);
+    }
+    void conv_plain(const ConvParams& p, int stride = 1, int up = 0) {
+        Op op{}; op.kind = OP_CONV; op.cp = p; op.stride = stride; op.up = up; op.flops = conv_flops(p);
+        plan->bwd_flops += op.flops;
+        push(op);
+    }
+};
+
+static ConvParams bwd_params(int B, int H, int W, int Hs, int Ws, int Cout) {
+    ConvParams p{};
+    p.B = B; p.H = H; p.W = W; p.Hs = Hs; p.Ws = Ws; p.Cout = Cout; p.out_scale = 1.0f; p.gn_eps = 1e-6f;
+    { const char* d = getenv("PNPFLOW_HIP_DBG"); p.dbg = d ? atoi(d) : 0; }
+    return p;
+}
+static void raw_seg(ConvParams& p, const float* src, int C, int cstride, int taps, const float* w) {
+    ConvSeg& s = p.seg[p.nseg++];
+    s.src = src; s.C = C; s.cstride = cstride; s.coff = 0; s.xform = 0; s.taps = taps; s.gn_off = 0; s.stats = nullptr;
+    s.w = w; s.w_mode = 0; s.w_bs = 0; s.w_cs = 0; s.w_ts = 0; s.w_ns = 0; s.w_ks = 0;
+}
+static void gen_seg(ConvParams& p, const float* src, int C, int cstride, const float* w, int64_t w_bs, int64_t w_ns, int64_t w_ks) {
+    ConvSeg& s = p.seg[p.nseg++];
+    s.src = src; s.C = C; s.cstride = cstride; s.coff = 0; s.xform = 0; s.taps = 1; s.gn_off = 0; s.stats = nullptr;
+    s.w = w; s.w_mode = 1; s.w_bs = w_bs; s.w_cs = 0; s.w_ts = 0; s.w_ns = w_ns; s.w_ks = w_ks;
+}
+
+// GroupNorm(+SiLU) backward over a (possibly concatenated) input.  srcs[j] = forward input tensor j,
+// gtmp[j] = gradient w.r.t. the activated/normalised tensor (overwritten), dst[j] = where dx goes,
+// add[j] = optional extra addend (identity-shortcut gradient).
+static void gn_backward(BwdCtx& c, const std::vector<Tensor>& srcs, const std::vector<Tensor>& gtmp, const std::vector<GradEntry*>& dst,
+                        const std::vector<const float*>& add, const std::string& norm_prefix, bool silu) {
+    pf_engine* e = c.e; const int B = c.B;
+    const int HW = srcs[0].H * srcs[0].W;
+    int Ct = 0; for (auto& t : srcs) Ct += t.C;
+    const int cpg = Ct / 32;
+    float* mu = c.fvec((size_t)B * Ct); float* rs = c.fvec((size_t)B * Ct);
+    float* m1 = c.fvec((size_t)B * Ct); float* m2 = c.fvec((size_t)B * Ct);
+    double* bsum = c.dsum((size_t)B * Ct * 2);
+    const float* gamma = upload(e, norm_prefix + "weight", W(e, norm_prefix + "weight").data);
+    const float* beta = upload(e, norm_prefix + "bias", W(e, norm_prefix + "bias").data);
+    { Op op{}; op.kind = OP_GN_FWD_COEF; op.P[0] = srcs[0].stats; op.P[1] = srcs.size() > 1 ? srcs[1].stats : nullptr; op.P[2] = mu; op.P[3] = rs;
+      op.I[0] = srcs[0].C; op.I[1] = srcs.size() > 1 ? srcs[1].C : 0; op.I[2] = cpg; op.I[3] = HW; c.push(op); }
+    int coff = 0;
+    for (size_t j = 0; j < srcs.size(); ++j) {
+        Op op{}; op.kind = OP_GN_BWD_PRE; op.O = gtmp[j].p; op.P[0] = srcs[j].p; op.P[1] = mu; op.P[2] = rs; op.P[3] = gamma; op.P[4] = beta;
+        op.P[6] = bsum; op.I[0] = HW; op.I[1] = srcs[j].C; op.I[2] = coff; op.I[3] = Ct; op.I[4] = silu ? 1 : 0; c.push(op);
+        coff += srcs[j].C;
+    }
+    { Op op{}; op.kind = OP_GN_BWD_COEF; op.P[6] = bsum; op.P[1] = m1; op.P[2] = m2; op.I[0] = Ct; op.I[1] = cpg; op.I[2] = HW; c.push(op); }
+    coff = 0;
+    for (size_t j = 0; j < srcs.size(); ++j) {
+        Op op{}; op.kind = OP_GN_BWD_POST; op.P[0] = gtmp[j].p; op.P[1] = srcs[j].p; op.P[2] = mu; op.P[3] = rs; op.P[4] = m1; op.P[5] = m2;
+        op.P[7] = add[j]; op.O = dst[j]->t.p; op.I[0] = HW; op.I[1] = srcs[j].C; op.I[2] = coff; op.I[3] = Ct; op.I[4] = dst[j]->has ? 1 : 0;
+        dst[j]->has = true; c.push(op);
+        coff += srcs[j].C;
+    }
+    c.bd->recycle(mu); c.bd->recycle(rs); c.bd->recycle(m1); c.bd->recycle(m2);
+}
+
+static int build_backward(pf_engine* e, Plan* plan, Builder& bd) {
+    const int B = plan->B;
+    const pf_unet_cfg& cf = e->cfg;
+    const int ch = cf.ch, H0 = cf.input_height;
+    BwdCtx c{e, plan, &bd, B};
+    // op 0: zero the backward sums (range filled in below)
+    { Op op{}; op.kind = OP_MEMSET; plan->bops.push_back(op); }
+    const size_t bwd_lo = bd.stats_bytes;
+    // ---- end: v = conv3x3(silu(gn(h)))  (models.py:492).  d(act) = adjoint conv of vec (image -> ch) --------
+    {
+        const HostTensor& w = W(e, "end_conv.2.weight");   // [Cimg][ch][3][3]
+        const int co_n = cf.output_channels;
+        std::vector<float> wp((size_t)9 * co_n * ch), zero(ch, 0.f);
+        for (int co = 0; co < co_n; ++co) for (int ci = 0; ci < ch; ++ci) for (int tap = 0; tap < 9; ++tap)
+            wp[((size_t)tap * co_n + co) * ch + ci] = w.data[((size_t)co * ch + ci) * 9 + (8 - tap)];
+        Tensor da = c.tmp(ch, H0, H0);
+        Op op{}; op.kind = OP_BEGIN; op.ep.out = da.p; op.ep.w = upload(e, "end_conv.adj", wp); op.ep.bias = upload(e, "zero.ch", zero);
+        op.ep.B = B; op.ep.H = H0; op.ep.W = H0; op.ep.Cimg = co_n; op.ep.C = ch; c.push(op);
+        gn_backward(c, {plan->t_last}, {da}, {&c.G(plan->t_last)}, {nullptr}, "end_conv.0.", true);
+        bd.recycle(da.p);
+    }
+    // ---- reverse walk -----------------------------------------------------------------------------------
+    for (auto it = plan->tape.rbegin(); it != plan->tape.rend(); ++it) {
+        const TapeRec& tr = *it;
+        GradEntry& gout = c.G(tr.out);
+        if (!gout.has) { e->err = "internal: backward reached a tensor without gradient"; return PF_ERR_INVALID; }
+        const int H = tr.out.H, Wd = tr.out.W;
+        if (tr.kind == TP_UP) {
+            // out = conv(nearest_up(x)): dU = adjoint conv at the fine resolution, dx = 2x2 sum-pool of dU
+            Tensor dU = c.tmp(tr.in0.C, H, Wd);
+            ConvParams p = bwd_params(B, H, Wd, H, Wd, tr.in0.C);
+            raw_seg(p, gout.t.p, tr.out.C, tr.out.C, 9, packed_conv_T(e, tr.pfx + "weight", 0, tr.in0.C));
+            p.out = dU.p; p.out_cstride = dU.C; c.conv_plain(p);
+            GradEntry& gx = c.G(tr.in0);
+            Op op{}; op.kind = OP_SUMPOOL; op.P[0] = dU.p; op.O = gx.t.p; op.I[0] = tr.in0.H; op.I[1] = tr.in0.W; op.I[2] = tr.in0.C; op.I[3] = gx.has ? 1 : 0;
+            gx.has = true; c.push(op);
+            bd.recycle(dU.p);
+        } else if (tr.kind == TP_DOWN) {
+            // out = conv_stride2(x): dx = adjoint conv of the zero-inserted gradient
+            ConvParams p = bwd_params(B, tr.in0.H, tr.in0.W, H, Wd, tr.in0.C);
+            raw_seg(p, gout.t.p, tr.out.C, tr.out.C, 9, packed_conv_T(e, tr.pfx + "weight", 0, tr.in0.C));
+            c.conv_to(p, c.G(tr.in0), 1, 2);
+        } else if (tr.kind == TP_RES) {
+            const ResDesc& r = *tr.r;
+            const int cin = tr.in0.C + (tr.has_in1 ? tr.in1.C : 0);
+            // conv2 adjoint -> d(act2), GN2+SiLU backward -> d(h1)
+            Tensor t1 = c.tmp(r.cout, H, Wd);
+            {
+                ConvParams p = bwd_params(B, H, Wd, H, Wd, r.cout);
+                raw_seg(p, gout.t.p, r.cout, r.cout, 9, packed_conv_T(e, r.prefix + "conv2.weight", 0, r.cout));
+                p.out = t1.p; p.out_cstride = r.cout; c.conv_plain(p);
+            }
+            GradEntry gh1; gh1.t = c.tmp(r.cout, H, Wd);
+            gn_backward(c, {tr.h1}, {t1}, {&gh1}, {nullptr}, r.prefix + "norm2.", true);
+            bd.recycle(t1.p);
+            // conv1 adjoint per source -> d(act1), GN1+SiLU backward over the concatenation
+            std::vector<Tensor> srcs{tr.in0}; if (tr.has_in1) srcs.push_back(tr.in1);
+            std::vector<Tensor> us; std::vector<GradEntry*> dsts; std::vector<const float*> adds;
+            int lo = 0;
+            for (auto& sT : srcs) {
+                Tensor u = c.tmp(sT.C, H, Wd);
+                ConvParams p = bwd_params(B, H, Wd, H, Wd, sT.C);
+                raw_seg(p, gh1.t.p, r.cout, r.cout, 9, packed_conv_T(e, r.prefix + "conv1.weight", lo, lo + sT.C));
+                p.out = u.p; p.out_cstride = sT.C; c.conv_plain(p);
+                us.push_back(u);
+                GradEntry& gd = c.G(sT);
+                if (cin != r.cout) {   // 1x1 shortcut adjoint goes straight into the gradient buffer
+                    ConvParams q = bwd_params(B, H, Wd, H, Wd, sT.C);
+                    raw_seg(q, gout.t.p, r.cout, r.cout, 1, packed_conv_T(e, r.prefix + "shortcut.weight", lo, lo + sT.C));
+                    c.conv_to(q, gd);
+                    adds.push_back(nullptr);
+                } else {
+                    adds.push_back(gout.t.p);   // identity shortcut
+                }
+                dsts.push_back(&gd);
+                lo += sT.C;
+            }
+            gn_backward(c, srcs, us, dsts, adds, r.prefix + "norm1.", true);
+            for (auto& u : us) bd.recycle(u.p);
+            bd.recycle(gh1.t.p);
+        } else {   // TP_ATTN  (models.py:145-162)
+            const Tensor& x = tr.in0; const int C = x.C, HW = H * Wd;
+            const float scale = 1.0f / sqrtf((float)C);
+            // d(o) = dout . Wproj
+            Tensor d_o = c.tmp(C, H, Wd);
+            { ConvParams p = bwd_params(B, H, Wd, H, Wd, C);
+              raw_seg(p, gout.t.p, C, C, 1, packed_conv_T(e, tr.pfx + "proj_out.weight", 0, C)); p.out = d_o.p; p.out_cstride = C; c.conv_plain(p); }
+            // dA[i][j] = sum_c d_o[i][c] v[j][c]
+            Tensor dA = c.tmp(HW, H, Wd);
+            { ConvParams p = bwd_params(B, H, Wd, H, Wd, HW);
+              gen_seg(p, d_o.p, C, C, tr.qkv.p + 2 * C, (int64_t)HW * 3 * C, 3 * C, 1); p.out = dA.p; p.out_cstride = HW; c.conv_plain(p); }
+            Tensor dqkv = c.tmp(3 * C, H, Wd);
+            // dv[j][c] = sum_i A[i][j] d_o[i][c]   (A^T as the pixel-major operand)
+            Tensor AT = c.tmp(HW, H, Wd);
+            { Op op{}; op.kind = OP_TRANSPOSE; op.P[0] = tr.S.p; op.O = AT.p; op.I[0] = HW; op.I[1] = HW; c.push(op); }
+            { ConvParams p = bwd_params(B, H, Wd, H, Wd, C);
+              gen_seg(p, AT.p, HW, HW, d_o.p, (int64_t)HW * C, 1, C); p.out = dqkv.p + 2 * C; p.out_cstride = 3 * C; c.conv_plain(p); }
+            // dS = scale * A .* (dA - rowsum(dA .* A))   in place
+            { Op op{}; op.kind = OP_SOFTMAX_BWD; op.P[0] = tr.S.p; op.O = dA.p; op.sm_rows = (int64_t)B * HW; op.sm_cols = HW; op.F = scale; c.push(op); }
+            // dq[i][c] = sum_j dS[i][j] k[j][c]
+            { ConvParams p = bwd_params(B, H, Wd, H, Wd, C);
+              gen_seg(p, dA.p, HW, HW, tr.qkv.p + C, (int64_t)HW * 3 * C, 1, 3 * C); p.out = dqkv.p; p.out_cstride = 3 * C; c.conv_plain(p); }
+            // dk[j][c] = sum_i dS[i][j] q[i][c]
+            { Op op{}; op.kind = OP_TRANSPOSE; op.P[0] = dA.p; op.O = AT.p; op.I[0] = HW; op.I[1] = HW; c.push(op); }
+            { ConvParams p = bwd_params(B, H, Wd, H, Wd, C);
+              gen_seg(p, AT.p, HW, HW, tr.qkv.p, (int64_t)HW * 3 * C, 1, 3 * C); p.out = dqkv.p + C; p.out_cstride = 3 * C; c.conv_plain(p); }
+            // d(hn) = dqkv . Wqkv ; GroupNorm backward (no activation) ; + identity path
+            Tensor dhn = c.tmp(C, H, Wd);
+            { ConvParams p = bwd_params(B, H, Wd, H, Wd, C);
+              raw_seg(p, dqkv.p, 3 * C, 3 * C, 1, packed_conv_T(e, tr.pfx + "qkv.w", 0, C)); p.out = dhn.p; p.out_cstride = C; c.conv_plain(p); }
+            gn_backward(c, {x}, {dhn}, {&c.G(x)}, {gout.t.p}, tr.pfx + "norm.", false);
+            for (float* q : {d_o.p, dA.p, dqkv.p, AT.p, dhn.p}) bd.recycle(q);
+        }
+    }
+    // ---- begin: h0 = conv3x3(x) (models.py:451): g = adjoint conv (ch -> image), NCHW out ------------------
+    {
+        GradEntry& g0 = c.G(plan->t_begin);
+        if (!g0.has) { e->err = "internal: no gradient at begin_conv output"; return PF_ERR_INVALID; }
+        const HostTensor& w = W(e, "begin_conv.weight");   // [ch][Cimg][3][3]
+        const int ci_n = cf.input_channels;
+        std::vector<float> wp((size_t)9 * ci_n * ch), zero3(4, 0.f);
+        for (int n = 0; n < ch; ++n) for (int ci = 0; ci < ci_n; ++ci) for (int tap = 0; tap < 9; ++tap)
+            wp[((size_t)tap * ci_n + ci) * ch + n] = w.data[((size_t)n * ci_n + ci) * 9 + (8 - tap)];
+        Op op{}; op.kind = OP_END; op.ep.in = g0.t.p; op.ep.w = upload(e, "begin_conv.adj", wp); op.ep.bias = upload(e, "zero.img", zero3);
+        op.ep.B = B; op.ep.H = H0; op.ep.W = H0; op.ep.Cimg = ci_n; op.ep.C = ch; op.ep.stats = nullptr; op.ep.gn_cpg = 1; op.ep.gn_eps = 1e-6f;
+        c.push(op);
+    }
+    plan->bops[0].ptr = (void*)(uintptr_t)(bwd_lo + 1);          // placeholder, resolved against the slab below
+    plan->bops[0].bytes = bd.stats_bytes - bwd_lo;
+    return PF_OK;
+}
+
+static int run_backward(pf_engine* e, Plan* plan, const float* vec, float* g, hipStream_t s) {
+    const int B = plan->B;
+    for (auto& op : plan->bops) {
+        hipError_t r = hipSuccess;
+        switch (op.kind) {
+            case OP_MEMSET: if (op.bytes) r = hipMemsetAsync(op.ptr, 0, op.bytes, s); break;
+            case OP_BEGIN: { EdgeConvParams ep = op.ep; ep.in = vec; r = launch_begin_conv(ep, s); break; }
+            case OP_END: { EdgeConvParams ep = op.ep; ep.out = g; r = launch_end_conv(ep, s); break; }
+            case OP_CONV: r = launch_conv(op.cp, op.stride, op.up, s); break;
+            case OP_GN_FWD_COEF:
+                r = launch_gn_fwd_coeffs((const double*)op.P[0], op.I[0], (const double*)op.P[1], op.I[1], op.I[2], op.I[3], 1e-6f, (float*)op.P[2],
+                                         (float*)op.P[3], B, s); break;
+            case OP_GN_BWD_PRE:
+                r = launch_gn_bwd_pre((float*)op.O, (const float*)op.P[0], (const float*)op.P[1], (const float*)op.P[2], (const float*)op.P[3],
+                                      (const float*)op.P[4], (double*)op.P[6], B, op.I[0], op.I[1], op.I[2], op.I[3], op.I[4], s); break;
+            case OP_GN_BWD_COEF:
+                r = launch_gn_bwd_coeffs((const double*)op.P[6], op.I[0], op.I[1], op.I[2], (float*)op.P[1], (float*)op.P[2], B, s); break;
+            case OP_GN_BWD_POST:
+                r = launch_gn_bwd_post((const float*)op.P[0], (const float*)op.P[1], (const float*)op.P[2], (const float*)op.P[3], (const float*)op.P[4],
+                                       (const float*)op.P[5], (const float*)op.P[7], (float*)op.O, B, op.I[0], op.I[1], op.I[2], op.I[3], op.I[4], s); break;
+            case OP_TRANSPOSE: r = launch_transpose((const float*)op.P[0], (float*)op.O, B, op.I[0], op.I[1], s); break;
+            case OP_SOFTMAX_BWD: r = launch_softmax_bwd((const float*)op.P[0], (float*)op.O, op.sm_rows, op.sm_cols, op.F, s); break;
+            case OP_SUMPOOL: r = launch_sumpool2((const float*)op.P[0], (float*)op.O, B, op.I[0], op.I[1], op.I[2], op.I[3], s); break;
+            default: break;
+        }
+        if (r != hipSuccess) { e->err = std::string("backward launch failed: ") + hipGetErrorString(r); return PF_ERR_HIP; }
+    }
     return PF_OK;
 }
 
@@ -690,9 +1005,50 @@ int pf_unet_forward(pf_engine* e, const float* x, const float* t, float* v, int 
     if (!e->finalized) { e->err = "weights not finalized"; return PF_ERR_STATE; }
     HIPCHK(e, hipSetDevice(e->device));
     Plan* plan = nullptr;
-    int rc = build_plan(e, B, &plan);
+    int rc = build_plan(e, B, false, &plan);
     if (rc != PF_OK) return rc;
     return run_plan(e, plan, x, t, v, (hipStream_t)stream);
+}
+
+int pf_unet_forward_retain(pf_engine* e, const float* x, const float* t, float* v, int B, void* stream) {
+    if (!e || !x || !t || !v || B <= 0) return PF_ERR_INVALID;
+    if (!e->finalized) { e->err = "weights not finalized"; return PF_ERR_STATE; }
+    HIPCHK(e, hipSetDevice(e->device));
+    Plan* plan = nullptr;
+    int rc = build_plan(e, B, true, &plan);
+    if (rc != PF_OK) return rc;
+    e->retained_B = B;
+    return run_plan(e, plan, x, t, v, (hipStream_t)stream);
+}
+
+int pf_unet_backward(pf_engine* e, const float* vec, float* g, int B, void* stream) {
+    if (!e || !vec || !g || B <= 0) return PF_ERR_INVALID;
+    if (e->retained_B != B) { e->err = "pf_unet_backward: no retained forward with this batch size"; return PF_ERR_STATE; }
+    HIPCHK(e, hipSetDevice(e->device));
+    Plan* plan = nullptr;
+    int rc = build_plan(e, B, true, &plan);
+    if (rc != PF_OK) return rc;
+    return run_backward(e, plan, vec, g, (hipStream_t)stream);
+}
+
+int pf_unet_vjp(pf_engine* e, const float* x, const float* t, const float* vec, float* v, float* g, int B, void* stream) {
+    int rc = pf_unet_forward_retain(e, x, t, v, B, stream);
+    if (rc != PF_OK) return rc;
+    return pf_unet_backward(e, vec, g, B, stream);
+}
+
+int pf_ot_ode_vec(const pf_degradation* d, const float* x, const float* vt, const float* y, const float* one_minus_t, const float* rt2,
+                  float sigma2, float* vec, int B, int C, int H, int W, void* stream) {
+    if (!d || !x || !vt || !y || !one_minus_t || !rt2 || !vec) return PF_ERR_INVALID;
+    LAUNCHCHK(launch_ot_ode_vec(to_view(d), x, vt, y, one_minus_t, rt2, sigma2, vec, B, C, H, W, (hipStream_t)stream));
+    return PF_OK;
+}
+
+int pf_ot_ode_update(float* x, const float* vt, const float* vec, const float* g, const float* one_minus_t, const float* coef, float delta,
+                     int B, int n_per_image, void* stream) {
+    if (!x || !vt || !vec || !g || !one_minus_t || !coef) return PF_ERR_INVALID;
+    LAUNCHCHK(launch_ot_ode_update(x, vt, vec, g, one_minus_t, coef, delta, B, n_per_image, (hipStream_t)stream));
+    return PF_OK;
 }
 
 int pf_engine_num_taps(const pf_engine* e) {
@@ -722,8 +1078,6 @@ int pf_engine_read_tap(pf_engine* e, int i, float* host_out, int64_t capacity, i
     return PF_OK;
 }
 
-#define LAUNCHCHK(call)                                                        \
-    do { hipError_t _r = (call); if (_r != hipSuccess) return _r == hipErrorInvalidValue ? PF_ERR_INVALID : PF_ERR_HIP; } while (0)
 
 int pf_degradation_H(const pf_degradation* d, const float* x, float* y, int B, int C, int H, int W, float* scratch, void* stream) {
     if (!d || !x || !y) return PF_ERR_INVALID;
@@ -824,7 +1178,7 @@ int pf_pnp_flow_restore(pf_engine* e, const pf_degradation* d, const pf_pnp_para
     if (rc != PF_OK) return rc;
     SolverBufs& b = e->sb;
     Plan* plan = nullptr;
-    if ((rc = build_plan(e, B, &plan)) != PF_OK) return rc;
+    if ((rc = build_plan(e, B, false, &plan)) != PF_OK) return rc;
     const DegView dv = to_view(d);
     HIPCHK(e, hipMemcpyAsync(b.t_all, prm->host_t, (size_t)prm->steps * 4, hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(b.coef_all, prm->host_coef, (size_t)prm->steps * 4, hipMemcpyHostToDevice, s));

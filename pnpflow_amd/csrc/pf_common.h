@@ -77,6 +77,18 @@ hipError_t launch_temb(const TembParams& p, hipStream_t s);
 hipError_t launch_softmax_rows(float* data, int64_t rows, int cols, hipStream_t s);
 hipError_t launch_channel_stats(const float* x, double* stats, int B, int HW, int C, hipStream_t s);
 
+// backward helpers (unet_bwd.hip)
+hipError_t launch_gn_fwd_coeffs(const double* st0, int C0, const double* st1, int C1, int cpg, int HW, float eps, float* mu, float* rs, int B,
+                                hipStream_t s);
+hipError_t launch_gn_bwd_pre(float* g, const float* x, const float* mu, const float* rs, const float* gamma, const float* beta, double* bsum,
+                             int B, int HW, int C, int coff, int Ct, int silu, hipStream_t s);
+hipError_t launch_gn_bwd_coeffs(const double* bsum, int Ct, int cpg, int HW, float* m1, float* m2, int B, hipStream_t s);
+hipError_t launch_gn_bwd_post(const float* dy, const float* x, const float* mu, const float* rs, const float* m1, const float* m2,
+                              const float* add, float* out, int B, int HW, int C, int coff, int Ct, int accumulate, hipStream_t s);
+hipError_t launch_transpose(const float* in, float* out, int B, int R, int Cc, hipStream_t s);
+hipError_t launch_softmax_bwd(const float* A, float* dA, int64_t rows, int cols, float scale, hipStream_t s);
+hipError_t launch_sumpool2(const float* in, float* out, int B, int H, int W, int C, int accumulate, hipStream_t s);
+
 // pointwise / operator kernels (NCHW fp32 images)
 struct DegView {       // device-side view of pf_degradation
     int kind, half, sf, ntaps;
@@ -96,5 +108,13 @@ hipError_t launch_denoise_accum(float* acc, const float* zt, const float* v, con
 hipError_t launch_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, hipStream_t s);
 hipError_t launch_psnr(const float* rec, const float* clean, float* out, int B, int n, hipStream_t s);
 hipError_t launch_fill(float* out, int64_t n, float v, hipStream_t s);
+
+// OT-ODE per-pixel steps (pointwise.hip)
+hipError_t launch_ot_ode_vec(const DegView& d, const float* x, const float* vt, const float* y, const float* one_minus_t,
+                             const float* rt2, float sigma2, float* vec, int B, int C, int H, int W, hipStream_t s);
+hipError_t launch_ot_ode_update(float* x, const float* vt, const float* vec, const float* g, const float* one_minus_t, const float* coef,
+                                float delta, int B, int n, hipStream_t s);
+
+
 
 }  // namespace pf

@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void end_conv_kernel(const EdgeConvParams p) {
     const int b = bid / tiles_y;
     const int tid = threadIdx.x;
     for (int i = tid; i < 9 * p.Cimg * C; i += 256) s_w[i] = p.w[i];
-    if (tid < C) {
+    const bool raw = p.stats == nullptr;   // raw: plain 3x3 conv (used as the adjoint of begin_conv)
+    if (tid < C && !raw) {
         const int g = tid / p.gn_cpg;
         double s = 0.0, ss = 0.0;
         for (int j = g * p.gn_cpg; j < (g + 1) * p.gn_cpg; ++j) {
@@ -94,10 +95,12 @@ __global__ __launch_bounds__(256) void end_conv_kernel(const EdgeConvParams p) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
             v = *reinterpret_cast<const float4*>(p.in + ((size_t)(b * p.H + gy) * p.W + gx) * C + q * 4);
-            const float4 sc = *reinterpret_cast<const float4*>(s_sc + q * 4);
-            const float4 sh = *reinterpret_cast<const float4*>(s_sh + q * 4);
-            v.x = silu_acc(v.x * sc.x + sh.x); v.y = silu_acc(v.y * sc.y + sh.y);
-            v.z = silu_acc(v.z * sc.z + sh.z); v.w = silu_acc(v.w * sc.w + sh.w);
+            if (!raw) {
+                const float4 sc = *reinterpret_cast<const float4*>(s_sc + q * 4);
+                const float4 sh = *reinterpret_cast<const float4*>(s_sh + q * 4);
+                v.x = silu_acc(v.x * sc.x + sh.x); v.y = silu_acc(v.y * sc.y + sh.y);
+                v.z = silu_acc(v.z * sc.z + sh.z); v.w = silu_acc(v.w * sc.w + sh.w);
+            }
         }
         *reinterpret_cast<float4*>(s_patch + pix * CP + q * 4) = v;
     }

@@ -1,0 +1,125 @@
+"""OT_ODE solver with the API of pnpflow/methods/ot_ode.py (reference :9-213).
+
+Per iteration the reference runs a no-grad forward, a per-pixel closed-form solve, a second
+forward with autograd graph and an input-gradient backward (ot_ode.py:71-147).  Here one
+retained forward + the hand-written backward of the engine (pf_unet_forward_retain /
+pf_unet_backward) replace the two forwards + autograd; the closed-form solve and the Euler
+update are HIP pointwise kernels (pf_ot_ode_vec / pf_ot_ode_update).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from time import perf_counter
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .. import utils
+
+
+class OT_ODE(object):
+
+    def __init__(self, model, device, args):
+        self.device = device
+        self.args = args
+        self.model = model.to(device)
+        self.method = args.method
+        self.lib = _lib.load()
+        self.init_noise = None          # optional override of the randn_like in `initialization` (parity runs)
+        self.measurement_noise = None   # optional override of the torch.manual_seed(batch) draw
+        self.last_restored = None
+
+    def model_forward(self, x, t):
+        if self.args.model == "ot":
+            return self.model(x, t)
+        raise NotImplementedError("only the 'ot' U-Net is implemented")
+
+    def initialization(self, noisy_img, t0):
+        noise = self.init_noise if self.init_noise is not None else torch.randn(noisy_img.shape).to(noisy_img.device)
+        return t0 * noisy_img + (1 - t0) * noise
+
+    # schedule scalars of iteration `it`, with the reference's own fp32 expressions (ot_ode.py:69-73, 96, 133-143)
+    def _scalars(self, iteration, delta, problem, B, dev):
+        t1 = torch.ones(B) * delta * iteration
+        omt = 1 - t1
+        if problem == "superresolution":    # reproduces `delta * iteration**2` (ot_ode.py:96)
+            rt2 = torch.tensor((1 - delta * iteration) ** 2 / ((1 - delta * iteration) ** 2 + delta * iteration ** 2)).expand(B).clone()
+        else:
+            rt2 = (1 - t1) ** 2 / ((1 - t1) ** 2 + t1 ** 2)
+        t = t1
+        gamma = torch.ones(B) if self.args.gamma == "constant" else torch.sqrt(t / (t ** 2 + (1 - t) ** 2))
+        coef = (1 - t) / t * gamma
+        f = lambda a: a.to(torch.float32).contiguous().to(dev)
+        return f(t1), f(omt), f(rt2), f(coef)
+
+    def restore_batch(self, noisy_img, degradation, sigma_noise, iter_cb=None):
+        args = self.args
+        problem = args.problem
+        if problem not in ("denoising", "inpainting", "random_inpainting", "superresolution"):
+            raise NotImplementedError(f"ot_ode closed-form solve for '{problem}' is not implemented by this engine")
+        steps, delta = args.steps_ode, 1 / args.steps_ode
+        B = noisy_img.shape[0]
+        Cc, Hh = self.model.input_channels, self.model.input_height
+        dev = noisy_img.device
+        d = degradation.descriptor(B, Hh, Hh, dev)
+        y = noisy_img.contiguous().float()
+        x = self.initialization(degradation.H_adj(y.clone()), args.start_time).contiguous()     # ot_ode.py:50-52
+        vec = torch.empty_like(x)
+        n = x[0].numel()
+        st = _lib.current_stream_ptr()
+        for iteration in range(int(steps * args.start_time), int(steps)):
+            t1, omt, rt2, coef = self._scalars(iteration, delta, problem, B, dev)
+            vt = self.model.forward_retain(x, t1)
+            _lib.check(self.lib.pf_ot_ode_vec(C.byref(d), x.data_ptr(), vt.data_ptr(), y.data_ptr(), omt.data_ptr(), rt2.data_ptr(),
+                                              float(np.float32(sigma_noise) ** 2) if problem == "superresolution" else float(sigma_noise ** 2),
+                                              vec.data_ptr(), B, Cc, Hh, Hh, st), None, "pf_ot_ode_vec")
+            g = self.model.backward(vec)
+            _lib.check(self.lib.pf_ot_ode_update(x.data_ptr(), vt.data_ptr(), vec.data_ptr(), g.data_ptr(), omt.data_ptr(), coef.data_ptr(),
+                                                 float(delta), B, n, st), None, "pf_ot_ode_update")
+            if iter_cb is not None:
+                iter_cb(iteration, x)
+        return x
+
+    def solve_ip(self, test_loader, degradation, sigma_noise, H_funcs=None):
+        self.args.sigma_noise = sigma_noise
+        H, H_adj = degradation.H, degradation.H_adj
+        steps = self.args.steps_ode
+        loader = iter(test_loader)
+        for batch in range(self.args.max_batch):
+            (clean_img, labels) = next(loader)
+            self.args.batch = batch
+            noisy_img = H(clean_img.clone().to(self.device))
+            if self.measurement_noise is not None:
+                noise = self.measurement_noise(batch, noisy_img)
+            else:
+                torch.manual_seed(batch)
+                noise = torch.randn(noisy_img.shape, dtype=torch.float32).to(self.device)
+            noisy_img = noisy_img + noise * sigma_noise
+            clean_img = clean_img.to('cpu')
+            if self.args.compute_time:
+                torch.cuda.synchronize(); t0 = perf_counter()
+
+            def on_iter(iteration, x):
+                if self.args.save_results and (iteration % 10 == 0 or self.should_save_image(iteration, steps)):
+                    utils.compute_psnr(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=iteration)
+
+            x = self.restore_batch(noisy_img, degradation, sigma_noise, iter_cb=on_iter if self.args.save_results else None)
+            self.last_restored = x
+            if self.args.compute_time:
+                torch.cuda.synchronize()
+                utils.save_time_use({"batch": batch, "time_per_batch": perf_counter() - t0}, self.args)
+            if self.args.save_results:
+                utils.compute_psnr(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=int(steps) - 1)
+        if self.args.save_results:
+            utils.compute_average_psnr(self.args)
+
+    def should_save_image(self, iteration, steps):
+        return iteration % (steps // 10) == 0
+
+    def run_method(self, data_loaders, degradation, sigma_noise):
+        folder = utils.get_save_path_ip(self.args.dict_cfg_method)
+        self.args.save_path_ip = os.path.join(self.args.save_path, folder)
+        os.makedirs(self.args.save_path_ip, exist_ok=True)
+        self.solve_ip(data_loaders[self.args.eval_split], degradation, sigma_noise)

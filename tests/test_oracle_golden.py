@@ -144,3 +144,40 @@ def test_engine_rng_restatement_statistics():
     assert [hex(int(v)) for v in r] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
     r = O.philox4x32_10(np.full((1, 4), 0xFFFFFFFF, np.uint32), np.full(2, 0xFFFFFFFF, np.uint32))[0]
     assert [hex(int(v)) for v in r] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+
+
+# ---- OT-ODE (pnpflow/methods/ot_ode.py) ------------------------------------------------------
+@pytest.mark.parametrize("net", ["mnist", "tiny4"])
+def test_unet_vjp_matches_reference(golden, net):
+    g = golden("vjp_" + net)
+    cfg = O.unet_config(**CFGS[net]); sd = O.synthetic_state_dict(cfg, 0)
+    S, C = cfg["input_height"], cfg["input_channels"]
+    x = det_normal((2, C, S, S), 51); vec = det_normal((2, C, S, S), 52)
+    out = O.unet_vjp(sd, cfg, x, torch.from_numpy(g["t"]), vec)
+    np.testing.assert_allclose(out.numpy(), g["g"], atol=2e-5)
+
+
+OT_CASES = [("tiny4_random_inpainting", "tiny4", "random_inpainting", lambda S: (O.RandomInpainting(0.7), 0.01), 0.1, "constant"),
+            ("tiny4_inpainting", "tiny4", "inpainting", lambda S: (O.BoxInpainting(10), 0.05), 0.1, "gamma_t"),
+            ("tiny4_superresolution", "tiny4", "superresolution", lambda S: (O.Superresolution(2, S), 0.05), 0.1, "constant"),
+            ("mnist_denoising", "mnist", "denoising", lambda S: (O.Denoising(), 0.2), 0.3, "gamma_t")]
+
+
+@pytest.mark.parametrize("tag,net,problem,mk,t0,gamma", OT_CASES)
+def test_ot_ode_trajectory_matches_reference(golden, tag, net, problem, mk, t0, gamma):
+    g = golden("ot_ode_traj_" + tag)
+    cfg = O.unet_config(**CFGS[net]); sd = O.synthetic_state_dict(cfg, 0)
+    S, C = cfg["input_height"], cfg["input_channels"]
+    degradation, sigma = mk(S)
+    steps = int(g["steps"])
+    clean = det_image((2, C, S, S), 31)
+    y = O.make_measurement(clean, degradation, sigma, 0, noise=det_normal(tuple(degradation.H(clean).shape), 61, 0))
+    np.testing.assert_allclose(y.numpy(), g["noisy"], atol=1e-6)
+    its = {}
+    x = O.ot_ode_restore(lambda a, t: O.unet_forward(sd, cfg, a, t), lambda a, t, v: O.unet_vjp(sd, cfg, a, t, v), degradation, problem,
+                         y, sigma, steps=steps, start_time=t0, gamma=gamma,
+                         init_noise=det_normal(tuple(degradation.H_adj(y).shape), 61, 1), record=lambda it, xx: its.__setitem__(it, xx.clone()))
+    first = int(g["first"])
+    for it in (first, first + 1, steps - 1):
+        ref = g[f"x_it{it}"]
+        np.testing.assert_allclose(its[it].numpy(), ref, atol=1e-4 * max(1.0, float(np.abs(ref).max())), err_msg=f"iterate {it}")

@@ -204,13 +204,69 @@ def gen_traj(models, degr, utils, pnp):
         print("traj", tag, iterates[9].abs().mean().item())
 
 
+def gen_ot_ode(models, degr, utils):
+    """Real OT_ODE.solve_ip (pnpflow/methods/ot_ode.py) iterates + a stand-alone VJP."""
+    import pnpflow.methods.ot_ode as ot
+    # stand-alone J^T vec on the MNIST net and the tiny4 net
+    for net, B in (("mnist", 2), ("tiny4", 2)):
+        m, cfg, sd = build_ref_unet(models, net)
+        c = CFGS[net]; S = c["input_height"]
+        x = det_normal((B, c["input_channels"], S, S), 51); vec = det_normal((B, c["input_channels"], S, S), 52)
+        t = torch.tensor([0.25, 0.8][:B])
+        g = torch.autograd.functional.vjp(lambda z: m(z, t), inputs=x, v=vec)[1]
+        np.savez_compressed(os.path.join(OUT, f"vjp_{net}.npz"), t=t.numpy(), g=g.numpy())
+        print("vjp", net, g.abs().mean().item())
+    cases = [("tiny4_random_inpainting", "tiny4", "random_inpainting", lambda S: (degr.RandomInpainting(0.7), 0.01), 0.1, "constant"),
+             ("tiny4_inpainting", "tiny4", "inpainting", lambda S: (degr.BoxInpainting(10), 0.05), 0.1, "gamma_t"),
+             ("tiny4_superresolution", "tiny4", "superresolution", lambda S: (degr.Superresolution(2, S, device="cpu"), 0.05), 0.1, "constant"),
+             ("mnist_denoising", "mnist", "denoising", lambda S: (degr.Denoising(), 0.2), 0.3, "gamma_t")]
+    steps, B = 10, 2
+    for tag, net, problem, mk, t0, gamma in cases:
+        m, cfg, sd = build_ref_unet(models, net)
+        c = CFGS[net]; S = c["input_height"]
+        degradation, sigma = mk(S)
+        clean = det_image((B, c["input_channels"], S, S), 31)
+        args = utils.CfgNode(dict(method="ot_ode", model="ot", dataset="celeba", problem=problem, steps_ode=steps, start_time=t0,
+                                  gamma=gamma, max_batch=1, compute_time=False, compute_memory=False, save_results=True, batch=0,
+                                  save_path_ip="/tmp"))
+        iterates = {}; seq = {"n": 0}
+
+        def fake_randn_like(like, **kw):
+            i = seq["n"]; seq["n"] += 1
+            return det_normal(tuple(like.shape), 61, i)        # call 0: measurement noise, call 1: initialisation noise
+
+        def cap_psnr(clean_img, noisy_img, rec_img, a, H_adj, iter="final"):
+            iterates.setdefault(int(iter), rec_img.clone()); iterates["noisy"] = noisy_img.clone()
+        noop = lambda *a, **k: None
+        saved = (torch.randn_like, utils.compute_psnr, utils.compute_ssim, utils.compute_lpips, utils.save_images,
+                 utils.compute_average_psnr, utils.compute_average_ssim, utils.compute_average_lpips)
+        torch.randn_like = fake_randn_like
+        utils.compute_psnr, utils.compute_ssim, utils.compute_lpips, utils.save_images = cap_psnr, noop, noop, noop
+        utils.compute_average_psnr = utils.compute_average_ssim = utils.compute_average_lpips = noop
+        try:
+            ot.OT_ODE(m, torch.device("cpu"), args).solve_ip([(clean, torch.zeros(B))], degradation, sigma)
+        finally:
+            (torch.randn_like, utils.compute_psnr, utils.compute_ssim, utils.compute_lpips, utils.save_images,
+             utils.compute_average_psnr, utils.compute_average_ssim, utils.compute_average_lpips) = saved
+        assert seq["n"] == 2
+        first = int(steps * t0)
+        rec = dict(steps=np.array(steps), start_time=np.array(t0), sigma=np.array(sigma), noisy=iterates["noisy"].numpy(),
+                   first=np.array(first))
+        for it in (first, first + 1, steps - 1):
+            rec[f"x_it{it}"] = iterates[it].numpy()
+        np.savez_compressed(os.path.join(OUT, f"ot_ode_traj_{tag}.npz"), **rec)
+        print("ot_ode", tag, iterates[steps - 1].abs().mean().item())
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     models, degr, utils, pnp = import_reference()
-    which = sys.argv[1:] or ["unet", "degr", "traj"]
+    which = sys.argv[1:] or ["unet", "degr", "traj", "ot_ode"]
     if "unet" in which:
         gen_unet(models)
     if "degr" in which:
         gen_degradations(degr, utils)
     if "traj" in which:
         gen_traj(models, degr, utils, pnp)
+    if "ot_ode" in which:
+        gen_ot_ode(models, degr, utils)

@@ -26,6 +26,8 @@ WORKLOADS = {
     "c2": dict(dim=128, B=32, problem="inpainting", alpha=0.5, steps=100, ns=5, nres=6, label="CelebA-128 box-inpainting pnp_flow B=32/GPU 100x5 (BASELINE configs[1])"),
     "c3": dict(dim=128, B=64, problem="gaussian_deblurring_FFT", alpha=0.01, steps=100, ns=5, nres=6, label="CelebA-128 Gaussian deblurring pnp_flow B=64/GPU 100x5 (BASELINE configs[2])"),
     "c4": dict(dim=256, B=16, problem="superresolution", alpha=0.3, steps=100, ns=5, nres=6, label="AFHQ-256 superresolution x4 pnp_flow B=16/GPU 100x5 (BASELINE configs[3])"),
+    "c5": dict(dim=256, B=32, problem="random_inpainting", method="ot_ode", start_time=0.1, gamma="constant", alpha=0.0, steps=100, ns=1, nres=6,
+               label="AFHQ-256 random-inpainting ot_ode B=32/GPU steps_ode=100 start_time=0.1 (BASELINE configs[4])"),
     "tiny": dict(dim=64, B=4, problem="inpainting", alpha=0.5, steps=10, ns=2, nres=1, label="4-level test net 64x64 (smoke)"),
 }
 
@@ -40,13 +42,15 @@ def det_image(shape, seed):
     return ((x - lo) / (hi - lo) * 2 - 1).contiguous()
 
 
-def make_problem(D, problem, dim):
+def make_problem(D, problem, dim, global_batch=None, batch_offset=0):
     if problem == "inpainting":
         return D.BoxInpainting({64: 10, 128: 20, 256: 40}[dim]), 0.05
     if problem == "gaussian_deblurring_FFT":
         return D.GaussianDeblurring({128: 1.0, 256: 3.0}[dim], 61, "fft", 3, dim), 0.05
     if problem == "superresolution":
         return D.Superresolution({128: 2, 256: 4}[dim], dim), 0.05
+    if problem == "random_inpainting":
+        return D.RandomInpainting(0.7, global_batch=global_batch, batch_offset=batch_offset), 0.01
     raise ValueError(problem)
 
 
@@ -140,17 +144,25 @@ def main():
     sd = O.synthetic_state_dict(cfg, 0)
     model = UNet(3, dim, 32, ch_mult=(1, 2, 4, 8), num_res_blocks=wl["nres"], attn_resolutions=(16, 8), device_index=local)
     model.load_state_dict(sd)
-    degradation, sigma = make_problem(D, wl["problem"], dim)
+    lo, hi = shard_range(world * B, rank, world)
+    degradation, sigma = make_problem(D, wl["problem"], dim, global_batch=world * B, batch_offset=lo)
+    is_ode = wl.get("method") == "ot_ode"
 
-    args = CfgNode(dict(method="pnp_flow", model="ot", problem=wl["problem"], noise_type="gaussian", num_samples=wl["ns"],
+    args = CfgNode(dict(method=wl.get("method", "pnp_flow"), model="ot", problem=wl["problem"], noise_type="gaussian", num_samples=wl["ns"],
                         steps_pnp=wl["steps"], lr_pnp=1.0, gamma_style="alpha_1_minus_t", alpha=wl["alpha"], max_batch=1,
+                        steps_ode=wl["steps"], start_time=wl.get("start_time", 0.1), gamma=wl.get("gamma", "constant"),
                         compute_time=False, compute_memory=False, save_results=False, batch=0, sigma_noise=sigma))
-    solver = PNP_FLOW(model, dev, args)
-    solver.use_graph = not a.no_graph
-    solver.noise_seed = 2024
+    if is_ode:
+        from pnpflow_amd.methods.ot_ode import OT_ODE
+        solver = OT_ODE(model, dev, args)
+        gen0 = np.random.Generator(np.random.Philox(key=[98, rank]))
+        solver.init_noise = torch.from_numpy(gen0.standard_normal(size=(B, 3, dim, dim), dtype=np.float32)).to(dev)
+    else:
+        solver = PNP_FLOW(model, dev, args)
+        solver.use_graph = not a.no_graph
+        solver.noise_seed = 2024
 
     # synthetic batch of this rank (global batch = world*B, rank r owns [r*B, (r+1)*B)), resident in HBM
-    lo, hi = shard_range(world * B, rank, world)
     clean = det_image((B, 3, dim, dim), 1234 + rank).to(dev)
     gen = np.random.Generator(np.random.Philox(key=[99, rank]))
     y = degradation.H(clean)
@@ -159,6 +171,8 @@ def main():
 
     def step(i):
         args.batch = i            # selects the Philox noise stream block
+        if is_ode:
+            return solver.restore_batch(y, degradation, sigma)
         return solver.restore_batch(y, degradation, sigma, lr)
 
     for i in range(a.warmup):
@@ -219,13 +233,17 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["label"], "image": f"{dim}x{dim}x3", "batch_per_gpu": B, "global_batch": world * B,
                        "steps_pnp": wl["steps"], "num_samples": wl["ns"], "weights": "synthetic seed 0 (no checkpoint offline)",
-                       "noise": "on-device Philox4x32-10", "hipgraph": bool(solver.use_graph), "parallelism": f"dp{world} (independent batches)"},
+                       "noise": "on-device Philox4x32-10", "hipgraph": bool(getattr(solver, "use_graph", False)),
+                       "parallelism": f"dp{world} (independent batches)"},
             "psnr_db": round(psnr_mean, 4),
             "roofline": roof,
         }
-        if fwd_flops:
+        if fwd_flops and not is_ode:
             out["unet_tflops_end_to_end"] = round(total_images * wl["steps"] * wl["ns"] * fwd_flops / dt / 1e12, 2)
-        if not a.no_cpu_baseline and world == 1:
+        if fwd_flops and is_ode:   # algorithmic: 1 forward + 1 input-gradient backward (= 2 forward-equivalents) per Euler step
+            n_it = wl["steps"] - int(wl["steps"] * wl["start_time"])
+            out["unet_tflops_end_to_end"] = round(total_images * n_it * 2 * fwd_flops / dt / 1e12, 2)
+        if not a.no_cpu_baseline and world == 1 and not is_ode:
             out["cpu_baseline"] = cpu_baseline(wl, sd, cfg)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -364,14 +364,16 @@ def test_ot_ode_pointwise_steps(hip):
         ref = do.H_adj(sol)
         d = dg.descriptor(B, S, S, torch.device("cuda"))
         vec = torch.empty((B, 3, S, S), device="cuda")
-        rc = lib.pf_ot_ode_vec(C.byref(d), x.cuda().data_ptr(), vt.cuda().data_ptr(), y.cuda().data_ptr(), omt.cuda().data_ptr(), rt2.cuda().data_ptr(),
+        xd_, vtd_, yd_, omd_, rtd_ = x.cuda(), vt.cuda(), y.cuda(), omt.cuda(), rt2.cuda()     # keep the device copies alive
+        rc = lib.pf_ot_ode_vec(C.byref(d), xd_.data_ptr(), vtd_.data_ptr(), yd_.data_ptr(), omd_.data_ptr(), rtd_.data_ptr(),
                                sigma ** 2, vec.data_ptr(), B, 3, S, S, hip.current_stream_ptr())
         assert rc == 0, problem
         np.testing.assert_allclose(vec.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-5 * float(ref.abs().max()), err_msg=problem)
     coef = torch.tensor([1.7, 0.4]); delta = 0.01
     xd = x.cuda().clone(); vecd = det_normal((B, 3, S, S), 85)
-    assert lib.pf_ot_ode_update(xd.data_ptr(), vt.cuda().data_ptr(), vecd.cuda().data_ptr(), gg.cuda().data_ptr(), omt.cuda().data_ptr(),
-                                coef.cuda().data_ptr(), delta, B, 3 * S * S, hip.current_stream_ptr()) == 0
+    vtd_, vecd_, ggd_, omd_, cfd_ = vt.cuda(), vecd.cuda(), gg.cuda(), omt.cuda(), coef.cuda()
+    assert lib.pf_ot_ode_update(xd.data_ptr(), vtd_.data_ptr(), vecd_.data_ptr(), ggd_.data_ptr(), omd_.data_ptr(),
+                                cfd_.data_ptr(), delta, B, 3 * S * S, hip.current_stream_ptr()) == 0
     ref = x + delta * (vt + coef.view(-1, 1, 1, 1) * (vecd + omt.view(-1, 1, 1, 1) * gg))
     np.testing.assert_allclose(xd.cpu().numpy(), ref.numpy(), atol=1e-6)
 

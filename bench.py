@@ -219,7 +219,10 @@ def main():
         model.profile(False)
         peak = 157.3   # TFLOP/s, fp32 MFMA dense peak (MI355X_MICROARCH.md)
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=None,
+        # HBM bytes per conv-GEMM launch from the PMC passes committed in profiles/r01_pmc_hbm_traffic_forward_c2.md
+        # (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, averaged over the 170 launches of one c2 forward); only known for c2
+        traffic = 93.4e6 if a.workload == "c2" else None
+        roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=traffic,
                     kernel="conv_mfma_kernel (fp32 32x32x2 MFMA implicit GEMM)", launches=int(launches // n_fw),
                     avg_launch_us=round(ms * 1e3 / max(1, launches), 2),
                     algorithmic_gflop_per_launch=round(flops / max(1, launches) / 1e9, 4))

@@ -34,9 +34,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float silu_fast(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
 
-template <int MT, int NT, int WM, int WN, int S, int UP, int BM>
+template <int MT, int NT, int WM, int WN, int S, int UP, int BM, int KC>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
-    constexpr int KC = CONV_KC, KCP = KC + 4, KQ = KC / 4;
+    // KC = input channels per K-chunk: 16 for 3x3 segments; 64 for launches made only of 1-tap segments
+    // (1x1 convs, attention matmuls), whose chunks would otherwise be 2 k-steps between two barriers
+    constexpr int KCP = KC + 4, KQ = KC / 4, KS = KC / 8;
     constexpr int TH = 2 * MT * WM, TW = 16;
     constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PP = PH * PW;
     constexpr int BN = WN * NT * 32;
@@ -163,9 +165,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) nclamp[nt] = min(nbase + nt * 32, p.Cout - 1);
     auto load_b = [&](const ConvSeg& sg, int ch, int s, float4 (&dst)[NT]) {
-        const int tap = s >> 1, ks = s & 1;
+        const int tap = s / KS, ks = s % KS;
         if constexpr (BM == 0) {
-            const float* wp = sg.w + ((size_t)(ch * sg.taps + tap) * 2 + ks) * ((size_t)p.Cout * 8) + hi * 4;
+            // fragment-major repack: [chunk16][tap][kstep(2)][Cout][8]; for a 1-tap segment that is simply [kstep][Cout][8]
+            const size_t kidx = (KC == 16) ? (size_t)(ch * sg.taps + tap) * 2 + ks : (size_t)ch * KS + ks;
+            const float* wp = sg.w + kidx * ((size_t)p.Cout * 8) + hi * 4;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) dst[nt] = *reinterpret_cast<const float4*>(wp + (size_t)nclamp[nt] * 8);
         } else {   // generic strided operand (attention): element (n, k) at w + b*w_bs + n*w_ns + k*w_ks
@@ -191,16 +195,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         if (nch * KC >= sg.C) { nsi = si + 1; nch = 0; }
         const bool more = nsi < p.nseg;
 
-        const int nsteps = (p.dbg & 1) ? 0 : sg.taps * 2;
+        const int nsteps = (p.dbg & 1) ? 0 : sg.taps * KS;
         float4 b0[NT], b1[NT], b2[NT];
-        if (nsteps > 0) { load_b(sg, ch, 0, b0); load_b(sg, ch, 1, b1); }
+        if (nsteps > 0) { load_b(sg, ch, 0, b0); load_b(sg, ch, min(1, nsteps - 1), b1); }
         if (more && !(p.dbg & 2)) prefetch(nsi, nch);   // issued after the first two B fragments: the
                                                         // in-order vmcnt wait for them does not drag these along
         // one k-step: 8 input channels of one tap.  `bc`/`ac` hold this step's B / A fragments, `bl`
         // receives the B fragments of step s+2 and `al` the A fragments of step s+1 (register rings
         // with static names: a rotating copy would make the compiler wait for what it just issued).
         auto load_a = [&](int s, float4 (&dst)[MT]) {
-            const int tap = s >> 1, ks = s & 1;
+            const int tap = s / KS, ks = s % KS;
             const int ky = sg.taps == 9 ? tap / 3 : 1, kx = sg.taps == 9 ? tap % 3 : 1;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -231,14 +235,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         };
         float4 a0[MT], a1[MT];
         if (A_PREFETCH && nsteps > 0) load_a(0, a0);
-        if (nsteps == 18) {
-            for (int s = 0; s < 18; s += 6) {
-                k_step(s, b0, b2, a0, a1);     k_step(s + 1, b1, b0, a1, a0); k_step(s + 2, b2, b1, a0, a1);
-                k_step(s + 3, b0, b2, a1, a0); k_step(s + 4, b1, b0, a0, a1); k_step(s + 5, b2, b1, a1, a0);
-            }
-        } else if (nsteps == 2) {
-            k_step(0, b0, b2, a0, a1); k_step(1, b1, b0, a1, a0);
+        // nsteps is 18 (3x3, KC 16), 2 (1 tap, KC 16) or 8 (1 tap, KC 64): groups of 6 + a tail of 2
+        int s = 0;
+        for (; s + 6 <= nsteps; s += 6) {
+            k_step(s, b0, b2, a0, a1);     k_step(s + 1, b1, b0, a1, a0); k_step(s + 2, b2, b1, a0, a1);
+            k_step(s + 3, b0, b2, a1, a0); k_step(s + 4, b1, b0, a0, a1); k_step(s + 5, b2, b1, a1, a0);
         }
+        if (nsteps - s == 2) { k_step(s, b0, b2, a0, a1); k_step(s + 1, b1, b0, a1, a0); }
         if (!more) break;
         si = nsi; ch = nch;
     }
@@ -288,15 +291,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     }
 }
 
-template <int MT, int NT, int WM, int WN, int S, int UP, int BM>
+template <int MT, int NT, int WM, int WN, int S, int UP, int BM, int KC>
 static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
-    constexpr int KCP = CONV_KC + 4;
+    constexpr int KCP = KC + 4;
     constexpr int TH = 2 * MT * WM, TW = 16;
     constexpr int PP = ((TH - 1) * S + 3) * ((TW - 1) * S + 3);
     constexpr int BN = WN * NT * 32;
     const size_t lds = (size_t)(PP * KCP + 2 * ((p.gn_C + 3) & ~3)) * sizeof(float);
     static bool attr_set = false;
-    auto kern = conv_mfma_kernel<MT, NT, WM, WN, S, UP, BM>;
+    auto kern = conv_mfma_kernel<MT, NT, WM, WN, S, UP, BM, KC>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -312,20 +315,20 @@ static long wg_count(const ConvParams& p, int TH, int BN) {
     return (long)p.B * ((p.H + TH - 1) / TH) * ((p.W + 15) / 16) * ((p.Cout + BN - 1) / BN);
 }
 
-template <int S, int UP, int BM>
+template <int S, int UP, int BM, int KC>
 static hipError_t launch_sel(const ConvParams& p, hipStream_t stream) {
     static const long MIN_WGS = getenv("PNPFLOW_HIP_MIN_WGS") ? atol(getenv("PNPFLOW_HIP_MIN_WGS")) : 512;   // >= 2 workgroups per CU
     if (S == 1) {
-        if (p.Cout <= 32) return launch_cfg<2, 1, 4, 1, S, UP, BM>(p, stream);                                    // 16x16 px x 32
-        if (p.Cout <= 64 && wg_count(p, 16, 64) >= MIN_WGS) return launch_cfg<2, 2, 4, 1, S, UP, BM>(p, stream);  // 16x16 px x 64
-        if (p.Cout > 64 && wg_count(p, 8, 128) >= MIN_WGS) return launch_cfg<2, 2, 2, 2, S, UP, BM>(p, stream);   // 8x16 px x 128
-        if (p.Cout > 64 && wg_count(p, 4, 128) >= MIN_WGS) return launch_cfg<1, 2, 2, 2, S, UP, BM>(p, stream);   // 4x16 px x 128
-        if (wg_count(p, 8, 64) >= MIN_WGS) return launch_cfg<1, 2, 4, 1, S, UP, BM>(p, stream);                   // 8x16 px x 64
-        return launch_cfg<1, 1, 2, 2, S, UP, BM>(p, stream);                                                      // 4x16 px x 64
+        if (p.Cout <= 32) return launch_cfg<2, 1, 4, 1, S, UP, BM, KC>(p, stream);                                    // 16x16 px x 32
+        if (p.Cout <= 64 && wg_count(p, 16, 64) >= MIN_WGS) return launch_cfg<2, 2, 4, 1, S, UP, BM, KC>(p, stream);  // 16x16 px x 64
+        if (p.Cout > 64 && wg_count(p, 8, 128) >= MIN_WGS) return launch_cfg<2, 2, 2, 2, S, UP, BM, KC>(p, stream);   // 8x16 px x 128
+        if (p.Cout > 64 && wg_count(p, 4, 128) >= MIN_WGS) return launch_cfg<1, 2, 2, 2, S, UP, BM, KC>(p, stream);   // 4x16 px x 128
+        if (wg_count(p, 8, 64) >= MIN_WGS) return launch_cfg<1, 2, 4, 1, S, UP, BM, KC>(p, stream);                   // 8x16 px x 64
+        return launch_cfg<1, 1, 2, 2, S, UP, BM, KC>(p, stream);                                                      // 4x16 px x 64
     } else {
-        if (p.Cout <= 32) return launch_cfg<1, 1, 4, 1, S, UP, BM>(p, stream);                                    // 8x16 px x 32
-        if (p.Cout <= 64) return launch_cfg<1, 2, 4, 1, S, UP, BM>(p, stream);                                    // 8x16 px x 64
-        return launch_cfg<1, 1, 2, 2, S, UP, BM>(p, stream);                                                      // 4x16 px x 64
+        if (p.Cout <= 32) return launch_cfg<1, 1, 4, 1, S, UP, BM, KC>(p, stream);                                    // 8x16 px x 32
+        if (p.Cout <= 64) return launch_cfg<1, 2, 4, 1, S, UP, BM, KC>(p, stream);                                    // 8x16 px x 64
+        return launch_cfg<1, 1, 2, 2, S, UP, BM, KC>(p, stream);                                                      // 4x16 px x 64
     }
 }
 
@@ -335,12 +338,15 @@ hipError_t launch_conv(const ConvParams& p, int stride, int up, hipStream_t stre
     if (generic) {
         for (int i = 0; i < p.nseg; ++i) if (p.seg[i].w_mode == 0) return hipErrorInvalidValue;   // not mixed
         if (stride != 1 || up) return hipErrorInvalidValue;
-        return launch_sel<1, 0, 1>(p, stream);
     }
-    if (stride == 2) return launch_sel<2, 0, 0>(p, stream);
-    if (up == 2) return launch_sel<1, 2, 0>(p, stream);
-    if (up) return launch_sel<1, 1, 0>(p, stream);
-    return launch_sel<1, 0, 0>(p, stream);
+    bool all_1tap = true;
+    for (int i = 0; i < p.nseg; ++i) all_1tap &= p.seg[i].taps == 1 && p.seg[i].C >= 64;
+    if (all_1tap && stride == 1 && !up) return generic ? launch_sel<1, 0, 1, 64>(p, stream) : launch_sel<1, 0, 0, 64>(p, stream);
+    if (generic) return launch_sel<1, 0, 1, 16>(p, stream);
+    if (stride == 2) return launch_sel<2, 0, 0, 16>(p, stream);
+    if (up == 2) return launch_sel<1, 2, 0, 16>(p, stream);
+    if (up) return launch_sel<1, 1, 0, 16>(p, stream);
+    return launch_sel<1, 0, 0, 16>(p, stream);
 }
 
 size_t conv_flops(const ConvParams& p) {

@@ -107,6 +107,7 @@ struct pf_engine {
     std::map<std::string, int> temb_off;   // ResBlock prefix -> offset in the stacked temb projection
     std::map<int, std::unique_ptr<Plan>> plans;
     int retained_B = 0;
+    int precision = 0;   // 0: exact fp32 MFMA; 1: split-fp16 (3 x f16 MFMA, fp32-equivalent) for the packed-weight convs
     SolverBufs sb;
     hipStream_t work_stream = nullptr;   // used when the caller passes the NULL stream and asks for graph replay
     // profiling
@@ -262,9 +263,35 @@ static float* packed_conv(pf_engine* e, const std::string& wname, int lo, int hi
     return upload(e, key, out);
 }
 
+// split-fp16 repack of the same slice: [chunk][tap][Cout][16 hi | 16 lo] halfs, values pre-scaled by 2^8
+static const void* packed_conv16(pf_engine* e, const std::string& wname, int lo, int hi) {
+    const std::string key = wname + "#h" + std::to_string(lo) + ":" + std::to_string(hi);
+    auto it = e->dev.find(key);
+    if (it != e->dev.end()) return it->second;
+    const HostTensor& t = W(e, wname);
+    const int O = (int)t.shape[0], I = (int)t.shape[1], kk = (int)(t.shape[2] * t.shape[3]);
+    const int C = hi - lo, nchunk = (C + CONV_KC - 1) / CONV_KC;
+    std::vector<_Float16> out((size_t)nchunk * kk * O * 32, (_Float16)0.f);
+    for (int chn = 0; chn < nchunk; ++chn)
+        for (int tap = 0; tap < kk; ++tap)
+            for (int n = 0; n < O; ++n)
+                for (int k = 0; k < CONV_KC; ++k) {
+                    const int c = chn * CONV_KC + k;
+                    if (c >= C) continue;
+                    const float w = t.data[((size_t)n * I + lo + c) * kk + tap] * 256.0f;
+                    const _Float16 h = (_Float16)w;
+                    const _Float16 l = (_Float16)(w - (float)h);
+                    const size_t row = (((size_t)chn * kk + tap) * O + n) * 32;
+                    out[row + k] = h; out[row + 16 + k] = l;
+                }
+    std::vector<float> raw(out.size() / 2);
+    memcpy(raw.data(), out.data(), out.size() * sizeof(_Float16));
+    return upload(e, key, raw);
+}
+
 static void fill_packed_seg(ConvSeg& s, const float* w, int taps, int Cout) {
     (void)taps; (void)Cout;
-    s.w = w; s.w_mode = 0; s.w_bs = 0; s.w_cs = 0; s.w_ts = 0; s.w_ns = 0; s.w_ks = 0;
+    s.w = w; s.w_mode = 0; s.w_bs = 0; s.w_cs = 0; s.w_ts = 0; s.w_ns = 0; s.w_ks = 0; s.w16 = nullptr;
 }
 
 // --------------------------------------------------------------------------------------
@@ -325,9 +352,11 @@ static Tensor res_block(Builder& bd, const ResDesc& r, const Tensor& in0, const 
         ConvParams p = base_params(B, H, Wd, H, Wd, h1);
         add_seg(p, in0, 2, 9, 0);
         fill_packed_seg(p.seg[0], packed_conv(e, r.prefix + "conv1.weight", 0, in0.C), 9, r.cout);
+        p.seg[0].w16 = packed_conv16(e, r.prefix + "conv1.weight", 0, in0.C);
         if (in1) {
             add_seg(p, *in1, 2, 9, in0.C);
             fill_packed_seg(p.seg[1], packed_conv(e, r.prefix + "conv1.weight", in0.C, cin), 9, r.cout);
+            p.seg[1].w16 = packed_conv16(e, r.prefix + "conv1.weight", in0.C, cin);
         }
         p.gn_C = cin; p.gn_cpg = cin / 32;
         p.gamma = upload(e, r.prefix + "norm1.weight", W(e, r.prefix + "norm1.weight").data);
@@ -341,6 +370,7 @@ static Tensor res_block(Builder& bd, const ResDesc& r, const Tensor& in0, const 
         ConvParams p = base_params(B, H, Wd, H, Wd, out);
         add_seg(p, h1, 2, 9, 0);
         fill_packed_seg(p.seg[0], packed_conv(e, r.prefix + "conv2.weight", 0, r.cout), 9, r.cout);
+        p.seg[0].w16 = packed_conv16(e, r.prefix + "conv2.weight", 0, r.cout);
         p.gn_C = r.cout; p.gn_cpg = r.cout / 32;
         p.gamma = upload(e, r.prefix + "norm2.weight", W(e, r.prefix + "norm2.weight").data);
         p.beta = upload(e, r.prefix + "norm2.bias", W(e, r.prefix + "norm2.bias").data);
@@ -349,9 +379,11 @@ static Tensor res_block(Builder& bd, const ResDesc& r, const Tensor& in0, const 
             const std::string sw = r.prefix + "shortcut.weight";
             add_seg(p, in0, 0, 1, 0);
             fill_packed_seg(p.seg[p.nseg - 1], packed_conv(e, sw, 0, in0.C), 1, r.cout);
+            p.seg[p.nseg - 1].w16 = packed_conv16(e, sw, 0, in0.C);
             if (in1) {
                 add_seg(p, *in1, 0, 1, 0);
                 fill_packed_seg(p.seg[p.nseg - 1], packed_conv(e, sw, in0.C, cin), 1, r.cout);
+                p.seg[p.nseg - 1].w16 = packed_conv16(e, sw, in0.C, cin);
             }
             const auto& sb = W(e, r.prefix + "shortcut.bias").data;
             for (size_t i = 0; i < bias.size(); ++i) bias[i] += sb[i];
@@ -390,6 +422,7 @@ static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x) {
         ConvParams p = base_params(B, H, Wd, H, Wd, qkv);
         add_seg(p, x, 1, 1, 0);
         fill_packed_seg(p.seg[0], e->dev.at(key + ".w"), 1, 3 * C);
+        p.seg[0].w16 = packed_conv16(e, key + ".w", 0, C);
         p.gn_C = C; p.gn_cpg = C / 32;
         p.gamma = upload(e, pfx + "norm.weight", W(e, pfx + "norm.weight").data);
         p.beta = upload(e, pfx + "norm.bias", W(e, pfx + "norm.bias").data);
@@ -422,6 +455,7 @@ static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x) {
         ConvParams p = base_params(B, H, Wd, H, Wd, out);
         add_seg(p, o, 0, 1, 0);
         fill_packed_seg(p.seg[0], packed_conv(e, pfx + "proj_out.weight", 0, C), 1, C);
+        p.seg[0].w16 = packed_conv16(e, pfx + "proj_out.weight", 0, C);
         p.addvec = upload(e, pfx + "proj_out.bias", W(e, pfx + "proj_out.bias").data); p.addvec_bs = 0;
         p.residual = x.p; p.res_cstride = C;
         push_conv(bd, p);
@@ -441,6 +475,7 @@ static Tensor resample_conv(Builder& bd, const std::string& pfx, const Tensor& x
     ConvParams p = base_params(B, H, Wd, x.H, x.W, out);
     add_seg(p, x, 0, 9, 0);
     fill_packed_seg(p.seg[0], packed_conv(e, pfx + "weight", 0, x.C), 9, x.C);
+    p.seg[0].w16 = packed_conv16(e, pfx + "weight", 0, x.C);
     p.addvec = upload(e, pfx + "bias", W(e, pfx + "bias").data); p.addvec_bs = 0;
     push_conv(bd, p, down ? 2 : 1, down ? 0 : 1);
     if (bd.plan->retain) {
@@ -857,6 +892,18 @@ static int run_backward(pf_engine* e, Plan* plan, const float* vec, float* g, hi
     return PF_OK;
 }
 
+static hipError_t dispatch_conv(pf_engine* e, const Op& op, hipStream_t s) {
+    if (e->precision != 0) {
+        bool ok16 = true;
+        for (int i = 0; i < op.cp.nseg; ++i) ok16 &= op.cp.seg[i].w_mode == 0 && op.cp.seg[i].w16 != nullptr;
+        // mode 2 (auto): the split-fp16 kernel stages weights through LDS per workgroup, which only pays on the
+        // layers with many output pixels (measured: B*H*W >= 64 Ki); the small-spatial deep levels keep the fp32 MFMA
+        if (e->precision == 2) ok16 &= (long)op.cp.B * op.cp.H * op.cp.W >= (getenv("PNPFLOW_HIP_M16") ? atol(getenv("PNPFLOW_HIP_M16")) : 65536);
+        if (ok16) return launch_conv16(op.cp, op.stride, op.up, s);
+    }
+    return launch_conv(op.cp, op.stride, op.up, s);
+}
+
 static int run_plan(pf_engine* e, Plan* plan, const float* x, const float* t, float* v, hipStream_t s) {
     for (auto& op : plan->ops) {
         hipError_t r = hipSuccess;
@@ -872,11 +919,11 @@ static int run_plan(pf_engine* e, Plan* plan, const float* x, const float* t, fl
                     }
                     auto& ev = e->ev_pool[e->ev_used++];
                     hipEventRecord(ev.first, s);
-                    r = launch_conv(op.cp, op.stride, op.up, s);
+                    r = dispatch_conv(e, op, s);
                     hipEventRecord(ev.second, s);
                     e->prof_flops += (double)op.flops;
                 } else {
-                    r = launch_conv(op.cp, op.stride, op.up, s);
+                    r = dispatch_conv(e, op, s);
                 }
                 break;
             case OP_SOFTMAX: r = launch_softmax_rows(op.sm, op.sm_rows, op.sm_cols, s); break;
@@ -996,7 +1043,8 @@ int pf_engine_finalize_weights(pf_engine* e) {
 
 int pf_engine_set_precision(pf_engine* e, int mode) {
     if (!e) return PF_ERR_INVALID;
-    if (mode != 0) { e->err = "only precision mode 0 (exact fp32 MFMA) is implemented"; return PF_ERR_INVALID; }
+    if (mode < 0 || mode > 2) { e->err = "precision mode must be 0 (fp32 MFMA), 1 (split-fp16 MFMA) or 2 (per-layer choice)"; return PF_ERR_INVALID; }
+    e->precision = mode;
     return PF_OK;
 }
 

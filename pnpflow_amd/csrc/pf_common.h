@@ -20,6 +20,7 @@ struct ConvSeg {
     int w_mode;           // 0: fragment-major repack [chunk][tap][kstep(2)][Cout][8] (see packed_conv)
                           // 1: generic strided operand: element (n,k) at b*w_bs + n*w_ns + k*w_ks
     int64_t w_bs, w_cs, w_ts, w_ns, w_ks;
+    const void* w16;      // optional split-fp16 repack [chunk][tap][Cout][16 hi | 16 lo] (x256), see conv_mfma16.hip
 };
 
 struct ConvParams {
@@ -70,6 +71,7 @@ struct TembParams {
 };
 
 hipError_t launch_conv(const ConvParams& p, int stride, int up, hipStream_t s);
+hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t s);   // split-fp16 MFMA variant
 size_t conv_flops(const ConvParams& p);
 hipError_t launch_begin_conv(const EdgeConvParams& p, hipStream_t s);
 hipError_t launch_end_conv(const EdgeConvParams& p, hipStream_t s);

@@ -143,6 +143,11 @@ class UNet:
             out[name] = big[: B * c * h * w].reshape(B, c, h, w).copy()
         return out
 
+    def set_precision(self, mode: int):
+        """0: exact fp32 MFMA; 1: split-fp16 MFMA (fp32-equivalent, 3 x f16 MFMA per product)."""
+        _lib.check(self._lib.pf_engine_set_precision(self._h, int(mode)), self._h, "pf_engine_set_precision")
+        return self
+
     def profile(self, enable: bool):
         _lib.check(self._lib.pf_engine_profile(self._h, 1 if enable else 0), self._h, "pf_engine_profile")
 

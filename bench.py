@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--precision", type=int, default=0, choices=[0, 1, 2],
+                    help="0: exact fp32 MFMA (default, what `dtype`/`roofline` describe); 1: split-fp16 MFMA; 2: per-layer choice")
     a = ap.parse_args()
     wl = WORKLOADS[a.workload]
 
@@ -144,6 +146,7 @@ def main():
     sd = O.synthetic_state_dict(cfg, 0)
     model = UNet(3, dim, 32, ch_mult=(1, 2, 4, 8), num_res_blocks=wl["nres"], attn_resolutions=(16, 8), device_index=local)
     model.load_state_dict(sd)
+    model.set_precision(a.precision)
     lo, hi = shard_range(world * B, rank, world)
     degradation, sigma = make_problem(D, wl["problem"], dim, global_batch=world * B, batch_offset=lo)
     is_ode = wl.get("method") == "ot_ode"
@@ -233,7 +236,9 @@ def main():
         out = {
             "metric": "restored images/sec", "value": round(total_images / dt, 4), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {0: "f32", 1: "f32-equivalent (f16x3 split MFMA, fp32 accumulate)", 2: "f32 / f32-equivalent f16x3 split per layer"}[a.precision],
+            "data": "synthetic",
             "config": {"workload": wl["label"], "image": f"{dim}x{dim}x3", "batch_per_gpu": B, "global_batch": world * B,
                        "steps_pnp": wl["steps"], "num_samples": wl["ns"], "weights": "synthetic seed 0 (no checkpoint offline)",
                        "noise": "on-device Philox4x32-10", "hipgraph": bool(getattr(solver, "use_graph", False)),

@@ -170,10 +170,14 @@ def test_psnr_matches_oracle(hip):
 # ---------------------------------------------------------------------------------------------
 # U-Net velocity field
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", [0, 1, 2])
 @pytest.mark.parametrize("name,B", [("mnist", 3), ("tiny4", 2), ("celeba128", 1), ("afhq256", 1)])
-def test_unet_forward_matches_oracle_and_golden(hip, golden, name, B):
+def test_unet_forward_matches_oracle_and_golden(hip, golden, name, B, precision):
+    """precision 0 = exact fp32 MFMA, 1 = split-fp16 MFMA (3 x f16 MFMA per product), 2 = per-layer choice:
+    all three are held to the SAME tolerance."""
     g = golden("unet_" + name)
     m, cfg, sd = model_for(name)
+    m.set_precision(precision)
     shape = tuple(int(v) for v in g["shape"])
     x = det_normal(shape, 11)
     t = torch.from_numpy(g["t"])
@@ -182,6 +186,7 @@ def test_unet_forward_matches_oracle_and_golden(hip, golden, name, B):
     with torch.no_grad():
         ref = O.unet_forward(sd, cfg, x, t)
     np.testing.assert_allclose(out.numpy(), ref.numpy(), atol=2e-4)
+    m.set_precision(0)
     if "out" in g:     # the real reference's output, committed
         np.testing.assert_allclose(out.numpy(), g["out"], atol=2e-4)
     else:
@@ -220,13 +225,14 @@ def traj_cases():
 
 
 @pytest.mark.parametrize("idx", range(5))
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_pnp_flow_trajectory_matches_reference(hip, golden, idx, use_graph):
+@pytest.mark.parametrize("use_graph,precision", [(False, 0), (True, 0), (True, 1)])
+def test_pnp_flow_trajectory_matches_reference(hip, golden, idx, use_graph, precision):
     from pnpflow_amd.methods.pnp_flow import PNP_FLOW
     from pnpflow_amd.utils import CfgNode, psnr_per_image
     tag, net, problem, mk, sigma = traj_cases()[idx]
     g = golden("pnp_traj_" + tag)
     m, cfg, sd = model_for(net)
+    m.set_precision(precision)
     S, Cc = cfg["input_height"], cfg["input_channels"]
     steps, ns = int(g["steps"]), int(g["num_samples"])
     B = 2
@@ -247,6 +253,7 @@ def test_pnp_flow_trajectory_matches_reference(hip, golden, idx, use_graph):
     clean = det_image((B, Cc, S, S), 31)
     p_hip = psnr_per_image(x, clean.cuda()).cpu()
     p_ref = O.psnr_per_image(torch.from_numpy(g["x_it9"]), clean)
+    m.set_precision(0)
     assert float((p_hip - p_ref).abs().max()) <= 0.05      # north_star: PSNR within +-0.05 dB of the reference
 
 

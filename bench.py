@@ -212,10 +212,13 @@ def main():
     # per-kernel boundaries), rank 0 only
     roof = None
     if rank == 0:
+        # same U-Net batch as the timed region: num_samples*B images per pass when the samples are batched
+        rep = wl["ns"] if getattr(solver, "batch_samples", False) else 1
+        n_fw = 2 if rep > 1 else 4
+        t_dev = torch.full((B * rep,), 0.37, device=dev)
+        zt = (clean + 0.1).repeat(rep, 1, 1, 1)
+        model(zt, t_dev)                     # builds the plan outside the profiled slice
         model.profile(True)
-        n_fw = 4
-        t_dev = torch.full((B,), 0.37, device=dev)
-        zt = clean + 0.1
         for _ in range(n_fw):
             model(zt, t_dev)
         launches, ms, flops = model.profile_read()
@@ -224,7 +227,7 @@ def main():
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # HBM bytes per conv-GEMM launch from the PMC passes committed in profiles/r01_pmc_hbm_traffic_forward_c2.md
         # (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, averaged over the 170 launches of one c2 forward); only known for c2
-        traffic = 93.4e6 if a.workload == "c2" else None
+        traffic = None   # see profiles/r01_pmc_hbm_traffic_forward_c2.md for the PMC passes (B=32 forwards: 93.4 MB per launch)
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=traffic,
                     kernel="conv_mfma_kernel (fp32 32x32x2 MFMA implicit GEMM)", launches=int(launches // n_fw),
                     avg_launch_us=round(ms * 1e3 / max(1, launches), 2),
@@ -242,6 +245,7 @@ def main():
             "config": {"workload": wl["label"], "image": f"{dim}x{dim}x3", "batch_per_gpu": B, "global_batch": world * B,
                        "steps_pnp": wl["steps"], "num_samples": wl["ns"], "weights": "synthetic seed 0 (no checkpoint offline)",
                        "noise": "on-device Philox4x32-10", "hipgraph": bool(getattr(solver, "use_graph", False)),
+                       "unet_batch": B * (wl["ns"] if getattr(solver, "batch_samples", False) else 1),
                        "parallelism": f"dp{world} (independent batches)"},
             "psnr_db": round(psnr_mean, 4),
             "roofline": roof,

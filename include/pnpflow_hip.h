@@ -167,6 +167,7 @@ typedef struct pf_pnp_params {
     uint64_t stream_base;     /* noise stream id of (iteration it, sample s) = stream_base + it*num_samples + s */
     const float* noise;       /* optional device [steps*num_samples][B*C*H*W] injected noise (parity runs) */
     int32_t use_graph;        /* capture one outer iteration in a hipGraph and replay it */
+    int32_t batch_samples;    /* evaluate the num_samples velocities of an iteration as one U-Net pass over num_samples*B images */
 } pf_pnp_params;
 
 /* Runs pnp_flow.py:93 and 102-121 for one batch:  x0 = H_adj(1);  `steps` iterations.

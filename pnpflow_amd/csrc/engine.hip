@@ -80,7 +80,7 @@ struct Plan {
 };
 
 struct SolverBufs {
-    int B = 0; size_t n = 0, ny = 0; int steps = 0;
+    int B = 0; size_t n = 0, ny = 0; int steps = 0, ns = 0;
     float *x = nullptr, *z = nullptr, *zt = nullptr, *v = nullptr, *scratch = nullptr;
     float *t_all = nullptr, *coef_all = nullptr, *t_cur = nullptr, *coef_cur = nullptr;
     int* iter = nullptr;
@@ -113,6 +113,7 @@ struct pf_engine {
     // profiling
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<const Op*> ev_ops;   // op of each recorded event pair (profiling detail)
     size_t ev_used = 0;
     int64_t prof_launches = 0; double prof_ms = 0.0, prof_flops = 0.0;
 };
@@ -918,6 +919,8 @@ static int run_plan(pf_engine* e, Plan* plan, const float* x, const float* t, fl
                         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); e->ev_pool.emplace_back(a, b);
                     }
                     auto& ev = e->ev_pool[e->ev_used++];
+                    if (e->ev_ops.size() < e->ev_used) e->ev_ops.resize(e->ev_used);
+                    e->ev_ops[e->ev_used - 1] = &op;
                     hipEventRecord(ev.first, s);
                     r = dispatch_conv(e, op, s);
                     hipEventRecord(ev.second, s);
@@ -1166,17 +1169,17 @@ int pf_psnr(const float* rec, const float* clean, float* out, int B, int n_per_i
     return PF_OK;
 }
 
-static int ensure_solver(pf_engine* e, int B, size_t n, size_t ny, int steps) {
+static int ensure_solver(pf_engine* e, int B, size_t n, size_t ny, int steps, int ns) {
     SolverBufs& b = e->sb;
-    if (b.B == B && b.n == n && b.ny == ny && b.steps >= steps) return PF_OK;
+    if (b.B == B && b.n == n && b.ny == ny && b.steps >= steps && b.ns >= ns) return PF_OK;
     free_solver(e);
     const size_t tot = (size_t)B * n;
-    HIPCHK(e, hipMalloc(&b.x, tot * 4)); HIPCHK(e, hipMalloc(&b.z, tot * 4)); HIPCHK(e, hipMalloc(&b.zt, tot * 4));
-    HIPCHK(e, hipMalloc(&b.v, tot * 4)); HIPCHK(e, hipMalloc(&b.scratch, 2 * tot * 4));
+    HIPCHK(e, hipMalloc(&b.x, tot * 4)); HIPCHK(e, hipMalloc(&b.z, tot * 4)); HIPCHK(e, hipMalloc(&b.zt, ns * tot * 4));
+    HIPCHK(e, hipMalloc(&b.v, ns * tot * 4)); HIPCHK(e, hipMalloc(&b.scratch, 2 * tot * 4));
     HIPCHK(e, hipMalloc(&b.t_all, (size_t)steps * 4)); HIPCHK(e, hipMalloc(&b.coef_all, (size_t)steps * 4));
-    HIPCHK(e, hipMalloc(&b.t_cur, (size_t)B * 4)); HIPCHK(e, hipMalloc(&b.coef_cur, (size_t)B * 4));
+    HIPCHK(e, hipMalloc(&b.t_cur, (size_t)ns * B * 4)); HIPCHK(e, hipMalloc(&b.coef_cur, (size_t)ns * B * 4));
     HIPCHK(e, hipMalloc(&b.iter, 64));
-    b.B = B; b.n = n; b.ny = ny; b.steps = steps;
+    b.B = B; b.n = n; b.ny = ny; b.steps = steps; b.ns = ns;
     return PF_OK;
 }
 
@@ -1184,10 +1187,28 @@ static int enqueue_iteration(pf_engine* e, Plan* plan, const DegView& dv, const 
                              int H, hipStream_t s) {
     SolverBufs& b = e->sb;
     const int n = C * H * H;
+    const int nsb = prm->batch_samples ? prm->num_samples : 1;
     hipLaunchKernelGGL(prep_iter_kernel, dim3(1), dim3(64), 0, s, (const int*)b.iter, (const float*)b.t_all, (const float*)b.coef_all,
-                       b.t_cur, b.coef_cur, B);
+                       b.t_cur, b.coef_cur, nsb * B);
     hipError_t r = launch_grad_step(dv, b.x, y, b.coef_cur, b.z, B, C, H, H, b.scratch, s);
     if (r != hipSuccess) { e->err = std::string("grad_step: ") + hipGetErrorString(r); return PF_ERR_HIP; }
+    if (prm->batch_samples) {
+        // the num_samples velocity evaluations of one outer iteration are independent given z: run them as ONE
+        // U-Net pass over num_samples*B images (`plan` was built for that batch); the average keeps the
+        // reference's summation order (pnp_flow.py:114-121)
+        const size_t tot = (size_t)B * n;
+        for (int smp = 0; smp < prm->num_samples; ++smp) {
+            r = launch_interp_iter(b.z, b.t_cur, prm->noise, prm->seed, prm->stream_base, b.iter, prm->num_samples, smp, b.zt + smp * tot, B, n, s);
+            if (r != hipSuccess) { e->err = std::string("interpolate: ") + hipGetErrorString(r); return PF_ERR_HIP; }
+        }
+        int rc = run_plan(e, plan, b.zt, b.t_cur, b.v, s);
+        if (rc != PF_OK) return rc;
+        for (int smp = 0; smp < prm->num_samples; ++smp) {
+            const int mode = (smp == 0 ? 1 : 0) | (smp == prm->num_samples - 1 ? 2 : 0);
+            r = launch_denoise_accum(b.x, b.zt + smp * tot, b.v + smp * tot, b.t_cur, mode, (float)prm->num_samples, B, n, s);
+            if (r != hipSuccess) { e->err = std::string("denoise_accum: ") + hipGetErrorString(r); return PF_ERR_HIP; }
+        }
+    } else
     for (int smp = 0; smp < prm->num_samples; ++smp) {
         r = launch_interp_iter(b.z, b.t_cur, prm->noise, prm->seed, prm->stream_base, b.iter, prm->num_samples, smp, b.zt, B, n, s);
         if (r != hipSuccess) { e->err = std::string("interpolate: ") + hipGetErrorString(r); return PF_ERR_HIP; }
@@ -1222,11 +1243,11 @@ int pf_pnp_flow_restore(pf_engine* e, const pf_degradation* d, const pf_pnp_para
     const size_t n = (size_t)C * H * H;
     const int Hy = d->kind == PF_DEG_SUPERRESOLUTION ? H / std::max(1, d->sf) : H;
     const size_t ny = (size_t)C * Hy * Hy;
-    int rc = ensure_solver(e, B, n, ny, prm->steps);
+    int rc = ensure_solver(e, B, n, ny, prm->steps, prm->batch_samples ? prm->num_samples : 1);
     if (rc != PF_OK) return rc;
     SolverBufs& b = e->sb;
     Plan* plan = nullptr;
-    if ((rc = build_plan(e, B, false, &plan)) != PF_OK) return rc;
+    if ((rc = build_plan(e, prm->batch_samples ? B * prm->num_samples : B, false, &plan)) != PF_OK) return rc;
     const DegView dv = to_view(d);
     HIPCHK(e, hipMemcpyAsync(b.t_all, prm->host_t, (size_t)prm->steps * 4, hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(b.coef_all, prm->host_coef, (size_t)prm->steps * 4, hipMemcpyHostToDevice, s));
@@ -1276,10 +1297,19 @@ int pf_engine_profile(pf_engine* e, int enable) {
 int pf_engine_profile_read(pf_engine* e, int64_t* launches, double* ms_conv_gemm, double* flops_conv_gemm) {
     if (!e) return PF_ERR_INVALID;
     HIPCHK(e, hipDeviceSynchronize());
+    FILE* dump = getenv("PNPFLOW_HIP_PROFILE_CSV") ? fopen(getenv("PNPFLOW_HIP_PROFILE_CSV"), "w") : nullptr;
+    if (dump) fprintf(dump, "idx,H,W,Cout,K,nseg,taps0,stride,up,gflop,us,tflops\n");
     for (size_t i = 0; i < e->ev_used; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e->ev_pool[i].first, e->ev_pool[i].second) == hipSuccess) { e->prof_ms += ms; e->prof_launches += 1; }
+        if (dump && i < e->ev_ops.size() && e->ev_ops[i]) {
+            const Op& op = *e->ev_ops[i]; size_t K = 0;
+            for (int j = 0; j < op.cp.nseg; ++j) K += (size_t)op.cp.seg[j].taps * op.cp.seg[j].C;
+            fprintf(dump, "%zu,%d,%d,%d,%zu,%d,%d,%d,%d,%.4f,%.2f,%.2f\n", i, op.cp.H, op.cp.W, op.cp.Cout, K, op.cp.nseg, op.cp.seg[0].taps,
+                    op.stride, op.up, op.flops / 1e9, ms * 1e3, op.flops / (ms * 1e-3) / 1e12);
+        }
     }
+    if (dump) fclose(dump);
     e->ev_used = 0;
     if (launches) *launches = e->prof_launches;
     if (ms_conv_gemm) *ms_conv_gemm = e->prof_ms;

@@ -32,6 +32,7 @@ class PNP_FLOW(object):
         self.noise = None          # optional (steps*num_samples, B, C, H, W) GPU tensor
         self.noise_seed = 0
         self.use_graph = True
+        self.batch_samples = True  # the num_samples evaluations of an iteration run as one pass over num_samples*B images
         self.last_restored = None  # the final x of the last batch (the reference only writes it to disk)
         self.measurement_noise = None   # optional override of the torch.manual_seed(batch) draw (multi-GPU shards)
 
@@ -99,6 +100,7 @@ class PNP_FLOW(object):
             assert nz.numel() == steps * ns * B * Cc * Hh * Hh
             prm.noise = nz.data_ptr()
         prm.use_graph = 1 if self.use_graph else 0
+        prm.batch_samples = 1 if self.batch_samples else 0
         x = torch.empty((B, Cc, Hh, Hh), dtype=torch.float32, device=noisy_img.device)
         y = noisy_img.contiguous().float()
         holder = {}

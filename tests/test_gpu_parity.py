@@ -225,8 +225,8 @@ def traj_cases():
 
 
 @pytest.mark.parametrize("idx", range(5))
-@pytest.mark.parametrize("use_graph,precision", [(False, 0), (True, 0), (True, 1)])
-def test_pnp_flow_trajectory_matches_reference(hip, golden, idx, use_graph, precision):
+@pytest.mark.parametrize("use_graph,precision,batch_samples", [(False, 0, False), (True, 0, False), (True, 0, True), (True, 1, True)])
+def test_pnp_flow_trajectory_matches_reference(hip, golden, idx, use_graph, precision, batch_samples):
     from pnpflow_amd.methods.pnp_flow import PNP_FLOW
     from pnpflow_amd.utils import CfgNode, psnr_per_image
     tag, net, problem, mk, sigma = traj_cases()[idx]
@@ -240,7 +240,7 @@ def test_pnp_flow_trajectory_matches_reference(hip, golden, idx, use_graph, prec
                         lr_pnp=1.0, gamma_style="alpha_1_minus_t", alpha=float(g["alpha"]), max_batch=1, compute_time=False,
                         compute_memory=False, save_results=False, batch=0))
     solver = PNP_FLOW(m, torch.device("cuda"), args)
-    solver.use_graph = use_graph
+    solver.use_graph = use_graph; solver.batch_samples = batch_samples
     solver.noise = torch.stack([det_normal((B, Cc, S, S), 41, 1 + i) for i in range(steps * ns)]).cuda()
     degradation = mk(S)
     y = torch.from_numpy(g["noisy"]).cuda()

@@ -227,7 +227,10 @@ def main():
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # HBM bytes per conv-GEMM launch from the PMC passes committed in profiles/r01_pmc_hbm_traffic_forward_c2.md
         # (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, averaged over the 170 launches of one c2 forward); only known for c2
-        traffic = None   # see profiles/r01_pmc_hbm_traffic_forward_c2.md for the PMC passes (B=32 forwards: 93.4 MB per launch)
+        # HBM bytes per conv-GEMM launch from the PMC passes committed in profiles/r01_pmc_hbm_traffic_forward_c2.md
+        # (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, averaged over the 170 launches of one forward at the U-Net batch of
+        # this workload, 160 images); only collected for c2 at the default precision
+        traffic = 503.7e6 if (a.workload == "c2" and a.precision == 0 and rep == 5) else None
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=traffic,
                     kernel="conv_mfma_kernel (fp32 32x32x2 MFMA implicit GEMM)", launches=int(launches // n_fw),
                     avg_launch_us=round(ms * 1e3 / max(1, launches), 2),

@@ -124,6 +124,9 @@ int pf_degradation_H_adj(const pf_degradation* d, const float* y, float* x, int 
  * scratch: >= 2*B*C*H*W floats for GAUSSIAN_BLUR, may be NULL otherwise. */
 int pf_grad_step(const pf_degradation* d, const float* x, const float* y, const float* coef, float* z,
                  int B, int C, int H, int W, float* scratch, void* stream);
+/* Laplace noise model (pnp_flow.py:42-43): z = x - coef[b] * H_adj(2*heaviside(H(x) - y, 0) - 1), coef[b] = lr_t[b]/sigma */
+int pf_grad_step_laplace(const pf_degradation* d, const float* x, const float* y, const float* coef, float* z,
+                         int B, int C, int H, int W, float* scratch, void* stream);
 /* z_tilde = t[b]*z + (1-t[b])*eps    (interpolation_step, pnp_flow.py:47-48)
  * eps = `noise` if non-NULL, else Philox4x32-10/Box-Muller (seed, stream_id). */
 int pf_interpolate(const float* z, const float* t, const float* noise, uint64_t seed, uint64_t stream_id,
@@ -167,6 +170,7 @@ typedef struct pf_pnp_params {
     uint64_t stream_base;     /* noise stream id of (iteration it, sample s) = stream_base + it*num_samples + s */
     const float* noise;       /* optional device [steps*num_samples][B*C*H*W] injected noise (parity runs) */
     int32_t use_graph;        /* capture one outer iteration in a hipGraph and replay it */
+    int32_t noise_model;      /* 0 gaussian (pf_grad_step), 1 laplace (pf_grad_step_laplace) */
     int32_t batch_samples;    /* evaluate the num_samples velocities of an iteration as one U-Net pass over num_samples*B images */
 } pf_pnp_params;
 

@@ -95,7 +95,8 @@ def main():
         print('sigma_noise', sigma_noise)
         print("[pnpflow_amd] dataset readers are out of scope offline: using synthetic clean images")
         loaders = {s: SyntheticLoader(args.batch_size_ip, args.num_channels, args.dim_image, args.max_batch) for s in ('train', 'val', 'test')}
-        args.save_path = os.path.join(args.output_root, 'results', args.dataset, args.model, args.problem, args.method, args.eval_split)
+        args.save_path = os.path.join(args.output_root, 'results_laplace' if args.noise_type == 'laplace' else 'results', args.dataset, args.model,
+                                      args.problem, args.method, args.eval_split)
         os.makedirs(args.save_path, exist_ok=True)
         if args.method == 'pnp_flow':
             method = PNP_FLOW(model, device, args)

@@ -384,7 +384,7 @@ def learning_rate_strat(lr: float, t: torch.Tensor, gamma_style: str, alpha: flo
 def pnp_flow_restore(model: Callable, degradation: Degradation, noisy_img: torch.Tensor, sigma_noise: float, *,
                      steps: int, num_samples: int, lr_pnp: float = 1.0, gamma_style: str = "alpha_1_minus_t",
                      alpha: float = 1.0, noise_fn: Optional[Callable] = None,
-                     record: Optional[Callable] = None) -> torch.Tensor:
+                     record: Optional[Callable] = None, noise_type: str = "gaussian") -> torch.Tensor:
     """Inner loop of PNP_FLOW.solve_ip for one batch, gaussian noise
     (pnpflow/methods/pnp_flow.py:60-62, 93, 102-121).
 
@@ -392,7 +392,7 @@ def pnp_flow_restore(model: Callable, degradation: Degradation, noisy_img: torch
     (pnp_flow.py:48) so that trajectories are comparable across devices;  record(it, x)
     is called after each outer iteration."""
     H, H_adj = degradation.H, degradation.H_adj
-    lr = sigma_noise ** 2 * lr_pnp                                   # :60-62
+    lr = (sigma_noise ** 2 if noise_type == "gaussian" else sigma_noise) * lr_pnp      # :60-66
     delta = 1.0 / steps
     x = H_adj(torch.ones_like(noisy_img))                            # :93
     if noise_fn is None:
@@ -401,7 +401,12 @@ def pnp_flow_restore(model: Callable, degradation: Degradation, noisy_img: torch
         for it in range(int(steps)):
             t1 = torch.ones(len(x)) * delta * it                     # :107-108
             lr_t = learning_rate_strat(lr, t1, gamma_style, alpha)   # :109
-            z = x - lr_t * (H_adj(H(x) - noisy_img) / sigma_noise ** 2)   # :111-112, :39-41
+            if noise_type == "gaussian":
+                grad = H_adj(H(x) - noisy_img) / sigma_noise ** 2        # :39-41
+            else:                                                        # laplace, :42-43
+                r = H(x) - noisy_img
+                grad = H_adj(2 * torch.heaviside(r, torch.zeros_like(r)) - 1) / sigma_noise
+            z = x - lr_t * grad                                          # :111-112
             x_new = torch.zeros_like(x)
             tv = t1.view(-1, 1, 1, 1)
             for s in range(num_samples):                             # :114-118

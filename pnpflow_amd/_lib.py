@@ -32,7 +32,7 @@ class PfDegradation(C.Structure):
 class PfPnpParams(C.Structure):
     _fields_ = [("steps", C.c_int32), ("num_samples", C.c_int32), ("host_t", C.POINTER(C.c_float)),
                 ("host_coef", C.POINTER(C.c_float)), ("seed", C.c_uint64), ("stream_base", C.c_uint64),
-                ("noise", C.c_void_p), ("use_graph", C.c_int32), ("batch_samples", C.c_int32)]
+                ("noise", C.c_void_p), ("use_graph", C.c_int32), ("noise_model", C.c_int32), ("batch_samples", C.c_int32)]
 
 
 ITER_CB = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
@@ -62,6 +62,7 @@ SIGNATURES = {
     "pf_degradation_H": (C.c_int, [C.POINTER(PfDegradation), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pf_degradation_H_adj": (C.c_int, [C.POINTER(PfDegradation), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pf_grad_step": (C.c_int, [C.POINTER(PfDegradation), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "pf_grad_step_laplace": (C.c_int, [C.POINTER(PfDegradation), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "pf_interpolate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pf_denoise_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "pf_fill_normal": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]),

@@ -1143,7 +1143,13 @@ int pf_degradation_H_adj(const pf_degradation* d, const float* y, float* x, int 
 int pf_grad_step(const pf_degradation* d, const float* x, const float* y, const float* coef, float* z, int B, int C, int H, int W,
                  float* scratch, void* stream) {
     if (!d || !x || !y || !coef || !z) return PF_ERR_INVALID;
-    LAUNCHCHK(launch_grad_step(to_view(d), x, y, coef, z, B, C, H, W, scratch, (hipStream_t)stream));
+    LAUNCHCHK(launch_grad_step(to_view(d), x, y, coef, z, B, C, H, W, scratch, 0, (hipStream_t)stream));
+    return PF_OK;
+}
+int pf_grad_step_laplace(const pf_degradation* d, const float* x, const float* y, const float* coef, float* z, int B, int C, int H, int W,
+                         float* scratch, void* stream) {
+    if (!d || !x || !y || !coef || !z) return PF_ERR_INVALID;
+    LAUNCHCHK(launch_grad_step(to_view(d), x, y, coef, z, B, C, H, W, scratch, 1, (hipStream_t)stream));
     return PF_OK;
 }
 int pf_interpolate(const float* z, const float* t, const float* noise, uint64_t seed, uint64_t stream_id, float* z_tilde, int B,
@@ -1190,7 +1196,7 @@ static int enqueue_iteration(pf_engine* e, Plan* plan, const DegView& dv, const 
     const int nsb = prm->batch_samples ? prm->num_samples : 1;
     hipLaunchKernelGGL(prep_iter_kernel, dim3(1), dim3(64), 0, s, (const int*)b.iter, (const float*)b.t_all, (const float*)b.coef_all,
                        b.t_cur, b.coef_cur, nsb * B);
-    hipError_t r = launch_grad_step(dv, b.x, y, b.coef_cur, b.z, B, C, H, H, b.scratch, s);
+    hipError_t r = launch_grad_step(dv, b.x, y, b.coef_cur, b.z, B, C, H, H, b.scratch, prm->noise_model == 1 ? 1 : 0, s);
     if (r != hipSuccess) { e->err = std::string("grad_step: ") + hipGetErrorString(r); return PF_ERR_HIP; }
     if (prm->batch_samples) {
         // the num_samples velocity evaluations of one outer iteration are independent given z: run them as ONE

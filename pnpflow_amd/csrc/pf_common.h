@@ -100,7 +100,7 @@ struct DegView {       // device-side view of pf_degradation
 hipError_t launch_deg_H(const DegView& d, const float* x, float* y, int B, int C, int H, int W, float* scratch, hipStream_t s);
 hipError_t launch_deg_Hadj(const DegView& d, const float* y, float* x, int B, int C, int H, int W, float* scratch, hipStream_t s);
 hipError_t launch_grad_step(const DegView& d, const float* x, const float* y, const float* coef, float* z,
-                            int B, int C, int H, int W, float* scratch, hipStream_t s);
+                            int B, int C, int H, int W, float* scratch, int laplace, hipStream_t s);
 hipError_t launch_interpolate(const float* z, const float* t, const float* noise, uint64_t seed, uint64_t stream_id,
                               float* zt, int B, int n, hipStream_t s);
 hipError_t launch_interp_iter(const float* z, const float* t, const float* noise, uint64_t seed, uint64_t stream_base,

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void zerofill_kernel(const float* y, float* x,
 // One pass of the separable circular Gaussian (degradations.py:55-89: the FFT product
 // with the rolled 61x61 filter is a circular convolution with outer(g,g)).
 //   dir 0: along x, dir 1: along y;  sign +1: convolution (H), -1: correlation (H_adj)
-//   mode 0: out = val;  1: out = val - aux[i];  2: out = aux[i] - coef[b]*val
+//   mode 0: out = val;  1: out = val - aux[i];  2: out = aux[i] - coef[b]*val;  3: out = sgn(val - aux[i]) in {-1,+1}
+//   (sgn = 2*heaviside(.,0)-1, the Laplace data-fit gradient of pnp_flow.py:42-43)
 __global__ __launch_bounds__(256) void blur_pass_kernel(const float* in, float* out, const float* taps, int ntaps,
                                                         int C, int H, int W, int dir, int sign, int mode,
                                                         const float* aux, const float* coef) {
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(256) void blur_pass_kernel(const float* in, float* 
         const size_t o = (size_t)b * n + i;
         if (mode == 1) acc = acc - aux[o];
         else if (mode == 2) acc = aux[o] - coef[b] * acc;
+        else if (mode == 3) acc = (acc - aux[o]) > 0.f ? 1.f : -1.f;
         out[o] = acc;
     }
 }
@@ -143,7 +145,7 @@ hipError_t launch_deg_Hadj(const DegView& d, const float* y, float* x, int B, in
 // ---- fused data-fidelity gradient step: z = x - coef[b] * H_adj(H x - y) -------------------
 // (pnp_flow.py:39-41 with lr = sigma^2*lr_pnp, :109-112; sigma^2 is folded into coef.)
 __global__ __launch_bounds__(256) void grad_step_mask_kernel(DegView d, const float* x, const float* y, const float* coef,
-                                                             float* z, int C, int H, int W) {
+                                                             float* z, int C, int H, int W, int laplace) {
     const int b = blockIdx.y;
     const int n = C * H * W;
     const float cf = coef[b];
@@ -152,12 +154,14 @@ __global__ __launch_bounds__(256) void grad_step_mask_kernel(DegView d, const fl
         const float m = mask_at(d, b, py, px, H, W);
         const size_t o = (size_t)b * n + i;
         const float xv = x[o];
-        z[o] = xv - cf * (m * (m * xv - y[o]));
+        float r = m * xv - y[o];
+        if (laplace) r = r > 0.f ? 1.f : -1.f;          // 2*heaviside(Hx-y, 0) - 1
+        z[o] = xv - cf * (m * r);
     }
 }
 
 __global__ __launch_bounds__(256) void grad_step_sr_kernel(const float* x, const float* y, const float* coef, float* z,
-                                                           int C, int H, int W, int sf) {
+                                                           int C, int H, int W, int sf, int laplace) {
     const int b = blockIdx.y;
     const int n = C * H * W, Hy = H / sf, Wy = W / sf;
     const float cf = coef[b];
@@ -166,27 +170,30 @@ __global__ __launch_bounds__(256) void grad_step_sr_kernel(const float* x, const
         const size_t o = (size_t)b * n + i;
         const float xv = x[o];
         float g = 0.f;
-        if (py % sf == 0 && px % sf == 0) g = xv - y[(((size_t)b * C + pl) * Hy + py / sf) * Wy + px / sf];
+        if (py % sf == 0 && px % sf == 0) {
+            g = xv - y[(((size_t)b * C + pl) * Hy + py / sf) * Wy + px / sf];
+            if (laplace) g = g > 0.f ? 1.f : -1.f;
+        }
         z[o] = xv - cf * g;
     }
 }
 
 hipError_t launch_grad_step(const DegView& d, const float* x, const float* y, const float* coef, float* z,
-                            int B, int C, int H, int W, float* scratch, hipStream_t s) {
+                            int B, int C, int H, int W, float* scratch, int laplace, hipStream_t s) {
     dim3 g = grid_for(C * H * W, B);
     switch (d.kind) {
         case DEG_DENOISE: case DEG_BOX: case DEG_MASK:
-            hipLaunchKernelGGL(grad_step_mask_kernel, g, dim3(256), 0, s, d, x, y, coef, z, C, H, W);
+            hipLaunchKernelGGL(grad_step_mask_kernel, g, dim3(256), 0, s, d, x, y, coef, z, C, H, W, laplace);
             return hipGetLastError();
         case DEG_SR:
             if (d.sf <= 0 || H % d.sf || W % d.sf) return hipErrorInvalidValue;
-            hipLaunchKernelGGL(grad_step_sr_kernel, g, dim3(256), 0, s, x, y, coef, z, C, H, W, d.sf);
+            hipLaunchKernelGGL(grad_step_sr_kernel, g, dim3(256), 0, s, x, y, coef, z, C, H, W, d.sf, laplace);
             return hipGetLastError();
         case DEG_BLUR: {
             if (!scratch || d.ntaps > 127 || !(d.ntaps & 1)) return hipErrorInvalidValue;
             float* s0 = scratch;
             float* s1 = scratch + (size_t)B * C * H * W;
-            hipError_t e = blur2(d, x, s0, s1, B, C, H, W, +1, 1, y, nullptr, s);     // s1 = Hx - y
+            hipError_t e = blur2(d, x, s0, s1, B, C, H, W, +1, laplace ? 3 : 1, y, nullptr, s);     // s1 = Hx - y  (or its sign)
             if (e != hipSuccess) return e;
             return blur2(d, s1, s0, z, B, C, H, W, -1, 2, x, coef, s);                 // z = x - coef*H_adj(s1)
         }

@@ -56,6 +56,9 @@ class PNP_FLOW(object):
     def grad_datafit(self, x, y, H, H_adj):
         if self.args.noise_type == 'gaussian':
             return H_adj(H(x) - y) / (self.args.sigma_noise ** 2)
+        elif self.args.noise_type == 'laplace':
+            r = H(x) - y
+            return H_adj(2 * torch.heaviside(r, torch.zeros_like(r)) - 1) / self.args.sigma_noise
         raise ValueError('Noise type not supported')
 
     def interpolation_step(self, x, t):
@@ -78,7 +81,8 @@ class PNP_FLOW(object):
             if not torch.is_tensor(lr_t):
                 lr_t = torch.tensor([float(lr_t)])
             t_vals[it] = float(t1[0])
-            coef[it] = float(lr_t.reshape(-1)[0]) / (sigma_noise ** 2)
+            # gaussian: grad/sigma^2 (pnp_flow.py:41); laplace: grad/sigma (:43)
+            coef[it] = float(lr_t.reshape(-1)[0]) / (sigma_noise ** 2 if self.args.noise_type == 'gaussian' else sigma_noise)
         return t_vals, coef
 
     def restore_batch(self, noisy_img, degradation, sigma_noise, lr, iter_cb=None):
@@ -101,6 +105,7 @@ class PNP_FLOW(object):
             prm.noise = nz.data_ptr()
         prm.use_graph = 1 if self.use_graph else 0
         prm.batch_samples = 1 if self.batch_samples else 0
+        prm.noise_model = 1 if args.noise_type == 'laplace' else 0
         x = torch.empty((B, Cc, Hh, Hh), dtype=torch.float32, device=noisy_img.device)
         y = noisy_img.contiguous().float()
         holder = {}
@@ -123,6 +128,9 @@ class PNP_FLOW(object):
         if self.args.noise_type == 'gaussian':
             self.args.lr_pnp = sigma_noise ** 2 * self.args.lr_pnp      # in place, as the reference (pnp_flow.py:61)
             lr = self.args.lr_pnp
+        elif self.args.noise_type == 'laplace':
+            self.args.lr_pnp = sigma_noise * self.args.lr_pnp           # pnp_flow.py:64-66
+            lr = self.args.lr_pnp
         else:
             raise ValueError('Noise type not supported')
 
@@ -133,6 +141,9 @@ class PNP_FLOW(object):
             noisy_img = H(clean_img.clone().to(self.device))
             if self.measurement_noise is not None:
                 noise = self.measurement_noise(batch, noisy_img)
+            elif self.args.noise_type == 'laplace':
+                # pnp_flow.py:81-85: unit-scale Laplace sample (scaled by sigma below), drawn on the CPU generator
+                noise = torch.distributions.laplace.Laplace(torch.zeros(noisy_img.shape), torch.ones(noisy_img.shape)).sample().to(self.device)
             else:
                 # the reference draws on the device generator after torch.manual_seed(batch)
                 # (pnp_flow.py:79-80); here the draw is made on the CPU generator so that it is

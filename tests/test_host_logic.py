@@ -80,7 +80,7 @@ def test_schedule_scalars_match_reference_expressions():
     class Dummy:
         def to(self, d):
             return self
-    args = CfgNode(dict(method="pnp_flow", model="ot", gamma_style="alpha_1_minus_t", alpha=0.3))
+    args = CfgNode(dict(method="pnp_flow", model="ot", gamma_style="alpha_1_minus_t", alpha=0.3, noise_type="gaussian"))
     s = PNP_FLOW.__new__(PNP_FLOW); s.args = args
     sigma, steps = 0.05, 100
     t_vals, coef = s._schedule(steps, sigma ** 2 * 1.0, sigma)
@@ -96,3 +96,14 @@ def test_schedule_scalars_match_reference_expressions():
     np.testing.assert_allclose(g.taps_host, O.gaussian_1d_taps(3.0, 61).astype(np.float32), rtol=1e-6)
     m = D.RandomInpainting(0.7, global_batch=8, batch_offset=4).mask(4, 16, 16, "cpu").numpy()
     np.testing.assert_array_equal(m, O.random_mask_array(8, 16, 16, 0.7)[4:8].astype(np.uint8))
+
+
+def test_reference_import_paths_resolve_to_the_engine():
+    """Drop-in: the reference's import lines work unchanged and land on pnpflow_amd."""
+    from pnpflow.methods.pnp_flow import PNP_FLOW
+    from pnpflow.methods.ot_ode import OT_ODE
+    from pnpflow.degradations import BoxInpainting, GaussianDeblurring, Superresolution, RandomInpainting, Denoising
+    from pnpflow.utils import load_cfg_from_cfg_file, merge_cfg_from_list, define_model, load_model
+    import pnpflow_amd.methods.pnp_flow as A
+    assert PNP_FLOW is A.PNP_FLOW and OT_ODE.__module__ == "pnpflow_amd.methods.ot_ode"
+    assert BoxInpainting(20).half_size_mask == 20 and Superresolution(4, 256).sf == 4

@@ -107,6 +107,38 @@ TRAJ = [("mnist_denoising", "mnist", lambda S: (O.Denoising(), 0.2)),
         ("tiny4_random_inpainting", "tiny4", lambda S: (O.RandomInpainting(0.7), 0.01))]
 
 
+def det_laplace(shape, scale):
+    """Same deterministic Laplace draw as tools/make_golden.py (inverse CDF of a Philox uniform)."""
+    g = np.random.Generator(np.random.Philox(key=[41, 0]))
+    u = torch.from_numpy(g.uniform(-0.5, 0.5, size=shape).astype(np.float32))
+    return -scale * torch.sign(u) * torch.log1p(-2 * u.abs())
+
+
+LAPLACE = [("laplace_tiny4_superresolution", lambda S: (O.Superresolution(2, S), 0.3)),
+           ("laplace_tiny4_deblurring", lambda S: (O.GaussianDeblurring(1.0, 61, "fft", 3, S), 0.3)),
+           ("laplace_tiny4_inpainting", lambda S: (O.BoxInpainting(10), 0.3))]
+
+
+@pytest.mark.parametrize("tag,mk", LAPLACE)
+def test_pnp_flow_laplace_trajectory_matches_reference(golden, tag, mk):
+    g = golden("pnp_traj_" + tag)
+    cfg = O.unet_config(**CFGS["tiny4"]); sd = O.synthetic_state_dict(cfg, 0)
+    S, C = cfg["input_height"], cfg["input_channels"]
+    degradation, sigma = mk(S)
+    steps, ns = int(g["steps"]), int(g["num_samples"])
+    clean = det_image((2, C, S, S), 31)
+    hx = degradation.H(clean.clone())
+    y = hx + det_laplace(tuple(hx.shape), torch.tensor(sigma)) * 1.0      # the reference adds Laplace(0, sigma) directly (pnp_flow.py:83-85)
+    np.testing.assert_allclose(y.numpy(), g["noisy"], atol=1e-6)
+    its = {}
+    O.pnp_flow_restore(lambda a, t: O.unet_forward(sd, cfg, a, t), degradation, y, sigma, steps=steps, num_samples=ns, alpha=float(g["alpha"]),
+                       noise_fn=lambda it, s, like: det_normal(tuple(like.shape), 41, 1 + it * ns + s),
+                       record=lambda it, xx: its.__setitem__(it, xx.clone()), noise_type="laplace")
+    for it in (0, 1, 4, 9):
+        np.testing.assert_allclose(its[it].numpy(), g[f"x_it{it}"], atol=2e-5, err_msg=f"iterate {it}")
+    assert abs(float(g["lr_pnp_after"]) - sigma) < 1e-12      # lr_pnp scaled by sigma (not sigma^2) in place (pnp_flow.py:65)
+
+
 @pytest.mark.parametrize("tag,net,mk", TRAJ)
 def test_pnp_flow_trajectory_matches_reference(golden, tag, net, mk):
     g = golden("pnp_traj_" + tag)

@@ -161,6 +161,10 @@ def gen_traj(models, degr, utils, pnp):
         ("tiny4_superresolution", "tiny4", "superresolution", lambda S: (degr.Superresolution(2, S, device="cpu"), 0.05), 0.3, 2),
         ("tiny4_deblurring", "tiny4", "gaussian_deblurring_FFT", lambda S: (degr.GaussianDeblurring(1.0, 61, "fft", 3, S, "cpu"), 0.05), 0.01, 2),
         ("tiny4_random_inpainting", "tiny4", "random_inpainting", lambda S: (degr.RandomInpainting(0.7), 0.01), 0.01, 2),
+        # Laplace noise model (pnp_flow.py:42-43, 64-66, 81-85; sigma 0.3 from main.py:121-176)
+        ("laplace_tiny4_superresolution", "tiny4", "superresolution", lambda S: (degr.Superresolution(2, S, device="cpu"), 0.3), 0.3, 2),
+        ("laplace_tiny4_deblurring", "tiny4", "gaussian_deblurring_FFT", lambda S: (degr.GaussianDeblurring(1.0, 61, "fft", 3, S, "cpu"), 0.3), 0.01, 2),
+        ("laplace_tiny4_inpainting", "tiny4", "inpainting", lambda S: (degr.BoxInpainting(10), 0.3), 0.5, 2),
     ]
     steps, num_samples = 10, 2
     for tag, net, problem, mk, alpha, B in cases:
@@ -169,8 +173,9 @@ def gen_traj(models, degr, utils, pnp):
         S = c["input_height"]
         degradation, sigma = mk(S)
         clean = det_image((B, c["input_channels"], S, S), 31)
+        laplace = tag.startswith("laplace")
         args = utils.CfgNode(dict(method="pnp_flow", model="ot", dataset="celeba", problem=problem,
-                                  noise_type="gaussian", num_samples=num_samples, steps_pnp=steps, lr_pnp=1.0,
+                                  noise_type="laplace" if laplace else "gaussian", num_samples=num_samples, steps_pnp=steps, lr_pnp=1.0,
                                   gamma_style="alpha_1_minus_t", alpha=alpha, max_batch=1, compute_time=False,
                                   compute_memory=False, save_results=True, batch=0, save_path_ip="/tmp"))
         iterates = {}
@@ -179,6 +184,15 @@ def gen_traj(models, degr, utils, pnp):
         def fake_randn_like(like, **kw):
             i = seq["n"]; seq["n"] += 1
             return det_normal(tuple(like.shape), 41, i)   # call 0 = measurement noise, then (it, sample) order
+
+        def fake_laplace_sample(self_, sample_shape=torch.Size()):
+            # deterministic Laplace(0, scale): call 0 of the noise sequence; inverse-CDF of a det uniform
+            seq["n"] += 1
+            g = np.random.Generator(np.random.Philox(key=[41, 0]))
+            u = torch.from_numpy(g.uniform(-0.5, 0.5, size=tuple(self_.loc.shape)).astype(np.float32))
+            return self_.loc - self_.scale * torch.sign(u) * torch.log1p(-2 * u.abs())
+        saved_lap = torch.distributions.laplace.Laplace.sample
+        torch.distributions.laplace.Laplace.sample = fake_laplace_sample
 
         def cap_psnr(clean_img, noisy_img, rec_img, a, H_adj, iter="final"):
             iterates.setdefault(int(iter), rec_img.clone())
@@ -195,6 +209,7 @@ def gen_traj(models, degr, utils, pnp):
         finally:
             (torch.randn_like, utils.compute_psnr, utils.compute_ssim, utils.compute_lpips, utils.save_images,
              utils.compute_average_psnr, utils.compute_average_ssim, utils.compute_average_lpips) = saved
+            torch.distributions.laplace.Laplace.sample = saved_lap
         assert seq["n"] == 1 + steps * num_samples
         rec = dict(steps=np.array(steps), num_samples=np.array(num_samples), alpha=np.array(alpha), sigma=np.array(sigma),
                    noisy=iterates["noisy"].numpy(), lr_pnp_after=np.array(args.lr_pnp))

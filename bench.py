@@ -21,6 +21,9 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HBM bytes per conv-GEMM launch from the PMC passes in profiles/ (2 x FETCH_SIZE + WRITE_SIZE, one c2 forward at 160 images)
+TRAFFIC_C2_F16X3 = 466.0e6
+
 WORKLOADS = {
     # name: (dim, batch per GPU, problem, alpha, steps_pnp, num_samples, net config, GFLOP per image per forward)
     "c2": dict(dim=128, B=32, problem="inpainting", alpha=0.5, steps=100, ns=5, nres=6, label="CelebA-128 box-inpainting pnp_flow B=32/GPU 100x5 (BASELINE configs[1])"),
@@ -120,8 +123,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--precision", type=int, default=0, choices=[0, 1, 2],
-                    help="0: exact fp32 MFMA (default, what `dtype`/`roofline` describe); 1: split-fp16 MFMA; 2: per-layer choice")
+    ap.add_argument("--precision", type=int, default=1, choices=[0, 1],
+                    help="1 (default): fp32-equivalent split-fp16 MFMA (3 x f16 MFMA per product); 0: exact fp32 MFMA")
     a = ap.parse_args()
     wl = WORKLOADS[a.workload]
 
@@ -223,17 +226,19 @@ def main():
             model(zt, t_dev)
         launches, ms, flops = model.profile_read()
         model.profile(False)
-        peak = 157.3   # TFLOP/s, fp32 MFMA dense peak (MI355X_MICROARCH.md)
-        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        # HBM bytes per conv-GEMM launch from the PMC passes committed in profiles/r01_pmc_hbm_traffic_forward_c2.md
-        # (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, averaged over the 170 launches of one c2 forward); only known for c2
-        # HBM bytes per conv-GEMM launch from the PMC passes committed in profiles/r01_pmc_hbm_traffic_forward_c2.md
-        # (2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes, averaged over the 170 launches of one forward at the U-Net batch of
-        # this workload, 160 images); only collected for c2 at the default precision
-        traffic = 503.7e6 if (a.workload == "c2" and a.precision == 0 and rep == 5) else None
-        roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=traffic,
-                    kernel="conv_mfma_kernel (fp32 32x32x2 MFMA implicit GEMM)", launches=int(launches // n_fw),
-                    avg_launch_us=round(ms * 1e3 / max(1, launches), 2),
+        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0      # ALGORITHMIC (fp32-equivalent) TFLOP/s of the conv-GEMM launches
+        if a.precision == 0:
+            peak = 157.3   # TFLOP/s, fp32 MFMA dense peak (MI355X_MICROARCH.md)
+            roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                        traffic=503.7e6 if (a.workload == "c2" and rep == 5) else None,
+                        kernel="conv_mfma_kernel (fp32 32x32x2 MFMA implicit GEMM)")
+        else:
+            peak = 2500.0  # TFLOP/s, f16 MFMA dense peak; every algorithmic product is executed as 3 f16 MFMA products
+            roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                        traffic=TRAFFIC_C2_F16X3 if (a.workload == "c2" and rep == 5) else None,
+                        kernel="conv_mfma16_kernel (f16 32x32x16 MFMA x3 split, implicit GEMM); attention matmuls on conv_mfma_kernel (fp32)",
+                        mfma_tflops_executed=round(3 * ach, 2), frac_executed=round(3 * ach / peak, 4))
+        roof.update(launches=int(launches // n_fw), avg_launch_us=round(ms * 1e3 / max(1, launches), 2),
                     algorithmic_gflop_per_launch=round(flops / max(1, launches) / 1e9, 4))
 
     if rank == 0:
@@ -243,7 +248,7 @@ def main():
             "metric": "restored images/sec", "value": round(total_images / dt, 4), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {0: "f32", 1: "f32-equivalent (f16x3 split MFMA, fp32 accumulate)", 2: "f32 / f32-equivalent f16x3 split per layer"}[a.precision],
+            "dtype": {0: "f32", 1: "f32-equivalent (f16 hi+lo split operands, 3 x f16 MFMA per product, f32 accumulate)"}[a.precision],
             "data": "synthetic",
             "config": {"workload": wl["label"], "image": f"{dim}x{dim}x3", "batch_per_gpu": B, "global_batch": world * B,
                        "steps_pnp": wl["steps"], "num_samples": wl["ns"], "weights": "synthetic seed 0 (no checkpoint offline)",

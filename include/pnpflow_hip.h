@@ -75,10 +75,11 @@ const char* pf_engine_weight_name(const pf_engine* e, int i);
 /* shape of the i-th entry (reference layout); returns the rank (<= 4) or a negative status. */
 int pf_engine_weight_shape(const pf_engine* e, int i, int64_t shape[4]);
 
-/* 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32);
- * 1 = split-fp16: every operand carried as an fp16 pair hi+lo, 3 x v_mfma_f32_32x32x16_f16 per product, fp32
- *     accumulate - fp32-equivalent results (same parity tolerances) at 3/16 of the matrix-pipe time.  Applies to
- *     the packed-weight convs of the forward; attention matmuls and the backward stay on the fp32 MFMA. */
+/* 1 (default) = split-fp16: every operand carried as an fp16 pair hi+lo, 3 x v_mfma_f32_32x32x16_f16 per product,
+ *     fp32 accumulate - fp32-equivalent results (the parity tests hold both modes to the same tolerance) at 3/16 of
+ *     the matrix-pipe time.  Applies to the packed-weight convs of the forward; the attention matmuls and the
+ *     backward stay on the fp32 MFMA.
+ * 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere. */
 int pf_engine_set_precision(pf_engine* e, int mode);
 
 /* ---- velocity field ---------------------------------------------------------------- */

@@ -1,18 +1,20 @@
 // Implicit-GEMM convolution on the gfx950 16-bit matrix cores with fp32-equivalent accuracy.
 //
-// Same GEMM view, tiling, fusion and epilogue as conv_mfma.hip, but the contraction runs on
+// Same GEMM view, fusion and epilogue as conv_mfma.hip, but the contraction runs on
 // v_mfma_f32_32x32x16_f16 (16x the rate of the fp32 MFMA) with every operand carried as an
 // unevaluated fp16 pair  a = a_hi + a_lo,  w = w_hi + w_lo  and the product expanded into three
-// MFMAs  a_hi*w_hi + a_hi*w_lo + a_lo*w_hi  accumulated in fp32 (the dropped a_lo*w_lo term is
+// MFMAs  a_lo*w_hi + a_hi*w_lo + a_hi*w_hi  accumulated in fp32 (the dropped a_lo*w_lo term is
 // 2^-22 relative).  fp16 products are exact in fp32, so the result matches the fp32-MFMA kernel to
 // fp32-rounding level (same parity tolerances in tests/), at 3/16 of its matrix-pipe time.
-//   * activations: split after GroupNorm/SiLU while staging; LDS row of a pixel = [16 hi | 16 lo | pad]
-//     halfs = 80 B (the same conflict-free 20-dword stride as the fp32 patch);
+//   * activations: split after GroupNorm/SiLU while staging; LDS row of a pixel =
+//     [KC hi halfs | KC lo halfs | pad] = KC+4 dwords (the same conflict-free stride as the fp32 patch);
 //   * weights: split on the host after an exact 2^8 pre-scale (keeps w_lo a normal fp16 number; the
-//     epilogue multiplies by 2^-8), packed [chunk][tap][Cout][16 hi | 16 lo] and staged through LDS
-//     (at this MFMA rate the B fragments would need 2/3 of the L1 bandwidth if read per wave).
+//     epilogue multiplies by 2^-8), packed [k16-step][Cout][16 hi | 16 lo] so that the B fragments of a
+//     wave (32 channels x 16 k, hi and lo) are one contiguous 2 KiB run, and read straight from L1/L2
+//     into a register ring two steps ahead of their use (as in conv_mfma.hip).  At this MFMA rate the
+//     weight stream is 16/3 x denser per matrix-pipe cycle than in the fp32 kernel, so the tile shapes
+//     give every wave 4 (or 2) M-tiles per N-tile: one B fragment pair feeds 12 (6) MFMAs.
 #include <cstdlib>
-#include <hip/hip_fp16.h>
 #include "pf_common.h"
 
 namespace pf {
@@ -23,21 +25,20 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_fast16(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
 
-template <int MT, int NT, int WM, int WN, int S, int UP>
+template <int MT, int NT, int WM, int WN, int S, int UP, int KC>
 __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
-    constexpr int KC = CONV_KC, KQ = KC / 4;
-    constexpr int ROW = 20;                      // dwords per LDS row: 8 (hi) + 8 (lo) + 4 (pad)
+    constexpr int ROW = KC + 4;                  // dwords per LDS row: KC/2 (hi) + KC/2 (lo) + 4 (pad)
+    constexpr int KQ = KC / 4, KH = KC / 2, KS = KC / 16;
     constexpr int TH = 2 * MT * WM, TW = 16;
     constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PP = PH * PW;
     constexpr int BN = WN * NT * 32;
     constexpr int A_F4 = PP * KQ, A_PER = (A_F4 + 255) / 256;
-    constexpr int W_U4 = 9 * BN * 4, W_PER = (W_U4 + 255) / 256;   // 64 B (4 x uint4) per (tap, n)
     static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(PP * ROW >= WM * BN * 2, "statistics scratch must fit in the patch buffer");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     uint32_t* s_patch = reinterpret_cast<uint32_t*>(smem_raw);   // [PP][ROW]
-    uint32_t* s_w = s_patch + PP * ROW;                           // [9][BN][ROW]
-    float* s_sc = reinterpret_cast<float*>(s_w + 9 * BN * ROW);
+    float* s_sc = reinterpret_cast<float*>(s_patch + PP * ROW);
     float* s_sh = s_sc + ((p.gn_C + 3) & ~3);
 
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
@@ -60,35 +61,21 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
             const int pix = idx / KQ;
             const int py = pix / PW, px = pix % PW;
             const int gy = oy0 * S - 1 + py, gx = ox0 * S - 1 + px;
-            a_lds[i] = pix * ROW + qi * 2;          // dword offset of this thread's 4 hi halfs (lo at +8)
+            a_lds[i] = pix * ROW + qi * 2;          // dword offset of this thread's 4 hi halfs (lo at +KH)
             if (gy >= 0 && gy < Hv && gx >= 0 && gx < Wv && !(UP == 2 && ((gy | gx) & 1))) {
                 const int sy = UP ? (gy >> 1) : gy, sx = UP ? (gx >> 1) : gx;
                 a_pix[i] = (b * p.Hs + sy) * p.Ws + sx;
             }
         }
     }
-    // weight staging descriptors: item idx -> (tap, n, q): global uint4 index and LDS dword offset
-    int w_src[W_PER], w_lds[W_PER];
-#pragma unroll
-    for (int i = 0; i < W_PER; ++i) {
-        const int idx = tid + i * 256;
-        const int tap = idx / (BN * 4), rem = idx % (BN * 4), n = rem / 4, q = rem % 4;
-        w_lds[i] = idx < W_U4 ? (tap * BN + n) * ROW + q * 4 : -1;
-        w_src[i] = (tap * p.Cout + min(n0 + n, p.Cout - 1)) * 4 + q;     // in uint4 units within a chunk block
-    }
 
     float4 ra[A_PER];
-    uint4 rw[W_PER];
     auto prefetch = [&](int si, int ch) {
         const ConvSeg& sg = p.seg[si];
         const int c = min(ch * KC + q4, sg.C - 4);
         const float* base = sg.src + sg.coff + c;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) ra[i] = *reinterpret_cast<const float4*>(base + (size_t)max(a_pix[i], 0) * sg.cstride);
-        const uint4* wb = reinterpret_cast<const uint4*>(sg.w16) + (size_t)ch * sg.taps * p.Cout * 4;
-        const int nitems = sg.taps * BN * 4;
-#pragma unroll
-        for (int i = 0; i < W_PER; ++i) rw[i] = wb[min(tid + i * 256, nitems - 1) == tid + i * 256 ? w_src[i] : 0];
     };
     auto store_lds = [&](int si, int ch) {
         const ConvSeg& sg = p.seg[si];
@@ -116,13 +103,9 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
                 l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
                 l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
                 *reinterpret_cast<f16x4*>(s_patch + a_lds[i]) = h;
-                *reinterpret_cast<f16x4*>(s_patch + a_lds[i] + 8) = l;
+                *reinterpret_cast<f16x4*>(s_patch + a_lds[i] + KH) = l;
             }
         }
-        const int nitems = sg.taps * BN * 4;
-#pragma unroll
-        for (int i = 0; i < W_PER; ++i)
-            if (w_lds[i] >= 0 && tid + i * 256 < nitems) *reinterpret_cast<uint4*>(s_w + w_lds[i]) = rw[i];
     };
 
     prefetch(0, 0);
@@ -159,6 +142,18 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
 
     const int prow = l31 >> 4, pcol = l31 & 15;
     const int nbase = n0 + wn * NT * 32 + l31;
+    int nclamp[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) nclamp[nt] = min(nbase + nt * 32, p.Cout - 1);
+
+    // B fragments of step s (s = tap for a 3x3 chunk, s = 16-channel slice for a 64-channel 1-tap chunk):
+    // 8 hi halfs + 8 lo halfs per lane, unconditional loads (clamped channel index)
+    auto load_b = [&](const ConvSeg& sg, int ch, int s, uint4 (&dh)[NT], uint4 (&dl)[NT]) {
+        const size_t kidx = (KC == 16) ? (size_t)ch * sg.taps + s : (size_t)ch * KS + s;
+        const uint4* wp = reinterpret_cast<const uint4*>(sg.w16) + kidx * ((size_t)p.Cout * 4) + hi;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { dh[nt] = wp[(size_t)nclamp[nt] * 4]; dl[nt] = wp[(size_t)nclamp[nt] * 4 + 2]; }
+    };
 
     int si = 0, ch = 0;
     while (true) {
@@ -169,37 +164,45 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
         int nsi = si, nch = ch + 1;
         if (nch * KC >= sg.C) { nsi = si + 1; nch = 0; }
         const bool more = nsi < p.nseg;
+
+        const int nsteps = (KC == 16) ? sg.taps : KS;      // 9 / 1 (KC 16) or 4 (KC 64, 1-tap launches)
+        uint4 bh0[NT], bl0[NT], bh1[NT], bl1[NT], bh2[NT], bl2[NT];
+        load_b(sg, ch, 0, bh0, bl0); load_b(sg, ch, min(1, nsteps - 1), bh1, bl1);
         if (more) prefetch(nsi, nch);
 
-        const int ntaps = sg.taps;
-        for (int tap = 0; tap < ntaps; ++tap) {
-            const int ky = ntaps == 9 ? tap / 3 : 1, kx = ntaps == 9 ? tap % 3 : 1;
-            f16x8 ah[MT], al[MT], bh[NT], bl[NT];
+        auto k_step = [&](int s, uint4 (&ch_)[NT], uint4 (&cl_)[NT], uint4 (&nh_)[NT], uint4 (&nl_)[NT]) {
+            load_b(sg, ch, min(s + 2, nsteps - 1), nh_, nl_);
+            __builtin_amdgcn_sched_barrier(0);
+            const int tap = (KC == 16) ? s : 0, j = (KC == 16) ? 0 : s;
+            const int ky = sg.taps == 9 ? tap / 3 : 1, kx = sg.taps == 9 ? tap % 3 : 1;
+            f16x8 ah[MT], al[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int ppix = (((wm * MT + mt) * 2 + prow) * S + ky) * PW + pcol * S + kx;
-                ah[mt] = *reinterpret_cast<const f16x8*>(s_patch + ppix * ROW + hi * 4);
-                al[mt] = *reinterpret_cast<const f16x8*>(s_patch + ppix * ROW + 8 + hi * 4);
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int row = tap * BN + (wn * NT + nt) * 32 + l31;
-                bh[nt] = *reinterpret_cast<const f16x8*>(s_w + row * ROW + hi * 4);
-                bl[nt] = *reinterpret_cast<const f16x8*>(s_w + row * ROW + 8 + hi * 4);
+                ah[mt] = *reinterpret_cast<const f16x8*>(s_patch + ppix * ROW + j * 8 + hi * 4);
+                al[mt] = *reinterpret_cast<const f16x8*>(s_patch + ppix * ROW + KH + j * 8 + hi * 4);
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], *reinterpret_cast<const f16x8*>(&ch_[nt]), acc[mt][nt], 0, 0, 0);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], *reinterpret_cast<const f16x8*>(&cl_[nt]), acc[mt][nt], 0, 0, 0);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], *reinterpret_cast<const f16x8*>(&ch_[nt]), acc[mt][nt], 0, 0, 0);
+        };
+        int s = 0;
+        for (; s + 3 <= nsteps; s += 3) {
+            k_step(s, bh0, bl0, bh2, bl2); k_step(s + 1, bh1, bl1, bh0, bl0); k_step(s + 2, bh2, bl2, bh1, bl1);
         }
+        if (nsteps - s == 1) k_step(s, bh0, bl0, bh2, bl2);
         if (!more) break;
         si = nsi; ch = nch;
     }
@@ -250,15 +253,15 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
     }
 }
 
-template <int MT, int NT, int WM, int WN, int S, int UP>
+template <int MT, int NT, int WM, int WN, int S, int UP, int KC>
 static hipError_t launch_cfg16(const ConvParams& p, hipStream_t stream) {
-    constexpr int ROW = 20;
+    constexpr int ROW = KC + 4;
     constexpr int TH = 2 * MT * WM, TW = 16;
     constexpr int PP = ((TH - 1) * S + 3) * ((TW - 1) * S + 3);
     constexpr int BN = WN * NT * 32;
-    const size_t lds = (size_t)(PP * ROW + 9 * BN * ROW + 2 * ((p.gn_C + 3) & ~3)) * 4;
+    const size_t lds = (size_t)(PP * ROW + 2 * ((p.gn_C + 3) & ~3)) * 4;
     static bool attr_set = false;
-    auto kern = conv_mfma16_kernel<MT, NT, WM, WN, S, UP>;
+    auto kern = conv_mfma16_kernel<MT, NT, WM, WN, S, UP, KC>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -274,30 +277,42 @@ static long wg_count16(const ConvParams& p, int TH, int BN) {
     return (long)p.B * ((p.H + TH - 1) / TH) * ((p.W + 15) / 16) * ((p.Cout + BN - 1) / BN);
 }
 
-template <int S, int UP>
+template <int S, int UP, int KC>
 static hipError_t launch_sel16(const ConvParams& p, hipStream_t stream) {
     static const long MIN_WGS = getenv("PNPFLOW_HIP_MIN_WGS") ? atol(getenv("PNPFLOW_HIP_MIN_WGS")) : 512;
     if constexpr (S == 1) {
-        if (p.Cout <= 32) return launch_cfg16<2, 1, 4, 1, S, UP>(p, stream);
-        if (wg_count16(p, 16, 64) >= MIN_WGS) return launch_cfg16<2, 2, 4, 1, S, UP>(p, stream);
-        if (wg_count16(p, 8, 64) >= MIN_WGS) return launch_cfg16<1, 2, 4, 1, S, UP>(p, stream);
-        return launch_cfg16<1, 1, 2, 2, S, UP>(p, stream);
+        if (p.Cout <= 32) {
+            if (KC == 16 && wg_count16(p, 32, 32) >= 2 * MIN_WGS) return launch_cfg16<4, 1, 4, 1, S, UP, KC>(p, stream);   // 32x16 px x 32
+            return launch_cfg16<2, 1, 4, 1, S, UP, KC>(p, stream);                                                        // 16x16 px x 32
+        }
+        if (p.Cout <= 64) {
+            if (wg_count16(p, 16, 64) >= MIN_WGS) return launch_cfg16<4, 1, 2, 2, S, UP, KC>(p, stream);                  // 16x16 px x 64
+            if (wg_count16(p, 8, 64) >= MIN_WGS) return launch_cfg16<2, 1, 2, 2, S, UP, KC>(p, stream);                   // 8x16 px x 64
+            return launch_cfg16<1, 1, 2, 2, S, UP, KC>(p, stream);                                                        // 4x16 px x 64
+        }
+        if (wg_count16(p, 8, 128) >= MIN_WGS) return launch_cfg16<4, 1, 1, 4, S, UP, KC>(p, stream);                      // 8x16 px x 128
+        if (wg_count16(p, 4, 128) >= MIN_WGS) return launch_cfg16<2, 1, 1, 4, S, UP, KC>(p, stream);                      // 4x16 px x 128
+        return launch_cfg16<1, 1, 2, 2, S, UP, KC>(p, stream);                                                            // 4x16 px x 64
     } else {
-        if (p.Cout <= 32) return launch_cfg16<1, 1, 4, 1, S, UP>(p, stream);
-        if (p.Cout <= 64) return launch_cfg16<1, 2, 4, 1, S, UP>(p, stream);
-        return launch_cfg16<1, 1, 2, 2, S, UP>(p, stream);
+        if (p.Cout <= 32) return launch_cfg16<1, 1, 4, 1, S, UP, KC>(p, stream);
+        if (p.Cout <= 64) return launch_cfg16<2, 1, 2, 2, S, UP, KC>(p, stream);
+        return launch_cfg16<1, 1, 2, 2, S, UP, KC>(p, stream);
     }
 }
 
-// Only fragment-major packed weights (w_mode 0) with a 16-bit repack are supported; the caller falls
-// back to the fp32 kernel (launch_conv) for the generic strided operands of attention.
+// Only fragment-major packed weights (w_mode 0) with a 16-bit repack are supported; the caller keeps the
+// fp32 kernel (launch_conv) for the generic strided operands of attention.
 hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t stream) {
-    for (int i = 0; i < p.nseg; ++i)
+    bool all_1tap = true;
+    for (int i = 0; i < p.nseg; ++i) {
         if (p.seg[i].w_mode != 0 || p.seg[i].w16 == nullptr) return hipErrorInvalidValue;
-    if (stride == 2) return launch_sel16<2, 0>(p, stream);
-    if (up == 2) return launch_sel16<1, 2>(p, stream);
-    if (up) return launch_sel16<1, 1>(p, stream);
-    return launch_sel16<1, 0>(p, stream);
+        all_1tap &= p.seg[i].taps == 1 && p.seg[i].C >= 64;
+    }
+    if (all_1tap && stride == 1 && !up) return launch_sel16<1, 0, 64>(p, stream);
+    if (stride == 2) return launch_sel16<2, 0, 16>(p, stream);
+    if (up == 2) return launch_sel16<1, 2, 16>(p, stream);
+    if (up) return launch_sel16<1, 1, 16>(p, stream);
+    return launch_sel16<1, 0, 16>(p, stream);
 }
 
 }  // namespace pf

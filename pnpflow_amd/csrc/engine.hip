@@ -107,7 +107,7 @@ struct pf_engine {
     std::map<std::string, int> temb_off;   // ResBlock prefix -> offset in the stacked temb projection
     std::map<int, std::unique_ptr<Plan>> plans;
     int retained_B = 0;
-    int precision = 0;   // 0: exact fp32 MFMA; 1: split-fp16 (3 x f16 MFMA, fp32-equivalent) for the packed-weight convs
+    int precision = 1;   // 1 (default): split-fp16 (3 x f16 MFMA, fp32-equivalent) for the packed-weight convs; 0: exact fp32 MFMA
     SolverBufs sb;
     hipStream_t work_stream = nullptr;   // used when the caller passes the NULL stream and asks for graph replay
     // profiling
@@ -897,9 +897,6 @@ static hipError_t dispatch_conv(pf_engine* e, const Op& op, hipStream_t s) {
     if (e->precision != 0) {
         bool ok16 = true;
         for (int i = 0; i < op.cp.nseg; ++i) ok16 &= op.cp.seg[i].w_mode == 0 && op.cp.seg[i].w16 != nullptr;
-        // mode 2 (auto): the split-fp16 kernel stages weights through LDS per workgroup, which only pays on the
-        // layers with many output pixels (measured: B*H*W >= 64 Ki); the small-spatial deep levels keep the fp32 MFMA
-        if (e->precision == 2) ok16 &= (long)op.cp.B * op.cp.H * op.cp.W >= (getenv("PNPFLOW_HIP_M16") ? atol(getenv("PNPFLOW_HIP_M16")) : 65536);
         if (ok16) return launch_conv16(op.cp, op.stride, op.up, s);
     }
     return launch_conv(op.cp, op.stride, op.up, s);
@@ -1046,7 +1043,7 @@ int pf_engine_finalize_weights(pf_engine* e) {
 
 int pf_engine_set_precision(pf_engine* e, int mode) {
     if (!e) return PF_ERR_INVALID;
-    if (mode < 0 || mode > 2) { e->err = "precision mode must be 0 (fp32 MFMA), 1 (split-fp16 MFMA) or 2 (per-layer choice)"; return PF_ERR_INVALID; }
+    if (mode < 0 || mode > 1) { e->err = "precision mode must be 0 (fp32 MFMA) or 1 (split-fp16 MFMA)"; return PF_ERR_INVALID; }
     e->precision = mode;
     return PF_OK;
 }

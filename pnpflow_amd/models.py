@@ -144,7 +144,7 @@ class UNet:
         return out
 
     def set_precision(self, mode: int):
-        """0: exact fp32 MFMA; 1: split-fp16 MFMA (fp32-equivalent, 3 x f16 MFMA per product)."""
+        """1 (default): split-fp16 MFMA (fp32-equivalent, 3 x f16 MFMA per product); 0: exact fp32 MFMA."""
         _lib.check(self._lib.pf_engine_set_precision(self._h, int(mode)), self._h, "pf_engine_set_precision")
         return self
 

@@ -25,7 +25,7 @@ def main():
     m = UNet(c["input_channels"], c["input_height"], c["ch"], ch_mult=c["ch_mult"], num_res_blocks=c["num_res_blocks"],
              attn_resolutions=c["attn_resolutions"])
     m.load_state_dict(sd)
-    m.set_precision(int(os.environ.get('PNPFLOW_PREC', '0')))
+    m.set_precision(int(os.environ.get('PNPFLOW_PREC', '1')))
     x = det_normal((B, c["input_channels"], c["input_height"], c["input_height"]), 11)
     t = torch.tensor([0.0, 0.37, 0.99, 0.5][:B] if B <= 4 else [0.37] * B, dtype=torch.float32)
     taps_ref = {}

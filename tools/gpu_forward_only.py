@@ -10,7 +10,7 @@ dim = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 cfg = O.unet_config(3, dim, 32, (1, 2, 4, 8), 6, (16, 8))
-m = UNet(3, dim, 32, ch_mult=(1, 2, 4, 8), num_res_blocks=6, attn_resolutions=(16, 8)); m.load_state_dict(O.synthetic_state_dict(cfg, 0)); m.set_precision(int(os.environ.get('PNPFLOW_PREC', '0')))
+m = UNet(3, dim, 32, ch_mult=(1, 2, 4, 8), num_res_blocks=6, attn_resolutions=(16, 8)); m.load_state_dict(O.synthetic_state_dict(cfg, 0)); m.set_precision(int(os.environ.get('PNPFLOW_PREC', '1')))
 x = torch.randn(B, 3, dim, dim).cuda(); t = torch.full((B,), 0.37).cuda()
 m(x, t); torch.cuda.synchronize()
 t0 = time.time()

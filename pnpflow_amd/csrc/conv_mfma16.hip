@@ -146,10 +146,11 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) nclamp[nt] = min(nbase + nt * 32, p.Cout - 1);
 
-    // B fragments of step s (s = tap for a 3x3 chunk, s = 16-channel slice for a 64-channel 1-tap chunk):
+    // B fragments of step s = tap * KS + j (tap of the 3x3 window, j-th 16-channel slice of the chunk):
     // 8 hi halfs + 8 lo halfs per lane, unconditional loads (clamped channel index)
     auto load_b = [&](const ConvSeg& sg, int ch, int s, uint4 (&dh)[NT], uint4 (&dl)[NT]) {
-        const size_t kidx = (KC == 16) ? (size_t)ch * sg.taps + s : (size_t)ch * KS + s;
+        const int tap = s / KS, j = s % KS;
+        const size_t kidx = ((size_t)ch * KS + j) * sg.taps + tap;     // global 16-channel slice index x taps + tap
         const uint4* wp = reinterpret_cast<const uint4*>(sg.w16) + kidx * ((size_t)p.Cout * 4) + hi;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) { dh[nt] = wp[(size_t)nclamp[nt] * 4]; dl[nt] = wp[(size_t)nclamp[nt] * 4 + 2]; }
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
         if (nch * KC >= sg.C) { nsi = si + 1; nch = 0; }
         const bool more = nsi < p.nseg;
 
-        const int nsteps = (KC == 16) ? sg.taps : KS;      // 9 / 1 (KC 16) or 4 (KC 64, 1-tap launches)
+        const int nsteps = sg.taps * KS;      // k16-steps per chunk: 9 / 1 (KC 16), 18 / 2 (KC 32), 4 (KC 64, 1-tap launches)
         uint4 bh0[NT], bl0[NT], bh1[NT], bl1[NT], bh2[NT], bl2[NT];
         load_b(sg, ch, 0, bh0, bl0); load_b(sg, ch, min(1, nsteps - 1), bh1, bl1);
         if (more) prefetch(nsi, nch);
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
         auto k_step = [&](int s, uint4 (&ch_)[NT], uint4 (&cl_)[NT], uint4 (&nh_)[NT], uint4 (&nl_)[NT]) {
             load_b(sg, ch, min(s + 2, nsteps - 1), nh_, nl_);
             __builtin_amdgcn_sched_barrier(0);
-            const int tap = (KC == 16) ? s : 0, j = (KC == 16) ? 0 : s;
+            const int tap = s / KS, j = s % KS;
             const int ky = sg.taps == 9 ? tap / 3 : 1, kx = sg.taps == 9 ? tap % 3 : 1;
             f16x8 ah[MT], al[MT];
 #pragma unroll
@@ -202,7 +203,8 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
         for (; s + 3 <= nsteps; s += 3) {
             k_step(s, bh0, bl0, bh2, bl2); k_step(s + 1, bh1, bl1, bh0, bl0); k_step(s + 2, bh2, bl2, bh1, bl1);
         }
-        if (nsteps - s == 1) k_step(s, bh0, bl0, bh2, bl2);
+        if (nsteps - s >= 1) k_step(s, bh0, bl0, bh2, bl2);
+        if (nsteps - s == 2) k_step(s + 1, bh1, bl1, bh0, bl0);
         if (!more) break;
         si = nsi; ch = nch;
     }
@@ -282,7 +284,7 @@ static hipError_t launch_sel16(const ConvParams& p, hipStream_t stream) {
     static const long MIN_WGS = getenv("PNPFLOW_HIP_MIN_WGS") ? atol(getenv("PNPFLOW_HIP_MIN_WGS")) : 512;
     if constexpr (S == 1) {
         if (p.Cout <= 32) {
-            if (KC == 16 && wg_count16(p, 32, 32) >= 2 * MIN_WGS) return launch_cfg16<4, 1, 4, 1, S, UP, KC>(p, stream);   // 32x16 px x 32
+            if (KC == 16 && wg_count16(p, 32, 32) >= 2 * MIN_WGS) return launch_cfg16<4, 1, 4, 1, S, UP, KC>(p, stream);   // 32x16 px x 32 (49 KB patch at KC 16)
             return launch_cfg16<2, 1, 4, 1, S, UP, KC>(p, stream);                                                        // 16x16 px x 32
         }
         if (p.Cout <= 64) {
@@ -308,11 +310,14 @@ hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t st
         if (p.seg[i].w_mode != 0 || p.seg[i].w16 == nullptr) return hipErrorInvalidValue;
         all_1tap &= p.seg[i].taps == 1 && p.seg[i].C >= 64;
     }
+    static const int kc_pref = getenv("PNPFLOW_HIP_KC") ? atoi(getenv("PNPFLOW_HIP_KC")) : 32;
+    bool all32 = kc_pref == 32;
+    for (int i = 0; i < p.nseg; ++i) all32 &= p.seg[i].C % 32 == 0;
     if (all_1tap && stride == 1 && !up) return launch_sel16<1, 0, 64>(p, stream);
     if (stride == 2) return launch_sel16<2, 0, 16>(p, stream);
     if (up == 2) return launch_sel16<1, 2, 16>(p, stream);
-    if (up) return launch_sel16<1, 1, 16>(p, stream);
-    return launch_sel16<1, 0, 16>(p, stream);
+    if (up) return all32 ? launch_sel16<1, 1, 32>(p, stream) : launch_sel16<1, 1, 16>(p, stream);
+    return all32 ? launch_sel16<1, 0, 32>(p, stream) : launch_sel16<1, 0, 16>(p, stream);
 }
 
 }  // namespace pf

@@ -284,7 +284,8 @@ static hipError_t launch_sel16(const ConvParams& p, hipStream_t stream) {
     static const long MIN_WGS = getenv("PNPFLOW_HIP_MIN_WGS") ? atol(getenv("PNPFLOW_HIP_MIN_WGS")) : 512;
     if constexpr (S == 1) {
         if (p.Cout <= 32) {
-            if (KC == 16 && wg_count16(p, 32, 32) >= 2 * MIN_WGS) return launch_cfg16<4, 1, 4, 1, S, UP, KC>(p, stream);   // 32x16 px x 32 (49 KB patch at KC 16)
+            static const int big_l0 = getenv("PNPFLOW_HIP_BIG_L0") ? atoi(getenv("PNPFLOW_HIP_BIG_L0")) : 0;
+            if (big_l0 && KC == 16 && wg_count16(p, 32, 32) >= 2 * MIN_WGS) return launch_cfg16<4, 1, 4, 1, S, UP, KC>(p, stream);   // 32x16 px x 32 (49 KB patch at KC 16)
             return launch_cfg16<2, 1, 4, 1, S, UP, KC>(p, stream);                                                        // 16x16 px x 32
         }
         if (p.Cout <= 64) {
@@ -311,7 +312,8 @@ hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t st
         all_1tap &= p.seg[i].taps == 1 && p.seg[i].C >= 64;
     }
     static const int kc_pref = getenv("PNPFLOW_HIP_KC") ? atoi(getenv("PNPFLOW_HIP_KC")) : 32;
-    bool all32 = kc_pref == 32;
+    static const int kc_l0 = getenv("PNPFLOW_HIP_KC_L0") ? atoi(getenv("PNPFLOW_HIP_KC_L0")) : 16;   // 32-channel layers: 16-channel chunks keep the patch at 26 KB (5-6 workgroups per CU)
+    bool all32 = (p.Cout <= 32 ? kc_l0 : kc_pref) == 32;
     for (int i = 0; i < p.nseg; ++i) all32 &= p.seg[i].C % 32 == 0;
     if (all_1tap && stride == 1 && !up) return launch_sel16<1, 0, 64>(p, stream);
     if (stride == 2) return launch_sel16<2, 0, 16>(p, stream);

@@ -34,11 +34,11 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
     constexpr int BN = WN * NT * 32;
     constexpr int A_F4 = PP * KQ, A_PER = (A_F4 + 255) / 256;
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(PP * ROW >= WM * BN * 2, "statistics scratch must fit in the patch buffer");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     uint32_t* s_patch = reinterpret_cast<uint32_t*>(smem_raw);   // [PP][ROW]
-    float* s_sc = reinterpret_cast<float*>(s_patch + PP * ROW);
+    constexpr int EPI = 4 * 32 * 36 + WM * BN * 2;           // floats needed by the epilogue (see below)
+    float* s_sc = reinterpret_cast<float*>(s_patch + (PP * ROW > EPI ? PP * ROW : EPI));
     float* s_sh = s_sc + ((p.gn_C + 3) & ~3);
 
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
@@ -209,36 +209,67 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
         si = nsi; ch = nch;
     }
 
-    // ---- epilogue (identical to conv_mfma.hip apart from the 2^-8 weight pre-scale) ----------
-    float* s_red = reinterpret_cast<float*>(s_patch);
+    // ---- epilogue ---------------------------------------------------------------------------------
+    // The MFMA accumulator layout gives each lane 16 pixels of ONE channel (4-byte accesses, 128-byte
+    // runs).  Each 32x32 tile is therefore transposed through a per-wave LDS scratch so that every lane
+    // owns 4 consecutive channels of a pixel: residual loads and output stores are 16 B per lane and a
+    // wave instruction covers 1 KiB of contiguous NHWC rows.
+    __syncthreads();                                   // every wave is done reading the patch
+    constexpr int TP = 36;                             // scratch row pitch in floats (32 + 4 pad)
+    float* s_tr = reinterpret_cast<float*>(s_patch) + wave * (32 * TP);
+    float* s_red = reinterpret_cast<float*>(s_patch) + 4 * 32 * TP;   // [WM][BN][2] behind the 4 scratch tiles
     const float oscale = p.out_scale * (1.0f / 256.0f);
-    if (p.stats_out != nullptr) __syncthreads();
+    const int cq = lane & 7;                           // this lane's channel quad inside a 32-channel tile
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int n = nbase + nt * 32;
-        const bool nok = n < p.Cout;
-        const float add = (p.addvec != nullptr && nok) ? p.addvec[(size_t)b * p.addvec_bs + n] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
+        const int ncol = n0 + (wn * NT + nt) * 32;     // first channel of this N-tile
+        const int n = ncol + l31;
+        const float add = (p.addvec != nullptr && n < p.Cout) ? p.addvec[(size_t)b * p.addvec_bs + n] : 0.f;
+        const int n4 = ncol + cq * 4;
+        const bool nok4 = n4 < p.Cout;
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int oy = oy0 + (wm * MT + mt) * 2 + (row >> 4), ox = ox0 + (row & 15);
-                if (nok && oy < p.H && ox < p.W) {
+                s_tr[row * TP + l31] = acc[mt][nt][r] * oscale + add;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int px = (lane >> 3) + 8 * i;    // pixel of the 32-pixel M-tile (2 rows x 16 cols)
+                const int oy = oy0 + (wm * MT + mt) * 2 + (px >> 4), ox = ox0 + (px & 15);
+                float4 v = *reinterpret_cast<const float4*>(s_tr + px * TP + cq * 4);
+                if (nok4 && oy < p.H && ox < p.W) {
                     const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
-                    float v = acc[mt][nt][r] * oscale + add;
-                    if (p.residual != nullptr) v += p.residual[pix * p.res_cstride + n];
-                    p.out[pix * p.out_cstride + n] = v;
-                    s1 += v; s2 += v * v;
+                    if (p.residual != nullptr) {
+                        const float4 rv = *reinterpret_cast<const float4*>(p.residual + pix * p.res_cstride + n4);
+                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                    }
+                    *reinterpret_cast<float4*>(p.out + pix * p.out_cstride + n4) = v;
+                    s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;
+                    s2[0] += v.x * v.x; s2[1] += v.y * v.y; s2[2] += v.z * v.z; s2[3] += v.w * v.w;
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();            // scratch is rewritten by the next tile
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         if (p.stats_out != nullptr) {
-            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-            if (hi == 0) {
-                const int col = (wn * NT + nt) * 32 + l31;
-                s_red[(wm * BN + col) * 2] = s1; s_red[(wm * BN + col) * 2 + 1] = s2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o); s2[j] += __shfl_xor(s2[j], o); }
+            }
+            if (lane < 8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = (wn * NT + nt) * 32 + cq * 4 + j;
+                    s_red[(wm * BN + col) * 2] = s1[j]; s_red[(wm * BN + col) * 2 + 1] = s2[j];
+                }
             }
         }
     }
@@ -261,7 +292,8 @@ static hipError_t launch_cfg16(const ConvParams& p, hipStream_t stream) {
     constexpr int TH = 2 * MT * WM, TW = 16;
     constexpr int PP = ((TH - 1) * S + 3) * ((TW - 1) * S + 3);
     constexpr int BN = WN * NT * 32;
-    const size_t lds = (size_t)(PP * ROW + 2 * ((p.gn_C + 3) & ~3)) * 4;
+    constexpr int EPI = 4 * 32 * 36 + WM * BN * 2;           // epilogue: 4 per-wave transpose tiles + statistics scratch (floats)
+    const size_t lds = (size_t)((PP * ROW > EPI ? PP * ROW : EPI) + 2 * ((p.gn_C + 3) & ~3)) * 4;
     static bool attr_set = false;
     auto kern = conv_mfma16_kernel<MT, NT, WM, WN, S, UP, KC>;
     if (!attr_set) {

@@ -45,11 +45,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     constexpr bool A_PREFETCH = false;   // measured: prefetching the LDS fragments one k-step ahead costs 8 % (more VGPRs, clumped ds_reads)
     constexpr int A_F4 = PP * KQ, A_PER = (A_F4 + 255) / 256;
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(PP * KCP >= WM * BN * 2, "statistics scratch must fit in the patch buffer");
 
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* s_patch = reinterpret_cast<float*>(smem_raw);   // [PP][KCP]
-    float* s_sc = s_patch + PP * KCP;                       // [gn_C] GroupNorm scale
+    constexpr int EPI = 4 * 32 * 36 + WM * BN * 2;         // floats needed by the epilogue (4 transpose tiles + statistics)
+    float* s_sc = s_patch + (PP * KCP > EPI ? PP * KCP : EPI);   // [gn_C] GroupNorm scale
     float* s_sh = s_sc + ((p.gn_C + 3) & ~3);               // [gn_C] GroupNorm shift
 
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
@@ -247,34 +247,65 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     }
 
     // ---- epilogue: scale, bias(+temb), residual, store NHWC, per-channel statistics ----
-    float* s_red = s_patch;                       // [WM][BN][2], reuses the patch buffer
-    if (p.stats_out != nullptr) __syncthreads();  // all waves are done reading the patch
+    // The MFMA accumulator layout gives each lane 16 pixels of ONE channel (4-byte accesses).  Each 32x32
+    // tile is transposed through a per-wave LDS scratch so that every lane owns 4 consecutive channels of
+    // a pixel: residual loads and output stores are 16 B per lane, 1 KiB of contiguous NHWC rows per
+    // wave instruction.
+    __syncthreads();                                   // every wave is done reading the patch
+    constexpr int TP = 36;                             // scratch row pitch in floats (32 + 4 pad)
+    float* s_tr = s_patch + wave * (32 * TP);
+    float* s_red = s_patch + 4 * 32 * TP;              // [WM][BN][2] behind the 4 scratch tiles
+    const int cq = lane & 7;                           // this lane's channel quad inside a 32-channel tile
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int n = nbase + nt * 32;
-        const bool nok = n < p.Cout;
-        const float add = (p.addvec != nullptr && nok) ? p.addvec[(size_t)b * p.addvec_bs + n] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
+        const int ncol = n0 + (wn * NT + nt) * 32;
+        const int n = ncol + l31;
+        const float add = (p.addvec != nullptr && n < p.Cout) ? p.addvec[(size_t)b * p.addvec_bs + n] : 0.f;
+        const int n4 = ncol + cq * 4;
+        const bool nok4 = n4 < p.Cout;
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int oy = oy0 + (wm * MT + mt) * 2 + (row >> 4), ox = ox0 + (row & 15);
-                if (nok && oy < p.H && ox < p.W) {
+                s_tr[row * TP + l31] = acc[mt][nt][r] * p.out_scale + add;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int px = (lane >> 3) + 8 * i;
+                const int oy = oy0 + (wm * MT + mt) * 2 + (px >> 4), ox = ox0 + (px & 15);
+                float4 v = *reinterpret_cast<const float4*>(s_tr + px * TP + cq * 4);
+                if (nok4 && oy < p.H && ox < p.W) {
                     const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
-                    float v = acc[mt][nt][r] * p.out_scale + add;
-                    if (p.residual != nullptr) v += p.residual[pix * p.res_cstride + n];
-                    p.out[pix * p.out_cstride + n] = v;
-                    s1 += v; s2 += v * v;
+                    if (p.residual != nullptr) {
+                        const float4 rv = *reinterpret_cast<const float4*>(p.residual + pix * p.res_cstride + n4);
+                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                    }
+                    *reinterpret_cast<float4*>(p.out + pix * p.out_cstride + n4) = v;
+                    s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;
+                    s2[0] += v.x * v.x; s2[1] += v.y * v.y; s2[2] += v.z * v.z; s2[3] += v.w * v.w;
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         if (p.stats_out != nullptr) {
-            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-            if (hi == 0) {
-                const int col = (wn * NT + nt) * 32 + l31;
-                s_red[(wm * BN + col) * 2] = s1; s_red[(wm * BN + col) * 2 + 1] = s2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) { s1[j] += __shfl_xor(s1[j], o); s2[j] += __shfl_xor(s2[j], o); }
+            }
+            if (lane < 8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = (wn * NT + nt) * 32 + cq * 4 + j;
+                    s_red[(wm * BN + col) * 2] = s1[j]; s_red[(wm * BN + col) * 2 + 1] = s2[j];
+                }
             }
         }
     }
@@ -297,7 +328,8 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     constexpr int TH = 2 * MT * WM, TW = 16;
     constexpr int PP = ((TH - 1) * S + 3) * ((TW - 1) * S + 3);
     constexpr int BN = WN * NT * 32;
-    const size_t lds = (size_t)(PP * KCP + 2 * ((p.gn_C + 3) & ~3)) * sizeof(float);
+    constexpr int EPI = 4 * 32 * 36 + WM * BN * 2;
+    const size_t lds = (size_t)((PP * KCP > EPI ? PP * KCP : EPI) + 2 * ((p.gn_C + 3) & ~3)) * sizeof(float);
     static bool attr_set = false;
     auto kern = conv_mfma_kernel<MT, NT, WM, WN, S, UP, BM, KC>;
     if (!attr_set) {

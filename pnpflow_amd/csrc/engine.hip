@@ -77,6 +77,7 @@ struct Plan {
     Tensor t_begin, t_last;
     std::vector<Op> bops;
     size_t bwd_flops = 0;
+    float* vec_scaled = nullptr; float* vjp_scale = nullptr; unsigned int* vjp_amax = nullptr;   // VJP input normalisation
 };
 
 struct SolverBufs {
@@ -648,6 +649,12 @@ static float* packed_conv_T(pf_engine* e, const std::string& wname, int lo, int 
     return packed_conv(e, key, 0, (int)e->host.at(key).shape[1]);
 }
 
+static const void* packed_conv16_T(pf_engine* e, const std::string& wname, int lo, int hi) {
+    packed_conv_T(e, wname, lo, hi);      // creates the transposed host tensor
+    const std::string key = wname + "#T" + std::to_string(lo) + ":" + std::to_string(hi);
+    return packed_conv16(e, key, 0, (int)e->host.at(key).shape[1]);
+}
+
 struct GradEntry { Tensor t; bool has = false; };
 
 struct BwdCtx {
@@ -687,10 +694,10 @@ static ConvParams bwd_params(int B, int H, int W, int Hs, int Ws, int Cout) {
     { const char* d = getenv("PNPFLOW_HIP_DBG"); p.dbg = d ? atoi(d) : 0; }
     return p;
 }
-static void raw_seg(ConvParams& p, const float* src, int C, int cstride, int taps, const float* w) {
+static void raw_seg(ConvParams& p, const float* src, int C, int cstride, int taps, const float* w, const void* w16 = nullptr) {
     ConvSeg& s = p.seg[p.nseg++];
     s.src = src; s.C = C; s.cstride = cstride; s.coff = 0; s.xform = 0; s.taps = taps; s.gn_off = 0; s.stats = nullptr;
-    s.w = w; s.w_mode = 0; s.w_bs = 0; s.w_cs = 0; s.w_ts = 0; s.w_ns = 0; s.w_ks = 0;
+    s.w = w; s.w_mode = 0; s.w_bs = 0; s.w_cs = 0; s.w_ts = 0; s.w_ns = 0; s.w_ks = 0; s.w16 = w16;
 }
 static void gen_seg(ConvParams& p, const float* src, int C, int cstride, const float* w, int64_t w_bs, int64_t w_ns, int64_t w_ks) {
     ConvSeg& s = p.seg[p.nseg++];
@@ -738,6 +745,8 @@ static int build_backward(pf_engine* e, Plan* plan, Builder& bd) {
     BwdCtx c{e, plan, &bd, B};
     // op 0: zero the backward sums (range filled in below)
     { Op op{}; op.kind = OP_MEMSET; plan->bops.push_back(op); }
+    plan->vec_scaled = bd.acquire((size_t)B * cf.input_channels * cf.input_height * cf.input_height);
+    plan->vjp_scale = bd.acquire(64); plan->vjp_amax = reinterpret_cast<unsigned int*>(bd.acquire(64));
     const size_t bwd_lo = bd.stats_bytes;
     // ---- end: v = conv3x3(silu(gn(h)))  (models.py:492).  d(act) = adjoint conv of vec (image -> ch) --------
     {
@@ -762,7 +771,7 @@ static int build_backward(pf_engine* e, Plan* plan, Builder& bd) {
             // out = conv(nearest_up(x)): dU = adjoint conv at the fine resolution, dx = 2x2 sum-pool of dU
             Tensor dU = c.tmp(tr.in0.C, H, Wd);
             ConvParams p = bwd_params(B, H, Wd, H, Wd, tr.in0.C);
-            raw_seg(p, gout.t.p, tr.out.C, tr.out.C, 9, packed_conv_T(e, tr.pfx + "weight", 0, tr.in0.C));
+            raw_seg(p, gout.t.p, tr.out.C, tr.out.C, 9, packed_conv_T(e, tr.pfx + "weight", 0, tr.in0.C), packed_conv16_T(e, tr.pfx + "weight", 0, tr.in0.C));
             p.out = dU.p; p.out_cstride = dU.C; c.conv_plain(p);
             GradEntry& gx = c.G(tr.in0);
             Op op{}; op.kind = OP_SUMPOOL; op.P[0] = dU.p; op.O = gx.t.p; op.I[0] = tr.in0.H; op.I[1] = tr.in0.W; op.I[2] = tr.in0.C; op.I[3] = gx.has ? 1 : 0;
@@ -771,7 +780,7 @@ static int build_backward(pf_engine* e, Plan* plan, Builder& bd) {
         } else if (tr.kind == TP_DOWN) {
             // out = conv_stride2(x): dx = adjoint conv of the zero-inserted gradient
             ConvParams p = bwd_params(B, tr.in0.H, tr.in0.W, H, Wd, tr.in0.C);
-            raw_seg(p, gout.t.p, tr.out.C, tr.out.C, 9, packed_conv_T(e, tr.pfx + "weight", 0, tr.in0.C));
+            raw_seg(p, gout.t.p, tr.out.C, tr.out.C, 9, packed_conv_T(e, tr.pfx + "weight", 0, tr.in0.C), packed_conv16_T(e, tr.pfx + "weight", 0, tr.in0.C));
             c.conv_to(p, c.G(tr.in0), 1, 2);
         } else if (tr.kind == TP_RES) {
             const ResDesc& r = *tr.r;
@@ -780,7 +789,7 @@ static int build_backward(pf_engine* e, Plan* plan, Builder& bd) {
             Tensor t1 = c.tmp(r.cout, H, Wd);
             {
                 ConvParams p = bwd_params(B, H, Wd, H, Wd, r.cout);
-                raw_seg(p, gout.t.p, r.cout, r.cout, 9, packed_conv_T(e, r.prefix + "conv2.weight", 0, r.cout));
+                raw_seg(p, gout.t.p, r.cout, r.cout, 9, packed_conv_T(e, r.prefix + "conv2.weight", 0, r.cout), packed_conv16_T(e, r.prefix + "conv2.weight", 0, r.cout));
                 p.out = t1.p; p.out_cstride = r.cout; c.conv_plain(p);
             }
             GradEntry gh1; gh1.t = c.tmp(r.cout, H, Wd);
@@ -793,13 +802,13 @@ static int build_backward(pf_engine* e, Plan* plan, Builder& bd) {
             for (auto& sT : srcs) {
                 Tensor u = c.tmp(sT.C, H, Wd);
                 ConvParams p = bwd_params(B, H, Wd, H, Wd, sT.C);
-                raw_seg(p, gh1.t.p, r.cout, r.cout, 9, packed_conv_T(e, r.prefix + "conv1.weight", lo, lo + sT.C));
+                raw_seg(p, gh1.t.p, r.cout, r.cout, 9, packed_conv_T(e, r.prefix + "conv1.weight", lo, lo + sT.C), packed_conv16_T(e, r.prefix + "conv1.weight", lo, lo + sT.C));
                 p.out = u.p; p.out_cstride = sT.C; c.conv_plain(p);
                 us.push_back(u);
                 GradEntry& gd = c.G(sT);
                 if (cin != r.cout) {   // 1x1 shortcut adjoint goes straight into the gradient buffer
                     ConvParams q = bwd_params(B, H, Wd, H, Wd, sT.C);
-                    raw_seg(q, gout.t.p, r.cout, r.cout, 1, packed_conv_T(e, r.prefix + "shortcut.weight", lo, lo + sT.C));
+                    raw_seg(q, gout.t.p, r.cout, r.cout, 1, packed_conv_T(e, r.prefix + "shortcut.weight", lo, lo + sT.C), packed_conv16_T(e, r.prefix + "shortcut.weight", lo, lo + sT.C));
                     c.conv_to(q, gd);
                     adds.push_back(nullptr);
                 } else {
@@ -817,7 +826,7 @@ static int build_backward(pf_engine* e, Plan* plan, Builder& bd) {
             // d(o) = dout . Wproj
             Tensor d_o = c.tmp(C, H, Wd);
             { ConvParams p = bwd_params(B, H, Wd, H, Wd, C);
-              raw_seg(p, gout.t.p, C, C, 1, packed_conv_T(e, tr.pfx + "proj_out.weight", 0, C)); p.out = d_o.p; p.out_cstride = C; c.conv_plain(p); }
+              raw_seg(p, gout.t.p, C, C, 1, packed_conv_T(e, tr.pfx + "proj_out.weight", 0, C), packed_conv16_T(e, tr.pfx + "proj_out.weight", 0, C)); p.out = d_o.p; p.out_cstride = C; c.conv_plain(p); }
             // dA[i][j] = sum_c d_o[i][c] v[j][c]
             Tensor dA = c.tmp(HW, H, Wd);
             { ConvParams p = bwd_params(B, H, Wd, H, Wd, HW);
@@ -840,7 +849,7 @@ static int build_backward(pf_engine* e, Plan* plan, Builder& bd) {
             // d(hn) = dqkv . Wqkv ; GroupNorm backward (no activation) ; + identity path
             Tensor dhn = c.tmp(C, H, Wd);
             { ConvParams p = bwd_params(B, H, Wd, H, Wd, C);
-              raw_seg(p, dqkv.p, 3 * C, 3 * C, 1, packed_conv_T(e, tr.pfx + "qkv.w", 0, C)); p.out = dhn.p; p.out_cstride = C; c.conv_plain(p); }
+              raw_seg(p, dqkv.p, 3 * C, 3 * C, 1, packed_conv_T(e, tr.pfx + "qkv.w", 0, C), packed_conv16_T(e, tr.pfx + "qkv.w", 0, C)); p.out = dhn.p; p.out_cstride = C; c.conv_plain(p); }
             gn_backward(c, {x}, {dhn}, {&c.G(x)}, {gout.t.p}, tr.pfx + "norm.", false);
             for (float* q : {d_o.p, dA.p, dqkv.p, AT.p, dhn.p}) bd.recycle(q);
         }
@@ -863,15 +872,22 @@ static int build_backward(pf_engine* e, Plan* plan, Builder& bd) {
     return PF_OK;
 }
 
+static hipError_t dispatch_conv(pf_engine* e, const Op& op, hipStream_t s);
 static int run_backward(pf_engine* e, Plan* plan, const float* vec, float* g, hipStream_t s) {
     const int B = plan->B;
+    // J^T is linear in vec: normalise vec by a power of two (exact) so that the split-fp16 adjoint convs stay in
+    // range for any input magnitude, and undo the scale on the result
+    const int64_t nimg = (int64_t)B * e->cfg.input_channels * e->cfg.input_height * e->cfg.input_height;
+    { hipError_t r = launch_vjp_normalise(vec, plan->vec_scaled, nimg, plan->vjp_amax, plan->vjp_scale, s);
+      if (r != hipSuccess) { e->err = std::string("vjp normalise: ") + hipGetErrorString(r); return PF_ERR_HIP; } }
+    vec = plan->vec_scaled;
     for (auto& op : plan->bops) {
         hipError_t r = hipSuccess;
         switch (op.kind) {
             case OP_MEMSET: if (op.bytes) r = hipMemsetAsync(op.ptr, 0, op.bytes, s); break;
             case OP_BEGIN: { EdgeConvParams ep = op.ep; ep.in = vec; r = launch_begin_conv(ep, s); break; }
             case OP_END: { EdgeConvParams ep = op.ep; ep.out = g; r = launch_end_conv(ep, s); break; }
-            case OP_CONV: r = launch_conv(op.cp, op.stride, op.up, s); break;
+            case OP_CONV: r = dispatch_conv(e, op, s); break;
             case OP_GN_FWD_COEF:
                 r = launch_gn_fwd_coeffs((const double*)op.P[0], op.I[0], (const double*)op.P[1], op.I[1], op.I[2], op.I[3], 1e-6f, (float*)op.P[2],
                                          (float*)op.P[3], B, s); break;
@@ -890,6 +906,8 @@ static int run_backward(pf_engine* e, Plan* plan, const float* vec, float* g, hi
         }
         if (r != hipSuccess) { e->err = std::string("backward launch failed: ") + hipGetErrorString(r); return PF_ERR_HIP; }
     }
+    { hipError_t r = launch_scale_inplace(g, nimg, plan->vjp_scale + 1, s);
+      if (r != hipSuccess) { e->err = std::string("vjp rescale: ") + hipGetErrorString(r); return PF_ERR_HIP; } }
     return PF_OK;
 }
 

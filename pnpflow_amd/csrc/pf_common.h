@@ -110,6 +110,8 @@ hipError_t launch_denoise_accum(float* acc, const float* zt, const float* v, con
 hipError_t launch_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, hipStream_t s);
 hipError_t launch_psnr(const float* rec, const float* clean, float* out, int B, int n, hipStream_t s);
 hipError_t launch_fill(float* out, int64_t n, float v, hipStream_t s);
+hipError_t launch_vjp_normalise(const float* vec, float* vec_scaled, int64_t n, unsigned int* amax_bits, float* scale, hipStream_t s);
+hipError_t launch_scale_inplace(float* x, int64_t n, const float* scale, hipStream_t s);
 
 // OT-ODE per-pixel steps (pointwise.hip)
 hipError_t launch_ot_ode_vec(const DegView& d, const float* x, const float* vt, const float* y, const float* one_minus_t,

@@ -395,6 +395,39 @@ hipError_t launch_ot_ode_update(float* x, const float* vt, const float* vec, con
     return hipGetLastError();
 }
 
+// ---- power-of-two normalisation of the VJP input (keeps the backward's fp16-split operands in range) -----
+__global__ __launch_bounds__(256) void absmax_kernel(const float* x, int64_t n, unsigned int* amax_bits) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));     // non-negative floats order like their bit patterns
+}
+// scale[0] = 2^-ceil(log2(amax)) (1 if amax is 0 or not finite), scale[1] = 1/scale[0]
+__global__ void pow2_scale_kernel(const unsigned int* amax_bits, float* scale) {
+    const float a = __uint_as_float(*amax_bits);
+    float s = 1.f;
+    if (a > 0.f && a < 3.0e38f) { int e; frexpf(a, &e); s = ldexpf(1.f, -e); }     // a = m*2^e, m in [0.5,1)  ->  a*s in [0.5,1)
+    scale[0] = s; scale[1] = 1.f / s;
+}
+__global__ __launch_bounds__(256) void scale_kernel(const float* in, float* out, int64_t n, const float* scale) {
+    const float s = *scale;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = in[i] * s;
+}
+hipError_t launch_vjp_normalise(const float* vec, float* vec_scaled, int64_t n, unsigned int* amax_bits, float* scale, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(amax_bits, 0, sizeof(unsigned int), s);
+    if (e != hipSuccess) return e;
+    const unsigned g = (unsigned)std::min<int64_t>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(absmax_kernel, dim3(g), dim3(256), 0, s, vec, n, amax_bits);
+    hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, s, (const unsigned int*)amax_bits, scale);
+    hipLaunchKernelGGL(scale_kernel, dim3(g), dim3(256), 0, s, vec, vec_scaled, n, (const float*)scale);
+    return hipGetLastError();
+}
+hipError_t launch_scale_inplace(float* x, int64_t n, const float* scale, hipStream_t s) {
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 1024)), dim3(256), 0, s, (const float*)x, x, n, scale);
+    return hipGetLastError();
+}
+
 // per-image PSNR, data range 1, after postprocess (x+1)/2 (utils.py:560-577, 610)
 __global__ __launch_bounds__(1024) void psnr_kernel(const float* rec, const float* clean, float* out, int n) {
     __shared__ double s_red[1024];

@@ -371,6 +371,13 @@ def test_unet_vjp_full_net_and_linearity(hip):
     np.testing.assert_allclose(g12.cpu().numpy(), (2.0 * g1 - 0.5 * g2).cpu().numpy(), atol=2e-4 * scale)
     ref = O.unet_vjp(sd, cfg, x, t, v1)
     np.testing.assert_allclose(g1.cpu().numpy(), ref.numpy(), atol=5e-4 * scale)
+    # homogeneity far outside the f16 range: the backward normalises vec by a power of two, so
+    # J^T(c*v) == c*J^T(v) bit for bit for c = 2^k, and to rounding for any other huge/tiny c
+    for c in (2.0 ** 40, 2.0 ** -60):
+        assert torch.equal(m.backward((c * v1).cuda()), g1 * c)
+    for c in (3.7e9, 1.3e-12):
+        np.testing.assert_allclose((m.backward((c * v1).cuda()) / c).cpu().numpy(), g1.cpu().numpy(), atol=2e-4 * scale)
+    assert torch.equal(m.backward(torch.zeros_like(v1).cuda()), torch.zeros_like(g1))
     # <J u, w> == <u, J^T w> with J u from a finite difference of the HIP forward
     u = det_normal((1, 3, 128, 128), 56)
     eps = 1e-2

@@ -152,12 +152,14 @@ int pf_unet_forward_retain(pf_engine* e, const float* x, const float* t, float* 
 int pf_unet_backward(pf_engine* e, const float* vec, float* g, int B, void* stream);
 int pf_unet_vjp(pf_engine* e, const float* x, const float* t, const float* vec, float* v, float* g, int B, void* stream);
 
-/* OT-ODE per-pixel steps (pnpflow/methods/ot_ode.py:72-130 and 141-147), for the operators whose
- * H H^T is diagonal (denoising, masks, decimation); GAUSSIAN_BLUR returns PF_ERR_INVALID.
+/* OT-ODE linear solve + adjoint (pnpflow/methods/ot_ode.py:72-130) and Euler update (:141-147).
  *   vec = H_adj( (rt2[b] H H^T + sigma2)^-1 (y - H(x + one_minus_t[b]*vt)) )
- *   x  += delta * (vt + coef[b] * (vec + one_minus_t[b]*g)),  coef = ((1-t)/t)*gamma */
+ *   x  += delta * (vt + coef[b] * (vec + one_minus_t[b]*g)),  coef = ((1-t)/t)*gamma
+ * Closed form per pixel where H H^T is diagonal (denoising, masks, decimation: ot_ode.py:81-106); for
+ * GAUSSIAN_BLUR the Fourier-domain solve of ot_ode.py:108-117 with a hand-written 2-D FFT, which needs
+ * scratch >= 4*B*C*H*W + H + W floats (H, W <= 2048); scratch may be NULL for the other operators. */
 int pf_ot_ode_vec(const pf_degradation* d, const float* x, const float* vt, const float* y, const float* one_minus_t,
-                  const float* rt2, float sigma2, float* vec, int B, int C, int H, int W, void* stream);
+                  const float* rt2, float sigma2, float* vec, int B, int C, int H, int W, float* scratch, void* stream);
 int pf_ot_ode_update(float* x, const float* vt, const float* vec, const float* g, const float* one_minus_t,
                      const float* coef, float delta, int B, int n_per_image, void* stream);
 

@@ -524,6 +524,10 @@ def ot_ode_solution(problem: str, d: torch.Tensor, degradation: Degradation, x_l
         rt2 = torch.tensor((1 - delta * iteration) ** 2 / ((1 - delta * iteration) ** 2 + delta * iteration ** 2))
         # diag(D D^T) = 1 for the decimation matrix (utils.py:1124-1146)
         return (1 / (rt2 + torch.tensor(sigma_noise) ** 2)) * d
+    if problem == "gaussian_deblurring_FFT":                            # ot_ode.py:108-117 (sol stays complex; H_adj takes the real part)
+        fft_kernel = torch.fft.fft2(degradation.filter)
+        inv = rt_squared * fft_kernel * torch.conj(fft_kernel) + sigma_noise ** 2
+        return torch.fft.ifft2(torch.fft.fft2(d) / inv)
     raise NotImplementedError(problem)
 
 

@@ -1104,8 +1104,13 @@ int pf_unet_vjp(pf_engine* e, const float* x, const float* t, const float* vec, 
 }
 
 int pf_ot_ode_vec(const pf_degradation* d, const float* x, const float* vt, const float* y, const float* one_minus_t, const float* rt2,
-                  float sigma2, float* vec, int B, int C, int H, int W, void* stream) {
+                  float sigma2, float* vec, int B, int C, int H, int W, float* scratch, void* stream) {
     if (!d || !x || !vt || !y || !one_minus_t || !rt2 || !vec) return PF_ERR_INVALID;
+    if (d->kind == PF_DEG_GAUSSIAN_BLUR) {
+        if (!scratch) return PF_ERR_INVALID;
+        LAUNCHCHK(launch_ot_ode_vec_blur(to_view(d), x, vt, y, one_minus_t, rt2, sigma2, vec, B, C, H, W, scratch, (hipStream_t)stream));
+        return PF_OK;
+    }
     LAUNCHCHK(launch_ot_ode_vec(to_view(d), x, vt, y, one_minus_t, rt2, sigma2, vec, B, C, H, W, (hipStream_t)stream));
     return PF_OK;
 }

@@ -92,6 +92,7 @@ hipError_t launch_softmax_bwd(const float* A, float* dA, int64_t rows, int cols,
 hipError_t launch_sumpool2(const float* in, float* out, int B, int H, int W, int C, int accumulate, hipStream_t s);
 
 // pointwise / operator kernels (NCHW fp32 images)
+enum { DEG_DENOISE = 0, DEG_BOX = 1, DEG_MASK = 2, DEG_SR = 3, DEG_BLUR = 4 };
 struct DegView {       // device-side view of pf_degradation
     int kind, half, sf, ntaps;
     const uint8_t* mask;
@@ -116,6 +117,8 @@ hipError_t launch_scale_inplace(float* x, int64_t n, const float* scale, hipStre
 // OT-ODE per-pixel steps (pointwise.hip)
 hipError_t launch_ot_ode_vec(const DegView& d, const float* x, const float* vt, const float* y, const float* one_minus_t,
                              const float* rt2, float sigma2, float* vec, int B, int C, int H, int W, hipStream_t s);
+hipError_t launch_ot_ode_vec_blur(const DegView& d, const float* x, const float* vt, const float* y, const float* one_minus_t,
+                                  const float* rt2, float sigma2, float* vec, int B, int C, int H, int W, float* scratch, hipStream_t s);
 hipError_t launch_ot_ode_update(float* x, const float* vt, const float* vec, const float* g, const float* one_minus_t, const float* coef,
                                 float delta, int B, int n, hipStream_t s);
 

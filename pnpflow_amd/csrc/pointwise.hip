@@ -6,7 +6,6 @@
 
 namespace pf {
 
-enum { DEG_DENOISE = 0, DEG_BOX = 1, DEG_MASK = 2, DEG_SR = 3, DEG_BLUR = 4 };
 
 // ---- mask value of the inpainting family at (b, y, x) -----------------------------------
 __device__ __forceinline__ float mask_at(const DegView& d, int b, int y, int x, int H, int W) {
@@ -371,7 +370,7 @@ __global__ __launch_bounds__(256) void ot_ode_vec_kernel(DegView d, const float*
 
 hipError_t launch_ot_ode_vec(const DegView& d, const float* x, const float* vt, const float* y, const float* one_minus_t, const float* rt2,
                              float sigma2, float* vec, int B, int C, int H, int W, hipStream_t s) {
-    if (d.kind == DEG_BLUR) return hipErrorInvalidValue;   // Fourier-domain solve not implemented
+    if (d.kind == DEG_BLUR) return hipErrorInvalidValue;   // Fourier-domain solve: launch_ot_ode_vec_blur (fft2.hip)
     if (d.kind == DEG_SR && (d.sf <= 0 || H % d.sf || W % d.sf)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ot_ode_vec_kernel, grid_for(C * H * W, B), dim3(256), 0, s, d, x, vt, y, one_minus_t, rt2, sigma2, vec, C, H, W);
     return hipGetLastError();

@@ -57,8 +57,9 @@ class OT_ODE(object):
     def restore_batch(self, noisy_img, degradation, sigma_noise, iter_cb=None):
         args = self.args
         problem = args.problem
-        if problem not in ("denoising", "inpainting", "random_inpainting", "superresolution"):
-            raise NotImplementedError(f"ot_ode closed-form solve for '{problem}' is not implemented by this engine")
+        if problem not in ("denoising", "inpainting", "random_inpainting", "superresolution", "gaussian_deblurring_FFT"):
+            # the reference's remaining branch is a per-image GMRES on H H^T (ot_ode.py:118-128); none of its operators reach it
+            raise NotImplementedError(f"ot_ode linear solve for '{problem}' is not implemented by this engine")
         steps, delta = args.steps_ode, 1 / args.steps_ode
         B = noisy_img.shape[0]
         Cc, Hh = self.model.input_channels, self.model.input_height
@@ -68,13 +69,16 @@ class OT_ODE(object):
         x = self.initialization(degradation.H_adj(y.clone()), args.start_time).contiguous()     # ot_ode.py:50-52
         vec = torch.empty_like(x)
         n = x[0].numel()
+        # Fourier-domain solve (ot_ode.py:108-117): workspace for x1_hat, H(x1_hat), the complex spectrum and |fft filter|^2
+        scratch = torch.empty(4 * x.numel() + 2 * Hh, dtype=torch.float32, device=dev) if problem == "gaussian_deblurring_FFT" else None
         st = _lib.current_stream_ptr()
         for iteration in range(int(steps * args.start_time), int(steps)):
             t1, omt, rt2, coef = self._scalars(iteration, delta, problem, B, dev)
             vt = self.model.forward_retain(x, t1)
             _lib.check(self.lib.pf_ot_ode_vec(C.byref(d), x.data_ptr(), vt.data_ptr(), y.data_ptr(), omt.data_ptr(), rt2.data_ptr(),
                                               float(np.float32(sigma_noise) ** 2) if problem == "superresolution" else float(sigma_noise ** 2),
-                                              vec.data_ptr(), B, Cc, Hh, Hh, st), None, "pf_ot_ode_vec")
+                                              vec.data_ptr(), B, Cc, Hh, Hh, scratch.data_ptr() if scratch is not None else None, st),
+                       None, "pf_ot_ode_vec")
             g = self.model.backward(vec)
             _lib.check(self.lib.pf_ot_ode_update(x.data_ptr(), vt.data_ptr(), vec.data_ptr(), g.data_ptr(), omt.data_ptr(), coef.data_ptr(),
                                                  float(delta), B, n, st), None, "pf_ot_ode_update")

@@ -192,7 +192,9 @@ def test_unet_vjp_matches_reference(golden, net):
 OT_CASES = [("tiny4_random_inpainting", "tiny4", "random_inpainting", lambda S: (O.RandomInpainting(0.7), 0.01), 0.1, "constant"),
             ("tiny4_inpainting", "tiny4", "inpainting", lambda S: (O.BoxInpainting(10), 0.05), 0.1, "gamma_t"),
             ("tiny4_superresolution", "tiny4", "superresolution", lambda S: (O.Superresolution(2, S), 0.05), 0.1, "constant"),
-            ("mnist_denoising", "mnist", "denoising", lambda S: (O.Denoising(), 0.2), 0.3, "gamma_t")]
+            ("mnist_denoising", "mnist", "denoising", lambda S: (O.Denoising(), 0.2), 0.3, "gamma_t"),
+            ("tiny4_gaussian_deblurring_FFT", "tiny4", "gaussian_deblurring_FFT", lambda S: (O.GaussianDeblurring(1.0, 61, "fft", 3, S), 0.05), 0.1,
+             "constant")]
 
 
 @pytest.mark.parametrize("tag,net,problem,mk,t0,gamma", OT_CASES)

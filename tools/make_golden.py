@@ -234,7 +234,9 @@ def gen_ot_ode(models, degr, utils):
     cases = [("tiny4_random_inpainting", "tiny4", "random_inpainting", lambda S: (degr.RandomInpainting(0.7), 0.01), 0.1, "constant"),
              ("tiny4_inpainting", "tiny4", "inpainting", lambda S: (degr.BoxInpainting(10), 0.05), 0.1, "gamma_t"),
              ("tiny4_superresolution", "tiny4", "superresolution", lambda S: (degr.Superresolution(2, S, device="cpu"), 0.05), 0.1, "constant"),
-             ("mnist_denoising", "mnist", "denoising", lambda S: (degr.Denoising(), 0.2), 0.3, "gamma_t")]
+             ("mnist_denoising", "mnist", "denoising", lambda S: (degr.Denoising(), 0.2), 0.3, "gamma_t"),
+             ("tiny4_gaussian_deblurring_FFT", "tiny4", "gaussian_deblurring_FFT",
+              lambda S: (degr.GaussianDeblurring(1.0, 61, "fft", 3, S, device="cpu"), 0.05), 0.1, "constant")]
     steps, B = 10, 2
     for tag, net, problem, mk, t0, gamma in cases:
         m, cfg, sd = build_ref_unet(models, net)

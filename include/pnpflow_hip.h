@@ -100,14 +100,16 @@ typedef enum pf_degradation_kind {
     PF_DEG_BOX_INPAINTING = 1,  /* BoxInpainting       degradations.py:23-32, utils.py:327-336 */
     PF_DEG_MASK_INPAINTING = 2, /* RandomInpainting    degradations.py:35-44 (mask supplied: utils.py:353-361) */
     PF_DEG_SUPERRESOLUTION = 3, /* Superresolution     degradations.py:92-127, mode=None, utils.py:283-310 */
-    PF_DEG_GAUSSIAN_BLUR = 4    /* GaussianDeblurring  degradations.py:55-89 (circular, separable) */
+    PF_DEG_GAUSSIAN_BLUR = 4,   /* GaussianDeblurring  degradations.py:55-89 (circular, separable) */
+    PF_DEG_SR_FILTERED = 5      /* Superresolution mode="bicubic": circular separable filter (utils.py:365-396), then decimation
+                                   degradations.py:97-127; uses sf, ntaps (4*sf, even), taps */
 } pf_degradation_kind;
 
 typedef struct pf_degradation {
     int32_t kind;
     int32_t half_size_mask;     /* BOX */
     int32_t sf;                 /* SUPERRESOLUTION */
-    int32_t ntaps;              /* GAUSSIAN_BLUR: odd, <= 127 */
+    int32_t ntaps;              /* GAUSSIAN_BLUR / SR_FILTERED: <= 127; tap ntaps/2 sits at offset 0 (the reference's roll by -(K-1)//2) */
     const uint8_t* mask;        /* MASK: device [B][H][W] bytes, 1 = keep */
     const float* taps;          /* GAUSSIAN_BLUR: device [ntaps] separable 1-D taps */
 } pf_degradation;
@@ -122,7 +124,7 @@ int pf_degradation_H_adj(const pf_degradation* d, const float* y, float* x, int 
 /* ---- PnP-Flow iteration pieces (pnpflow/methods/pnp_flow.py) ------------------------- */
 /* z = x - coef[b] * H_adj(H(x) - y),  coef[b] = lr_t[b] / sigma^2
  * replaces grad_datafit + the update at pnp_flow.py:39-41, 109-112 (gaussian noise).
- * scratch: >= 2*B*C*H*W floats for GAUSSIAN_BLUR, may be NULL otherwise. */
+ * scratch: >= 2*B*C*H*W floats for GAUSSIAN_BLUR and SR_FILTERED (pf_degradation_H/H_adj: B*C*H*W resp. 2*B*C*H*W), may be NULL otherwise. */
 int pf_grad_step(const pf_degradation* d, const float* x, const float* y, const float* coef, float* z,
                  int B, int C, int H, int W, float* scratch, void* stream);
 /* Laplace noise model (pnp_flow.py:42-43): z = x - coef[b] * H_adj(2*heaviside(H(x) - y, 0) - 1), coef[b] = lr_t[b]/sigma */

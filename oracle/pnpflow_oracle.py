@@ -329,21 +329,49 @@ class GaussianDeblurring(Degradation):
         return torch.real(torch.fft.ifft2(torch.fft.fft2(x) * torch.conj(torch.fft.fft2(self.filter))))
 
 
+def bicubic_filter(factor: int = 2) -> torch.Tensor:
+    """pnpflow/utils.py:365-396: Keys bicubic (a=-0.5), size (4 factor)^2, normalised to sum 1."""
+    x = np.abs(np.arange(start=-2 * factor + 0.5, stop=2 * factor, step=1) / factor)
+    a = -0.5
+    w = ((a + 2) * np.power(x, 3) - (a + 3) * np.power(x, 2) + 1) * (x <= 1)
+    w += (a * np.power(x, 3) - 5 * a * np.power(x, 2) + 8 * a * x - 4 * a) * (x > 1) * (x < 2)
+    w = np.outer(w, w)
+    return torch.Tensor(w / np.sum(w)).unsqueeze(0).unsqueeze(0)
+
+
 class Superresolution(Degradation):
-    """pnpflow/degradations.py:92-127 with mode=None (the only one main.py:165 uses):
+    """pnpflow/degradations.py:92-127.  mode=None (the only one main.py:165 uses):
     H = x[..., ::sf, ::sf] (utils.py:302-310); H_adj = zero-fill (utils.py:283-299).
+    mode="bicubic": circular FFT convolution with the rolled bicubic filter, then decimation (:117-120);
+    H_adj = zero-fill then the conjugate filter (:125-127).
     The dense downsampling matrix (degradations.py:110-111) is only read by ot_ode."""
     def __init__(self, sf, dim_image, mode=None, device="cpu"):
-        assert mode is None
-        self.sf = sf
+        assert mode in (None, "bicubic")
+        self.sf, self.mode = sf, mode
+        if mode == "bicubic":
+            k = bicubic_filter(sf)
+            f = torch.zeros((1, 3, dim_image, dim_image))
+            f[..., :k.shape[-1], :k.shape[-1]] = k
+            s = -(k.shape[-1] - 1) // 2                  # (-(K-1))//2 : floor division of the negative number, as :108
+            self.filter = torch.roll(f, shifts=(s, s), dims=(2, 3))
 
-    def H(self, x):
+    def _down(self, x):
         return x[..., ::self.sf, ::self.sf]
 
-    def H_adj(self, x):
+    def _up(self, x):
         z = torch.zeros((x.shape[0], x.shape[1], x.shape[2] * self.sf, x.shape[3] * self.sf), dtype=x.dtype)
         z[..., ::self.sf, ::self.sf] = x
         return z
+
+    def H(self, x):
+        if self.mode is None:
+            return self._down(x)
+        return self._down(torch.real(torch.fft.ifft2(torch.fft.fft2(x) * torch.fft.fft2(self.filter))))
+
+    def H_adj(self, x):
+        if self.mode is None:
+            return self._up(x)
+        return torch.real(torch.fft.ifft2(torch.fft.fft2(self._up(x)) * torch.conj(torch.fft.fft2(self.filter))))
 
 
 def make_degradation(problem: str, dim_image: int, num_channels: int = 3, noise_type: str = "gaussian"):

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libpnpflow_hip.so")
 
 PF_ABI_VERSION = 1
 
-PF_DEG_DENOISING, PF_DEG_BOX_INPAINTING, PF_DEG_MASK_INPAINTING, PF_DEG_SUPERRESOLUTION, PF_DEG_GAUSSIAN_BLUR = range(5)
+PF_DEG_DENOISING, PF_DEG_BOX_INPAINTING, PF_DEG_MASK_INPAINTING, PF_DEG_SUPERRESOLUTION, PF_DEG_GAUSSIAN_BLUR, PF_DEG_SR_FILTERED = range(6)
 
 
 class PfUnetCfg(C.Structure):

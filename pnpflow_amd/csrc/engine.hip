@@ -1267,7 +1267,7 @@ int pf_pnp_flow_restore(pf_engine* e, const pf_degradation* d, const pf_pnp_para
     const int C = e->cfg.input_channels, H = e->cfg.input_height;
     if (e->cfg.output_channels != C) { e->err = "restoration needs output_channels == input_channels"; return PF_ERR_INVALID; }
     const size_t n = (size_t)C * H * H;
-    const int Hy = d->kind == PF_DEG_SUPERRESOLUTION ? H / std::max(1, d->sf) : H;
+    const int Hy = (d->kind == PF_DEG_SUPERRESOLUTION || d->kind == PF_DEG_SR_FILTERED) ? H / std::max(1, d->sf) : H;
     const size_t ny = (size_t)C * Hy * Hy;
     int rc = ensure_solver(e, B, n, ny, prm->steps, prm->batch_samples ? prm->num_samples : 1);
     if (rc != PF_OK) return rc;

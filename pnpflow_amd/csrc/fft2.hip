@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void fft_rows_inv_kernel(const float2* z, floa
 __global__ void blur_power_spectrum_kernel(const float* taps, int ntaps, int N, float* pw) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= N) return;
-    const int r = (ntaps - 1) / 2;
+    const int r = ntaps / 2;
     double re = 0.0, im = 0.0;
     for (int j = 0; j < ntaps; ++j) {
         long long m = ((long long)u * (j - r)) % N;               // exp(-2 pi i u (j-r) / N)

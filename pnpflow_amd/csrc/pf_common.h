@@ -92,7 +92,7 @@ hipError_t launch_softmax_bwd(const float* A, float* dA, int64_t rows, int cols,
 hipError_t launch_sumpool2(const float* in, float* out, int B, int H, int W, int C, int accumulate, hipStream_t s);
 
 // pointwise / operator kernels (NCHW fp32 images)
-enum { DEG_DENOISE = 0, DEG_BOX = 1, DEG_MASK = 2, DEG_SR = 3, DEG_BLUR = 4 };
+enum { DEG_DENOISE = 0, DEG_BOX = 1, DEG_MASK = 2, DEG_SR = 3, DEG_BLUR = 4, DEG_SR_FILTER = 5 };
 struct DegView {       // device-side view of pf_degradation
     int kind, half, sf, ntaps;
     const uint8_t* mask;

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void blur_pass_kernel(const float* in, float* 
     __syncthreads();
     const int b = blockIdx.y;
     const int n = C * H * W;
-    const int r = (ntaps - 1) / 2;
+    const int r = ntaps / 2;          // index of the tap that sits at offset 0 after the reference's roll by -(K-1)//2 (floor division)
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const int px = i % W, py = (i / W) % H, pl = i / (W * H);
         const float* src = in + ((size_t)b * C + pl) * H * W;
@@ -117,8 +117,17 @@ hipError_t launch_deg_H(const DegView& d, const float* x, float* y, int B, int C
             return hipGetLastError();
         }
         case DEG_BLUR:
-            if (!scratch || d.ntaps > 127 || !(d.ntaps & 1)) return hipErrorInvalidValue;
+            if (!scratch || d.ntaps < 1 || d.ntaps > 127) return hipErrorInvalidValue;
             return blur2(d, x, scratch, y, B, C, H, W, +1, 0, nullptr, nullptr, s);
+        case DEG_SR_FILTER: {      // y = decimate(filter (*) x)
+            if (!scratch || d.ntaps < 1 || d.ntaps > 127 || d.sf <= 0 || H % d.sf || W % d.sf) return hipErrorInvalidValue;
+            float* s0 = scratch; float* s1 = scratch + (size_t)B * C * H * W;
+            hipError_t e = blur2(d, x, s0, s1, B, C, H, W, +1, 0, nullptr, nullptr, s);
+            if (e != hipSuccess) return e;
+            const size_t n = (size_t)B * C * (H / d.sf) * (W / d.sf);
+            hipLaunchKernelGGL(decimate_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, s, (const float*)s1, y, B * C, H, W, d.sf);
+            return hipGetLastError();
+        }
     }
     return hipErrorInvalidValue;
 }
@@ -135,8 +144,15 @@ hipError_t launch_deg_Hadj(const DegView& d, const float* y, float* x, int B, in
             return hipGetLastError();
         }
         case DEG_BLUR:
-            if (!scratch || d.ntaps > 127 || !(d.ntaps & 1)) return hipErrorInvalidValue;
+            if (!scratch || d.ntaps < 1 || d.ntaps > 127) return hipErrorInvalidValue;
             return blur2(d, y, scratch, x, B, C, H, W, -1, 0, nullptr, nullptr, s);
+        case DEG_SR_FILTER: {      // x = filter^T (*) zerofill(y)
+            if (!scratch || d.ntaps < 1 || d.ntaps > 127 || d.sf <= 0 || H % d.sf || W % d.sf) return hipErrorInvalidValue;
+            float* s0 = scratch; float* s1 = scratch + (size_t)B * C * H * W;
+            const size_t n = (size_t)B * C * H * W;
+            hipLaunchKernelGGL(zerofill_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, s, y, s0, B * C, H, W, d.sf);
+            return blur2(d, s0, s1, x, B, C, H, W, -1, 0, nullptr, nullptr, s);
+        }
     }
     return hipErrorInvalidValue;
 }
@@ -177,6 +193,22 @@ __global__ __launch_bounds__(256) void grad_step_sr_kernel(const float* x, const
     }
 }
 
+// out (full resolution) = zerofill( decimate(hx) - y )   (or its sign: laplace)
+__global__ __launch_bounds__(256) void sr_residual_kernel(const float* hx, const float* y, float* out, int C, int H, int W, int sf, int laplace) {
+    const int b = blockIdx.y;
+    const int n = C * H * W, Hy = H / sf, Wy = W / sf;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int px = i % W, py = (i / W) % H, pl = i / (W * H);
+        const size_t o = (size_t)b * n + i;
+        float g = 0.f;
+        if (py % sf == 0 && px % sf == 0) {
+            g = hx[o] - y[(((size_t)b * C + pl) * Hy + py / sf) * Wy + px / sf];
+            if (laplace) g = g > 0.f ? 1.f : -1.f;
+        }
+        out[o] = g;
+    }
+}
+
 hipError_t launch_grad_step(const DegView& d, const float* x, const float* y, const float* coef, float* z,
                             int B, int C, int H, int W, float* scratch, int laplace, hipStream_t s) {
     dim3 g = grid_for(C * H * W, B);
@@ -189,12 +221,21 @@ hipError_t launch_grad_step(const DegView& d, const float* x, const float* y, co
             hipLaunchKernelGGL(grad_step_sr_kernel, g, dim3(256), 0, s, x, y, coef, z, C, H, W, d.sf, laplace);
             return hipGetLastError();
         case DEG_BLUR: {
-            if (!scratch || d.ntaps > 127 || !(d.ntaps & 1)) return hipErrorInvalidValue;
+            if (!scratch || d.ntaps < 1 || d.ntaps > 127) return hipErrorInvalidValue;
             float* s0 = scratch;
             float* s1 = scratch + (size_t)B * C * H * W;
             hipError_t e = blur2(d, x, s0, s1, B, C, H, W, +1, laplace ? 3 : 1, y, nullptr, s);     // s1 = Hx - y  (or its sign)
             if (e != hipSuccess) return e;
             return blur2(d, s1, s0, z, B, C, H, W, -1, 2, x, coef, s);                 // z = x - coef*H_adj(s1)
+        }
+        case DEG_SR_FILTER: {
+            if (!scratch || d.ntaps < 1 || d.ntaps > 127 || d.sf <= 0 || H % d.sf || W % d.sf) return hipErrorInvalidValue;
+            float* s0 = scratch;
+            float* s1 = scratch + (size_t)B * C * H * W;
+            hipError_t e = blur2(d, x, s0, s1, B, C, H, W, +1, 0, nullptr, nullptr, s);             // s1 = filter (*) x
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(sr_residual_kernel, g, dim3(256), 0, s, (const float*)s1, y, s0, C, H, W, d.sf, laplace);
+            return blur2(d, s0, s1, z, B, C, H, W, -1, 2, x, coef, s);                 // z = x - coef*filter^T (*) s0
         }
     }
     return hipErrorInvalidValue;

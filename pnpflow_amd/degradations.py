@@ -41,9 +41,10 @@ class Degradation:
         if adjoint:
             out = torch.empty((B, Cc, Hf, Wf), dtype=torch.float32, device=x.device)
         else:
-            sf = getattr(self, "sf", 1) if self.kind == _lib.PF_DEG_SUPERRESOLUTION else 1
+            sf = getattr(self, "sf", 1) if self.kind in (_lib.PF_DEG_SUPERRESOLUTION, _lib.PF_DEG_SR_FILTERED) else 1
             out = torch.empty((B, Cc, Hf // sf, Wf // sf), dtype=torch.float32, device=x.device)
-        scratch = torch.empty((B, Cc, Hf, Wf), dtype=torch.float32, device=x.device) if self.kind == _lib.PF_DEG_GAUSSIAN_BLUR else None
+        n_scr = {_lib.PF_DEG_GAUSSIAN_BLUR: 1, _lib.PF_DEG_SR_FILTERED: 2}.get(self.kind, 0)
+        scratch = torch.empty((n_scr, B, Cc, Hf, Wf), dtype=torch.float32, device=x.device) if n_scr else None
         fn = lib.pf_degradation_H_adj if adjoint else lib.pf_degradation_H
         _lib.check(fn(C.byref(d), x.data_ptr(), out.data_ptr(), B, Cc, Hf, Wf,
                       scratch.data_ptr() if scratch is not None else None, _lib.current_stream_ptr()), None, fn.__name__)
@@ -150,20 +151,40 @@ class GaussianDeblurring(Degradation):
         return self._apply(x, True)
 
 
+def bicubic_taps(factor):
+    """1-D factor of the reference's bicubic filter (utils.py:365-396): Keys cubic (a = -0.5) sampled at
+    (k + 0.5)/factor - 2; the reference's normalised outer(w, w) equals outer(w/sum w, w/sum w)."""
+    x = np.abs(np.arange(start=-2 * factor + 0.5, stop=2 * factor, step=1) / factor)
+    a = -0.5
+    w = ((a + 2) * x ** 3 - (a + 3) * x ** 2 + 1) * (x <= 1) + (a * x ** 3 - 5 * a * x ** 2 + 8 * a * x - 4 * a) * (x > 1) * (x < 2)
+    return (w / w.sum()).astype(np.float32)
+
+
 class Superresolution(Degradation):
-    """reference pnpflow/degradations.py:92-127 with mode=None (main.py:165):
-    H = x[..., ::sf, ::sf], H_adj = zero-fill.  The dense (HW/sf^2, HW) matrix the reference
-    builds in the constructor is only read by ot_ode and is not materialised here."""
+    """reference pnpflow/degradations.py:92-127.  mode=None (main.py:165): H = x[..., ::sf, ::sf],
+    H_adj = zero-fill.  mode="bicubic": circular convolution with the 4sf x 4sf bicubic filter (separable:
+    two 1-D passes instead of the reference's FFTs), then decimation; H_adj = zero-fill, then the conjugate
+    filter.  The dense (HW/sf^2, HW) matrix the reference builds in the constructor is only read by ot_ode
+    (where diag(D D^T) = 1) and is not materialised here."""
     kind = _lib.PF_DEG_SUPERRESOLUTION
 
     def __init__(self, sf, dim_image, mode=None, device="cuda"):
         super().__init__()
-        if mode is not None:
-            raise NotImplementedError("bicubic superresolution is not implemented (main.py uses mode=None)")
+        if mode not in (None, "bicubic"):
+            raise NotImplementedError(f"Superresolution mode {mode!r}")
         self.sf, self.dim_image, self.mode = sf, dim_image, mode
+        if mode == "bicubic":
+            self.kind = _lib.PF_DEG_SR_FILTERED
+            self.taps_host = bicubic_taps(sf)
+            self._taps = {}
 
     def descriptor(self, B, H, W, device):
         d = _lib.PfDegradation(); d.kind = self.kind; d.sf = int(self.sf)
+        if self.mode == "bicubic":
+            key = str(device)
+            if key not in self._taps:
+                self._taps[key] = torch.from_numpy(self.taps_host).to(device)
+            d.ntaps = int(self.taps_host.shape[0]); d.taps = self._taps[key].data_ptr()
         return d
 
     def H(self, x):

@@ -57,6 +57,8 @@ def deg_pairs(S):
             ("random", D.RandomInpainting(0.7), O.RandomInpainting(0.7)),
             ("sr2", D.Superresolution(2, S), O.Superresolution(2, S)),
             ("sr4", D.Superresolution(4, S), O.Superresolution(4, S)),
+            ("srbic2", D.Superresolution(2, S, mode="bicubic"), O.Superresolution(2, S, mode="bicubic")),
+            ("srbic4", D.Superresolution(4, S, mode="bicubic"), O.Superresolution(4, S, mode="bicubic")),
             ("blur1", D.GaussianDeblurring(1.0, 61, "fft", 3, S), O.GaussianDeblurring(1.0, 61, "fft", 3, S)),
             ("blur3", D.GaussianDeblurring(3.0, 61, "fft", 3, S), O.GaussianDeblurring(3.0, 61, "fft", 3, S))]
 
@@ -67,7 +69,7 @@ def test_degradations_match_oracle(hip, S, B):
     for name, dg, do in deg_pairs(S):
         y_ref = do.H(x)
         y = dg.H(x.cuda()).cpu()
-        exact = not name.startswith("blur")
+        exact = not name.startswith(("blur", "srbic"))
         if exact:
             assert torch.equal(y, y_ref.contiguous()), name
         else:
@@ -93,6 +95,9 @@ def test_degradations_match_golden(hip, golden):
         y = d.H(x64)
         np.testing.assert_array_equal(y.cpu().numpy(), g[f"sr{sf}_H"])
         np.testing.assert_array_equal(d.H_adj(y).cpu().numpy(), g[f"sr{sf}_Hadj"])
+        d = D.Superresolution(sf, 64, mode="bicubic")
+        np.testing.assert_allclose(d.H(x64).cpu().numpy(), g[f"srbic{sf}_H"], atol=1e-5)
+        np.testing.assert_allclose(d.H_adj(det_normal((2, 3, 64 // sf, 64 // sf), 24).cuda()).cpu().numpy(), g[f"srbic{sf}_Hadj"], atol=1e-5)
     for sig in (1.0, 3.0):
         d = D.GaussianDeblurring(sig, 61, "fft", 3, 64)
         np.testing.assert_allclose(d.H(x64).cpu().numpy(), g[f"blur{sig}_H"], atol=1e-5)
@@ -221,10 +226,11 @@ def traj_cases():
             ("tiny4_inpainting", "tiny4", "inpainting", lambda S: D.BoxInpainting(10), 0.05),
             ("tiny4_superresolution", "tiny4", "superresolution", lambda S: D.Superresolution(2, S), 0.05),
             ("tiny4_deblurring", "tiny4", "gaussian_deblurring_FFT", lambda S: D.GaussianDeblurring(1.0, 61, "fft", 3, S), 0.05),
-            ("tiny4_random_inpainting", "tiny4", "random_inpainting", lambda S: D.RandomInpainting(0.7), 0.01)]
+            ("tiny4_random_inpainting", "tiny4", "random_inpainting", lambda S: D.RandomInpainting(0.7), 0.01),
+            ("tiny4_superresolution_bicubic", "tiny4", "superresolution", lambda S: D.Superresolution(2, S, mode="bicubic"), 0.05)]
 
 
-@pytest.mark.parametrize("idx", range(5))
+@pytest.mark.parametrize("idx", range(6))
 @pytest.mark.parametrize("use_graph,precision,batch_samples", [(False, 0, False), (True, 0, False), (True, 0, True), (True, 1, True)])
 def test_pnp_flow_trajectory_matches_reference(hip, golden, idx, use_graph, precision, batch_samples):
     from pnpflow_amd.methods.pnp_flow import PNP_FLOW

@@ -73,6 +73,13 @@ def test_degradations_match_reference(golden):
         y = d.H(x64).contiguous()
         np.testing.assert_array_equal(y.numpy(), g[f"sr{sf}_H"])
         np.testing.assert_array_equal(d.H_adj(y).numpy(), g[f"sr{sf}_Hadj"])
+        d = O.Superresolution(sf, 64, mode="bicubic")
+        np.testing.assert_allclose(d.H(x64).numpy(), g[f"srbic{sf}_H"], atol=1e-6)
+        np.testing.assert_allclose(d.H_adj(det_normal((2, 3, 64 // sf, 64 // sf), 24)).numpy(), g[f"srbic{sf}_Hadj"], atol=1e-6)
+        # separable factorisation + roll offset used by the HIP kernel: tap K/2 of the 1-D factor sits at offset 0
+        k = O.bicubic_filter(sf)[0, 0].numpy(); w = k.sum(0)
+        np.testing.assert_allclose(np.outer(w, w), k, atol=1e-8)
+        assert d.filter[0, 0, 0, 0] == k[2 * sf, 2 * sf]
     for sig in (1.0, 3.0):
         d = O.GaussianDeblurring(sig, 61, "fft", 3, 64)
         np.testing.assert_allclose(d.H(x64).numpy(), g[f"blur{sig}_H"], atol=1e-6)
@@ -94,7 +101,7 @@ def test_degradations_match_reference(golden):
 def test_adjoint_identity():
     x = det_normal((2, 3, 64, 64), 5)
     for d, yshape in ((O.BoxInpainting(10), (2, 3, 64, 64)), (O.RandomInpainting(0.7), (2, 3, 64, 64)),
-                      (O.Superresolution(2, 64), (2, 3, 32, 32)), (O.GaussianDeblurring(3.0, 61, "fft", 3, 64), (2, 3, 64, 64))):
+                      (O.Superresolution(2, 64), (2, 3, 32, 32)), (O.Superresolution(4, 64, mode="bicubic"), (2, 3, 16, 16)), (O.GaussianDeblurring(3.0, 61, "fft", 3, 64), (2, 3, 64, 64))):
         y = det_normal(yshape, 6)
         a = (d.H(x).double() * y.double()).sum(); b = (x.double() * d.H_adj(y).double()).sum()
         assert abs(a - b) <= 1e-5 * max(1.0, abs(a))
@@ -104,7 +111,8 @@ TRAJ = [("mnist_denoising", "mnist", lambda S: (O.Denoising(), 0.2)),
         ("tiny4_inpainting", "tiny4", lambda S: (O.BoxInpainting(10), 0.05)),
         ("tiny4_superresolution", "tiny4", lambda S: (O.Superresolution(2, S), 0.05)),
         ("tiny4_deblurring", "tiny4", lambda S: (O.GaussianDeblurring(1.0, 61, "fft", 3, S), 0.05)),
-        ("tiny4_random_inpainting", "tiny4", lambda S: (O.RandomInpainting(0.7), 0.01))]
+        ("tiny4_random_inpainting", "tiny4", lambda S: (O.RandomInpainting(0.7), 0.01)),
+        ("tiny4_superresolution_bicubic", "tiny4", lambda S: (O.Superresolution(2, S, mode="bicubic"), 0.05))]
 
 
 def det_laplace(shape, scale):

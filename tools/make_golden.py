@@ -134,6 +134,11 @@ def gen_degradations(degr, utils):
         d = degr.Superresolution(sf, S, device="cpu")
         ylow = d.H(x64)
         rec[f"sr{sf}_H"] = ylow.contiguous().numpy(); rec[f"sr{sf}_Hadj"] = d.H_adj(ylow.contiguous()).numpy()
+    # bicubic superresolution (degradations.py:97-127; only reachable through the class API, main.py uses mode=None)
+    for sf, S in ((2, 64), (4, 64)):
+        d = degr.Superresolution(sf, S, mode="bicubic", device="cpu")
+        ylow = d.H(x64)
+        rec[f"srbic{sf}_H"] = ylow.contiguous().numpy(); rec[f"srbic{sf}_Hadj"] = d.H_adj(det_normal((2, 3, 64 // sf, 64 // sf), 24)).numpy()
     # gaussian deblurring (FFT, circular)
     for sig, S in ((1.0, 64), (3.0, 64)):
         d = degr.GaussianDeblurring(sig, 61, "fft", 3, S, "cpu")
@@ -161,6 +166,7 @@ def gen_traj(models, degr, utils, pnp):
         ("tiny4_superresolution", "tiny4", "superresolution", lambda S: (degr.Superresolution(2, S, device="cpu"), 0.05), 0.3, 2),
         ("tiny4_deblurring", "tiny4", "gaussian_deblurring_FFT", lambda S: (degr.GaussianDeblurring(1.0, 61, "fft", 3, S, "cpu"), 0.05), 0.01, 2),
         ("tiny4_random_inpainting", "tiny4", "random_inpainting", lambda S: (degr.RandomInpainting(0.7), 0.01), 0.01, 2),
+        ("tiny4_superresolution_bicubic", "tiny4", "superresolution", lambda S: (degr.Superresolution(2, S, mode="bicubic", device="cpu"), 0.05), 0.3, 2),
         # Laplace noise model (pnp_flow.py:42-43, 64-66, 81-85; sigma 0.3 from main.py:121-176)
         ("laplace_tiny4_superresolution", "tiny4", "superresolution", lambda S: (degr.Superresolution(2, S, device="cpu"), 0.3), 0.3, 2),
         ("laplace_tiny4_deblurring", "tiny4", "gaussian_deblurring_FFT", lambda S: (degr.GaussianDeblurring(1.0, 61, "fft", 3, S, "cpu"), 0.3), 0.01, 2),

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
 
     prefetch(0, 0);
 
-    for (int c = tid; c < p.gn_C; c += 256) {
+    for (int c = tid; c < ((p.dbg & 64) ? 0 : p.gn_C); c += 256) {
         const int g = c / p.gn_cpg;
         double s = 0.0, ss = 0.0;
         for (int j = g * p.gn_cpg; j < (g + 1) * p.gn_cpg; ++j) {
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
     while (true) {
         const ConvSeg& sg = p.seg[si];
         __syncthreads();
-        store_lds(si, ch);
+        if (!(p.dbg & 2) || (si == 0 && ch == 0)) store_lds(si, ch);
         __syncthreads();
         int nsi = si, nch = ch + 1;
         if (nch * KC >= sg.C) { nsi = si + 1; nch = 0; }
@@ -169,10 +169,10 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
         const int nsteps = sg.taps * KS;      // k16-steps per chunk: 9 / 1 (KC 16), 18 / 2 (KC 32), 4 (KC 64, 1-tap launches)
         uint4 bh0[NT], bl0[NT], bh1[NT], bl1[NT], bh2[NT], bl2[NT];
         load_b(sg, ch, 0, bh0, bl0); load_b(sg, ch, min(1, nsteps - 1), bh1, bl1);
-        if (more) prefetch(nsi, nch);
+        if (more && !(p.dbg & 2)) prefetch(nsi, nch);
 
         auto k_step = [&](int s, uint4 (&ch_)[NT], uint4 (&cl_)[NT], uint4 (&nh_)[NT], uint4 (&nl_)[NT]) {
-            load_b(sg, ch, min(s + 2, nsteps - 1), nh_, nl_);
+            if (!(p.dbg & 8)) load_b(sg, ch, min(s + 2, nsteps - 1), nh_, nl_);
             __builtin_amdgcn_sched_barrier(0);
             const int tap = s / KS, j = s % KS;
             const int ky = sg.taps == 9 ? tap / 3 : 1, kx = sg.taps == 9 ? tap % 3 : 1;
@@ -180,8 +180,16 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int ppix = (((wm * MT + mt) * 2 + prow) * S + ky) * PW + pcol * S + kx;
+                if (p.dbg & 4) { ah[mt] = *reinterpret_cast<const f16x8*>(&ch_[0]); al[mt] = *reinterpret_cast<const f16x8*>(&cl_[0]); continue; }
                 ah[mt] = *reinterpret_cast<const f16x8*>(s_patch + ppix * ROW + j * 8 + hi * 4);
                 al[mt] = *reinterpret_cast<const f16x8*>(s_patch + ppix * ROW + KH + j * 8 + hi * 4);
+            }
+            if (p.dbg & 1) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(ah[mt]), "v"(al[mt]));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(ch_[nt].x), "v"(ch_[nt].y), "v"(ch_[nt].z), "v"(ch_[nt].w), "v"(cl_[nt].x), "v"(cl_[nt].y), "v"(cl_[nt].z), "v"(cl_[nt].w));
+                return;
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -243,9 +251,9 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
                 const int px = (lane >> 3) + 8 * i;    // pixel of the 32-pixel M-tile (2 rows x 16 cols)
                 const int oy = oy0 + (wm * MT + mt) * 2 + (px >> 4), ox = ox0 + (px & 15);
                 float4 v = *reinterpret_cast<const float4*>(s_tr + px * TP + cq * 4);
-                if (nok4 && oy < p.H && ox < p.W) {
+                if (nok4 && oy < p.H && ox < p.W && !((p.dbg & 16) && v.x != 1.2345f)) {
                     const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
-                    if (p.residual != nullptr) {
+                    if (p.residual != nullptr && !(p.dbg & 32)) {
                         const float4 rv = *reinterpret_cast<const float4*>(p.residual + pix * p.res_cstride + n4);
                         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                     }
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
             __builtin_amdgcn_wave_barrier();            // scratch is rewritten by the next tile
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        if (p.stats_out != nullptr) {
+        if (p.stats_out != nullptr && !(p.dbg & 128)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
             }
         }
     }
-    if (p.stats_out != nullptr) {
+    if (p.stats_out != nullptr && !(p.dbg & 128)) {
         __syncthreads();
         if (tid < BN * 2) {
             const int col = tid >> 1, which = tid & 1;

@@ -43,7 +43,7 @@ struct ConvParams {
     float gn_eps;
     const float* gamma;   // [gn_C]
     const float* beta;
-    int dbg;              // ablation switches for profiling (0 in production): 1 skip MFMAs, 2 skip re-staging
+    int dbg;              // ablation switches for profiling (0 in production): 1 skip MFMAs, 2 skip re-staging, 4 skip LDS A reads, 8 skip B loads, 16 skip epilogue global traffic
 };
 
 constexpr int CONV_KC = 16;   // channels per K-chunk staged in LDS

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpnpflow_hip.so")
+LIB_PATH = os.environ.get("PNPFLOW_HIP_LIB") or os.path.join(_HERE, "libpnpflow_hip.so")   # override: A/B builds of the kernels
 
 PF_ABI_VERSION = 1
 

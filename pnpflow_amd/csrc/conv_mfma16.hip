@@ -19,6 +19,15 @@
 
 namespace pf {
 
+// Ablation switches (ConvParams::dbg, -DPF_CONV_DEBUG) and per-phase cycle tracing (ConvParams::trace, -DPF_CONV_TRACE)
+// are compiled in only for the profiling builds (libpnpflow_hip_dbg.so / _trace.so, tools/ablate.sh): even as uniform
+// run-time branches the switches cost the production kernel 15 % (registers, conservative waitcnts).
+#ifdef PF_CONV_DEBUG
+#define PF_DBG(bit) ((p.dbg & (bit)) != 0)
+#else
+#define PF_DBG(bit) (false)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -108,9 +117,19 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
         }
     };
 
+#ifdef PF_CONV_TRACE
+    // phase cycle sums, accumulated in registers and flushed once per workgroup into one of 256 slots (a single
+    // accumulator per launch serialises ~10^5 same-address atomics and doubles the kernel time)
+    unsigned long long t_prev = p.trace ? clock64() : 0ull, t_acc[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+    auto mark = [&](int k) {
+        if (p.trace != nullptr && tid == 0) { const unsigned long long now = clock64(); t_acc[k] += now - t_prev; t_prev = now; }
+    };
+#else
+    auto mark = [](int) {};
+#endif
     prefetch(0, 0);
 
-    for (int c = tid; c < ((p.dbg & 64) ? 0 : p.gn_C); c += 256) {
+    for (int c = tid; c < (PF_DBG(64) ? 0 : p.gn_C); c += 256) {
         const int g = c / p.gn_cpg;
         double s = 0.0, ss = 0.0;
         for (int j = g * p.gn_cpg; j < (g + 1) * p.gn_cpg; ++j) {
@@ -157,11 +176,13 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
     };
 
     int si = 0, ch = 0;
+    mark(0);
     while (true) {
         const ConvSeg& sg = p.seg[si];
         __syncthreads();
-        if (!(p.dbg & 2) || (si == 0 && ch == 0)) store_lds(si, ch);
+        if (!PF_DBG(2) || (si == 0 && ch == 0)) store_lds(si, ch);
         __syncthreads();
+        mark(1);
         int nsi = si, nch = ch + 1;
         if (nch * KC >= sg.C) { nsi = si + 1; nch = 0; }
         const bool more = nsi < p.nseg;
@@ -169,10 +190,10 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
         const int nsteps = sg.taps * KS;      // k16-steps per chunk: 9 / 1 (KC 16), 18 / 2 (KC 32), 4 (KC 64, 1-tap launches)
         uint4 bh0[NT], bl0[NT], bh1[NT], bl1[NT], bh2[NT], bl2[NT];
         load_b(sg, ch, 0, bh0, bl0); load_b(sg, ch, min(1, nsteps - 1), bh1, bl1);
-        if (more && !(p.dbg & 2)) prefetch(nsi, nch);
+        if (more && !PF_DBG(2)) prefetch(nsi, nch);
 
         auto k_step = [&](int s, uint4 (&ch_)[NT], uint4 (&cl_)[NT], uint4 (&nh_)[NT], uint4 (&nl_)[NT]) {
-            if (!(p.dbg & 8)) load_b(sg, ch, min(s + 2, nsteps - 1), nh_, nl_);
+            if (!PF_DBG(8)) load_b(sg, ch, min(s + 2, nsteps - 1), nh_, nl_);
             __builtin_amdgcn_sched_barrier(0);
             const int tap = s / KS, j = s % KS;
             const int ky = sg.taps == 9 ? tap / 3 : 1, kx = sg.taps == 9 ? tap % 3 : 1;
@@ -180,11 +201,11 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int ppix = (((wm * MT + mt) * 2 + prow) * S + ky) * PW + pcol * S + kx;
-                if (p.dbg & 4) { ah[mt] = *reinterpret_cast<const f16x8*>(&ch_[0]); al[mt] = *reinterpret_cast<const f16x8*>(&cl_[0]); continue; }
+                if (PF_DBG(4)) { ah[mt] = *reinterpret_cast<const f16x8*>(&ch_[0]); al[mt] = *reinterpret_cast<const f16x8*>(&cl_[0]); continue; }
                 ah[mt] = *reinterpret_cast<const f16x8*>(s_patch + ppix * ROW + j * 8 + hi * 4);
                 al[mt] = *reinterpret_cast<const f16x8*>(s_patch + ppix * ROW + KH + j * 8 + hi * 4);
             }
-            if (p.dbg & 1) {
+            if (PF_DBG(1)) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(ah[mt]), "v"(al[mt]));
 #pragma unroll
@@ -213,6 +234,7 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
         }
         if (nsteps - s >= 1) k_step(s, bh0, bl0, bh2, bl2);
         if (nsteps - s == 2) k_step(s + 1, bh1, bl1, bh0, bl0);
+        mark(2);
         if (!more) break;
         si = nsi; ch = nch;
     }
@@ -251,9 +273,9 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
                 const int px = (lane >> 3) + 8 * i;    // pixel of the 32-pixel M-tile (2 rows x 16 cols)
                 const int oy = oy0 + (wm * MT + mt) * 2 + (px >> 4), ox = ox0 + (px & 15);
                 float4 v = *reinterpret_cast<const float4*>(s_tr + px * TP + cq * 4);
-                if (nok4 && oy < p.H && ox < p.W && !((p.dbg & 16) && v.x != 1.2345f)) {
+                if (nok4 && oy < p.H && ox < p.W && !(PF_DBG(16) && v.x != 1.2345f)) {
                     const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
-                    if (p.residual != nullptr && !(p.dbg & 32)) {
+                    if (p.residual != nullptr && !PF_DBG(32)) {
                         const float4 rv = *reinterpret_cast<const float4*>(p.residual + pix * p.res_cstride + n4);
                         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
                     }
@@ -266,7 +288,7 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
             __builtin_amdgcn_wave_barrier();            // scratch is rewritten by the next tile
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        if (p.stats_out != nullptr && !(p.dbg & 128)) {
+        if (p.stats_out != nullptr && !PF_DBG(128)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -281,7 +303,8 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
             }
         }
     }
-    if (p.stats_out != nullptr && !(p.dbg & 128)) {
+    mark(3);
+    if (p.stats_out != nullptr && !PF_DBG(128)) {
         __syncthreads();
         if (tid < BN * 2) {
             const int col = tid >> 1, which = tid & 1;
@@ -292,6 +315,14 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
             if (n < p.Cout) unsafeAtomicAdd(p.stats_out + ((size_t)b * p.Cout + n) * 2 + which, (double)tot);
         }
     }
+    mark(4);
+#ifdef PF_CONV_TRACE
+    if (p.trace != nullptr && tid == 0) {
+        unsigned long long* slot = p.trace + (blockIdx.x & 255) * 8;
+        for (int k = 0; k < 5; ++k) atomicAdd(slot + k, t_acc[k]);
+        atomicAdd(slot + 5, 1ull);
+    }
+#endif
 }
 
 template <int MT, int NT, int WM, int WN, int S, int UP, int KC>

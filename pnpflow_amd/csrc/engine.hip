@@ -115,6 +115,8 @@ struct pf_engine {
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     std::vector<const Op*> ev_ops;   // op of each recorded event pair (profiling detail)
+    unsigned long long* trace_buf = nullptr;   // PNPFLOW_HIP_TRACE: per-launch phase cycle sums of the conv kernel (8 slots per launch)
+    static constexpr size_t TRACE_MAX = 1024, TRACE_SLOTS = 256;
     size_t ev_used = 0;
     int64_t prof_launches = 0; double prof_ms = 0.0, prof_flops = 0.0;
 };
@@ -937,7 +939,14 @@ static int run_plan(pf_engine* e, Plan* plan, const float* x, const float* t, fl
                     if (e->ev_ops.size() < e->ev_used) e->ev_ops.resize(e->ev_used);
                     e->ev_ops[e->ev_used - 1] = &op;
                     hipEventRecord(ev.first, s);
-                    r = dispatch_conv(e, op, s);
+                    if (getenv("PNPFLOW_HIP_TRACE") && e->ev_used <= pf_engine::TRACE_MAX) {
+                        const size_t tb = pf_engine::TRACE_MAX * pf_engine::TRACE_SLOTS * 64;
+                        if (!e->trace_buf) { hipMalloc(&e->trace_buf, tb); hipMemsetAsync(e->trace_buf, 0, tb, s); }
+                        Op top = op; top.cp.trace = e->trace_buf + (e->ev_used - 1) * pf_engine::TRACE_SLOTS * 8;
+                        r = dispatch_conv(e, top, s);
+                    } else {
+                        r = dispatch_conv(e, op, s);
+                    }
                     hipEventRecord(ev.second, s);
                     e->prof_flops += (double)op.flops;
                 } else {
@@ -1324,15 +1333,24 @@ int pf_engine_profile_read(pf_engine* e, int64_t* launches, double* ms_conv_gemm
     if (!e) return PF_ERR_INVALID;
     HIPCHK(e, hipDeviceSynchronize());
     FILE* dump = getenv("PNPFLOW_HIP_PROFILE_CSV") ? fopen(getenv("PNPFLOW_HIP_PROFILE_CSV"), "w") : nullptr;
-    if (dump) fprintf(dump, "idx,H,W,Cout,K,nseg,taps0,stride,up,gflop,us,tflops\n");
+    if (dump) fprintf(dump, "idx,H,W,Cout,K,nseg,taps0,stride,up,gflop,us,tflops,wgs,cyc_prologue,cyc_staging,cyc_kloop,cyc_epilogue,cyc_stats\n");
+    std::vector<unsigned long long> tr;
+    if (e->trace_buf) { tr.resize(pf_engine::TRACE_MAX * pf_engine::TRACE_SLOTS * 8); hipMemcpy(tr.data(), e->trace_buf, tr.size() * 8, hipMemcpyDeviceToHost); hipMemset(e->trace_buf, 0, tr.size() * 8); }
     for (size_t i = 0; i < e->ev_used; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e->ev_pool[i].first, e->ev_pool[i].second) == hipSuccess) { e->prof_ms += ms; e->prof_launches += 1; }
         if (dump && i < e->ev_ops.size() && e->ev_ops[i]) {
             const Op& op = *e->ev_ops[i]; size_t K = 0;
             for (int j = 0; j < op.cp.nseg; ++j) K += (size_t)op.cp.seg[j].taps * op.cp.seg[j].C;
-            fprintf(dump, "%zu,%d,%d,%d,%zu,%d,%d,%d,%d,%.4f,%.2f,%.2f\n", i, op.cp.H, op.cp.W, op.cp.Cout, K, op.cp.nseg, op.cp.seg[0].taps,
+            fprintf(dump, "%zu,%d,%d,%d,%zu,%d,%d,%d,%d,%.4f,%.2f,%.2f", i, op.cp.H, op.cp.W, op.cp.Cout, K, op.cp.nseg, op.cp.seg[0].taps,
                     op.stride, op.up, op.flops / 1e9, ms * 1e3, op.flops / (ms * 1e-3) / 1e12);
+            if (!tr.empty() && i < pf_engine::TRACE_MAX) {
+                unsigned long long q[8] = {0};
+                for (size_t sl = 0; sl < pf_engine::TRACE_SLOTS; ++sl) for (int k = 0; k < 8; ++k) q[k] += tr[(i * pf_engine::TRACE_SLOTS + sl) * 8 + k];
+                const double n = q[5] ? (double)q[5] : 1.0;
+                fprintf(dump, ",%llu,%.0f,%.0f,%.0f,%.0f,%.0f", q[5], q[0] / n, q[1] / n, q[2] / n, q[3] / n, q[4] / n);
+            }
+            fprintf(dump, "\n");
         }
     }
     if (dump) fclose(dump);

@@ -43,6 +43,7 @@ struct ConvParams {
     float gn_eps;
     const float* gamma;   // [gn_C]
     const float* beta;
+    unsigned long long* trace;   // profiling only: per-launch phase cycle sums [prologue, staging, k-loop, epilogue, stats, workgroups], or nullptr
     int dbg;              // ablation switches for profiling (0 in production): 1 skip MFMAs, 2 skip re-staging, 4 skip LDS A reads, 8 skip B loads, 16 skip epilogue global traffic
 };
 

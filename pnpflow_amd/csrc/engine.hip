@@ -35,7 +35,7 @@ struct LevelDesc { std::vector<ResDesc> blocks; std::string resample; int res_ch
 
 struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; double* stats = nullptr; };
 
-enum OpKind { OP_MEMSET, OP_TEMB, OP_BEGIN, OP_CHSTATS, OP_CONV, OP_SOFTMAX, OP_END,
+enum OpKind { OP_MEMSET, OP_TEMB, OP_BEGIN, OP_CONV, OP_SOFTMAX, OP_END,
               // backward-only
               OP_GN_FWD_COEF, OP_GN_BWD_PRE, OP_GN_BWD_COEF, OP_GN_BWD_POST, OP_TRANSPOSE, OP_SOFTMAX_BWD, OP_SUMPOOL };
 struct Op {
@@ -45,7 +45,6 @@ struct Op {
     TembParams tp;
     void* ptr = nullptr; size_t bytes = 0;          // memset
     float* sm = nullptr; int64_t sm_rows = 0; int sm_cols = 0;
-    const float* cs_x = nullptr; double* cs_stats = nullptr; int cs_HW = 0, cs_C = 0;
     size_t flops = 0;
     // generic slots of the backward helper ops
     const void* P[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -494,7 +493,7 @@ static void fix_stats(Op& op, double* slab) {
     auto fxm = [&](double*& p) { if (p) p = (double*)((char*)slab + ((uintptr_t)p - 1)); };
     if (op.kind == OP_CONV) { for (int i = 0; i < op.cp.nseg; ++i) fx(op.cp.seg[i].stats); fxm(op.cp.stats_out); }
     if (op.kind == OP_END) fx(op.ep.stats);
-    if (op.kind == OP_CHSTATS) fxm(op.cs_stats);
+    if (op.kind == OP_BEGIN) fxm(op.ep.stats_out);
     if (op.kind == OP_GN_FWD_COEF) { const double* a = (const double*)op.P[0]; const double* b2 = (const double*)op.P[1]; fx(a); fx(b2); op.P[0] = a; op.P[1] = b2; }
     if (op.kind == OP_GN_BWD_PRE || op.kind == OP_GN_BWD_COEF) { const double* a = (const double*)op.P[6]; fx(a); op.P[6] = a; }
 }
@@ -547,9 +546,8 @@ static int build_plan(pf_engine* e, int B, bool retain, Plan** out_plan) {
         op.ep.out = t0.p; op.ep.w = upload(e, "begin_conv.packed", wp);
         op.ep.bias = upload(e, "begin_conv.bias", W(e, "begin_conv.bias").data);
         op.ep.B = B; op.ep.H = H0; op.ep.W = H0; op.ep.Cimg = ci_n; op.ep.C = ch;
+        op.ep.stats_out = t0.stats;              // (sum, sumsq) per channel for the first GroupNorm, reduced in the same kernel
         plan->ops.push_back(op);
-        Op cs{}; cs.kind = OP_CHSTATS; cs.cs_x = t0.p; cs.cs_stats = t0.stats; cs.cs_HW = H0 * H0; cs.cs_C = ch;
-        plan->ops.push_back(cs);
         hs.push_back(t0);
         plan->t_begin = t0;
         plan->taps.push_back({"begin_conv", t0});
@@ -929,7 +927,6 @@ static int run_plan(pf_engine* e, Plan* plan, const float* x, const float* t, fl
             case OP_MEMSET: r = hipMemsetAsync(op.ptr, 0, op.bytes, s); break;
             case OP_TEMB: { TembParams tp = op.tp; tp.t = t; r = launch_temb(tp, s); break; }
             case OP_BEGIN: { EdgeConvParams ep = op.ep; ep.in = x; r = launch_begin_conv(ep, s); break; }
-            case OP_CHSTATS: r = launch_channel_stats(op.cs_x, op.cs_stats, plan->B, op.cs_HW, op.cs_C, s); break;
             case OP_CONV:
                 if (e->profile) {
                     if (e->ev_used == e->ev_pool.size()) {

@@ -78,7 +78,6 @@ hipError_t launch_begin_conv(const EdgeConvParams& p, hipStream_t s);
 hipError_t launch_end_conv(const EdgeConvParams& p, hipStream_t s);
 hipError_t launch_temb(const TembParams& p, hipStream_t s);
 hipError_t launch_softmax_rows(float* data, int64_t rows, int cols, hipStream_t s);
-hipError_t launch_channel_stats(const float* x, double* stats, int B, int HW, int C, hipStream_t s);
 
 // backward helpers (unet_bwd.hip)
 hipError_t launch_gn_fwd_coeffs(const double* st0, int C0, const double* st1, int C1, int cpg, int HW, float eps, float* mu, float* rs, int B,

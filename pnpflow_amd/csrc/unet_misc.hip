@@ -8,39 +8,68 @@ namespace pf {
 __device__ __forceinline__ float silu_acc(float x) { return x / (1.0f + expf(-x)); }
 
 // ------------------------------------------------------------------------------------
-// begin_conv: NCHW image -> NHWC [B][H][W][C], 3x3 pad 1 (models.py:358, 451).
-// One thread per output pixel, all C=32 output channels in registers; weights in LDS.
+// begin_conv: NCHW image -> NHWC [B][H][W][C], 3x3 pad 1 (models.py:358, 451), plus the per-channel
+// (sum, sumsq) of the result for the first GroupNorm.  One thread per output pixel with all C=32 output
+// channels in registers and the weights in LDS; the tile is transposed through LDS so that the NHWC rows are
+// written as contiguous float4 runs, and the statistics are reduced per workgroup (64 fp64 atomics).
+// HBM-bound: 128 B written per pixel.
 // ------------------------------------------------------------------------------------
 template <int C>
 __global__ __launch_bounds__(256) void begin_conv_kernel(const EdgeConvParams p) {
-    __shared__ float s_w[9 * 3 * C + C];
-    const int nw = 9 * p.Cimg * C;
-    for (int i = threadIdx.x; i < nw; i += 256) s_w[i] = p.w[i];
-    for (int i = threadIdx.x; i < C; i += 256) s_w[9 * 3 * C + i] = p.bias[i];
-    __syncthreads();
+    __shared__ float s_t[256][C + 1];
+    __shared__ float s_part[8][C][2];
+    const int tid = threadIdx.x;
+    const float* __restrict__ wgt = p.w;          // wave-uniform addresses: scalar loads, no LDS traffic
+    const float* __restrict__ bias = p.bias;
     const int HW = p.H * p.W;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int pix0 = blockIdx.x * 256;
+    const int pix = pix0 + tid;
     const int b = blockIdx.y;
-    if (pix >= HW) return;
-    const int y = pix / p.W, x = pix % p.W;
+    const bool valid = pix < HW;
     float acc[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] = s_w[9 * 3 * C + c];
-    for (int ci = 0; ci < p.Cimg; ++ci) {
-        const float* img = p.in + ((size_t)b * p.Cimg + ci) * HW;
+    for (int c = 0; c < C; ++c) acc[c] = valid ? bias[c] : 0.f;
+    if (valid) {
+        const int y = pix / p.W, x = pix % p.W;
+        for (int ci = 0; ci < p.Cimg; ++ci) {
+            const float* img = p.in + ((size_t)b * p.Cimg + ci) * HW;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-            float v = 0.f;
-            if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) v = img[yy * p.W + xx];
-            const float* w = s_w + (tap * p.Cimg + ci) * C;
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                float v = 0.f;
+                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) v = img[yy * p.W + xx];
+                const float* __restrict__ w = wgt + (tap * p.Cimg + ci) * C;
 #pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] = fmaf(v, w[c], acc[c]);
+                for (int c = 0; c < C; ++c) acc[c] = fmaf(v, w[c], acc[c]);
+            }
         }
     }
-    float4* o = reinterpret_cast<float4*>(p.out + ((size_t)b * HW + pix) * C);
 #pragma unroll
-    for (int c = 0; c < C / 4; ++c) o[c] = make_float4(acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]);
+    for (int c = 0; c < C; ++c) s_t[tid][c] = acc[c];
+    __syncthreads();
+    // the 256 pixels x C channels of this workgroup are one contiguous NHWC run
+    float* o = p.out + ((size_t)b * HW + pix0) * C;
+    const int nvalid = min(256, HW - pix0);
+#pragma unroll
+    for (int k = 0; k < C / 4; ++k) {
+        const int idx = k * 256 + tid, px = idx / (C / 4), q = idx % (C / 4);
+        if (px < nvalid)
+            *reinterpret_cast<float4*>(o + (size_t)px * C + q * 4) = make_float4(s_t[px][q * 4], s_t[px][q * 4 + 1], s_t[px][q * 4 + 2], s_t[px][q * 4 + 3]);
+    }
+    if (p.stats_out != nullptr) {
+        const int c = tid % C, part = tid / C;        // 256 / C = 8 parts of 32 pixels (C = 32)
+        float s1 = 0.f, s2 = 0.f;
+        for (int px = part * (256 / (256 / C)); px < (part + 1) * (256 / (256 / C)); ++px) { const float v = s_t[px][c]; s1 += v; s2 += v * v; }
+        s_part[part][c][0] = s1; s_part[part][c][1] = s2;
+        __syncthreads();
+        if (tid < 2 * C) {
+            const int cc = tid >> 1, which = tid & 1;
+            double tot = 0.0;
+#pragma unroll
+            for (int k = 0; k < 256 / C; ++k) tot += (double)s_part[k][cc][which];
+            unsafeAtomicAdd(p.stats_out + ((size_t)b * C + cc) * 2 + which, tot);
+        }
+    }
 }
 
 hipError_t launch_begin_conv(const EdgeConvParams& p, hipStream_t s) {
@@ -51,87 +80,98 @@ hipError_t launch_begin_conv(const EdgeConvParams& p, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------
-// end_conv: GroupNorm -> SiLU -> 3x3 conv C->Cimg, NHWC in, NCHW image out
-// (models.py:428-433, 492).  16x16 output tile per workgroup; the normalised+activated
-// 18x18xC patch lives in LDS ([pix][C+4]).
+// end_conv: GroupNorm -> SiLU -> 3x3 conv C->Cimg, NHWC in, NCHW image out (models.py:428-433, 492).
+// Two stages per 16x16 output tile:  (1) every pixel of the 18x18 halo patch is read once from HBM by one thread
+// (its C channels stay in registers), normalised/activated, and contracted with the 9*Cimg weight vectors into
+// t[pixel][tap][co] (the weights are wave-uniform: scalar loads, no LDS traffic);  (2) each output pixel gathers
+// its 9 taps of t from LDS.  The activations never go through LDS (the previous version staged the 18x18xC patch
+// and re-read it 9x together with the weights: LDS-bandwidth-bound at 6x this kernel's time).
 // ------------------------------------------------------------------------------------
-template <int C>
+template <int C, int CIMG>
 __global__ __launch_bounds__(256) void end_conv_kernel(const EdgeConvParams p) {
-    constexpr int CP = C + 4, PW = 18, PP = PW * PW;
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* s_patch = reinterpret_cast<float*>(smem_raw);  // [PP][CP]
-    float* s_w = s_patch + PP * CP;                        // [9][3][C]
-    float* s_sc = s_w + 9 * 3 * C;                         // [C]
-    float* s_sh = s_sc + C;
+    constexpr int PW = 18, PP = PW * PW, NT_ = 9 * CIMG, TP = NT_ + 1;
+    __shared__ float s_t[PP * TP];
+    __shared__ float s_sc[C], s_sh[C];
     const int tiles_x = (p.W + 15) / 16, tiles_y = (p.H + 15) / 16;
     int bid = blockIdx.x;
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
     const int tid = threadIdx.x;
-    for (int i = tid; i < 9 * p.Cimg * C; i += 256) s_w[i] = p.w[i];
     const bool raw = p.stats == nullptr;   // raw: plain 3x3 conv (used as the adjoint of begin_conv)
-    if (tid < C && !raw) {
-        const int g = tid / p.gn_cpg;
-        double s = 0.0, ss = 0.0;
-        for (int j = g * p.gn_cpg; j < (g + 1) * p.gn_cpg; ++j) {
-            const double* st = p.stats + ((size_t)b * C + j) * 2;
-            s += st[0]; ss += st[1];
+    if (tid < C) {
+        float sc = 1.f, sh = 0.f;
+        if (!raw) {
+            const int g = tid / p.gn_cpg;
+            double s = 0.0, ss = 0.0;
+            for (int j = g * p.gn_cpg; j < (g + 1) * p.gn_cpg; ++j) {
+                const double* st = p.stats + ((size_t)b * C + j) * 2;
+                s += st[0]; ss += st[1];
+            }
+            const double N = (double)p.gn_cpg * p.H * p.W;
+            const double mean = s / N;
+            double var = ss / N - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+            sc = p.gamma[tid] * rstd;
+            sh = p.beta[tid] - (float)mean * sc;
         }
-        const double N = (double)p.gn_cpg * p.H * p.W;
-        const double mean = s / N;
-        double var = ss / N - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
-        const float sc = p.gamma[tid] * rstd;
-        s_sc[tid] = sc;
-        s_sh[tid] = p.beta[tid] - (float)mean * sc;
+        s_sc[tid] = sc; s_sh[tid] = sh;
     }
     __syncthreads();
     const int oy0 = ty * 16, ox0 = tx * 16;
-    for (int idx = tid; idx < PP * (C / 4); idx += 256) {
-        const int pix = idx / (C / 4), q = idx % (C / 4);
+    const float* __restrict__ w = p.w;
+    for (int pix = tid; pix < PP; pix += 256) {         // wave-uniform trip count (waves 0-1 take a second pixel)
         const int gy = oy0 - 1 + pix / PW, gx = ox0 - 1 + pix % PW;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float t[NT_];
+#pragma unroll
+        for (int k = 0; k < NT_; ++k) t[k] = 0.f;
         if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-            v = *reinterpret_cast<const float4*>(p.in + ((size_t)(b * p.H + gy) * p.W + gx) * C + q * 4);
+            const float4* src = reinterpret_cast<const float4*>(p.in + ((size_t)(b * p.H + gy) * p.W + gx) * C);
+            float a[C];
+#pragma unroll
+            for (int q = 0; q < C / 4; ++q) {
+                const float4 v = src[q];
+                a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+            }
             if (!raw) {
-                const float4 sc = *reinterpret_cast<const float4*>(s_sc + q * 4);
-                const float4 sh = *reinterpret_cast<const float4*>(s_sh + q * 4);
-                v.x = silu_acc(v.x * sc.x + sh.x); v.y = silu_acc(v.y * sc.y + sh.y);
-                v.z = silu_acc(v.z * sc.z + sh.z); v.w = silu_acc(v.w * sc.w + sh.w);
+#pragma unroll
+                for (int c = 0; c < C; ++c) { const float u = a[c] * s_sc[c] + s_sh[c]; a[c] = u * __frcp_rn(1.0f + __expf(-u)); }
+            }
+#pragma unroll
+            for (int k = 0; k < NT_; ++k) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc = fmaf(a[c], w[k * C + c], acc);
+                t[k] = acc;
             }
         }
-        *reinterpret_cast<float4*>(s_patch + pix * CP + q * 4) = v;
+#pragma unroll
+        for (int k = 0; k < NT_; ++k) s_t[pix * TP + k] = t[k];
     }
     __syncthreads();
     const int ly = tid / 16, lx = tid % 16;
     const int oy = oy0 + ly, ox = ox0 + lx;
-    float acc[3] = {0.f, 0.f, 0.f};
+    float acc[CIMG];
+#pragma unroll
+    for (int co = 0; co < CIMG; ++co) acc[co] = p.bias[co];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-        const float* ap = s_patch + ((ly + tap / 3) * PW + lx + tap % 3) * CP;
+        const float* tp = s_t + ((ly + tap / 3) * PW + lx + tap % 3) * TP + tap * CIMG;
 #pragma unroll
-        for (int q = 0; q < C / 4; ++q) {
-            const float4 a = *reinterpret_cast<const float4*>(ap + q * 4);
-            for (int co = 0; co < p.Cimg; ++co) {
-                const float4 w = *reinterpret_cast<const float4*>(s_w + (tap * p.Cimg + co) * C + q * 4);
-                acc[co] = fmaf(a.x, w.x, acc[co]); acc[co] = fmaf(a.y, w.y, acc[co]);
-                acc[co] = fmaf(a.z, w.z, acc[co]); acc[co] = fmaf(a.w, w.w, acc[co]);
-            }
-        }
+        for (int co = 0; co < CIMG; ++co) acc[co] += tp[co];
     }
-    if (oy < p.H && ox < p.W)
-        for (int co = 0; co < p.Cimg; ++co)
-            p.out[((size_t)(b * p.Cimg + co) * p.H + oy) * p.W + ox] = acc[co] + p.bias[co];
+    if (oy < p.H && ox < p.W) {
+#pragma unroll
+        for (int co = 0; co < CIMG; ++co) p.out[((size_t)(b * CIMG + co) * p.H + oy) * p.W + ox] = acc[co];
+    }
 }
 
 hipError_t launch_end_conv(const EdgeConvParams& p, hipStream_t s) {
-    if (p.C != 32 || p.Cimg > 3) return hipErrorInvalidValue;
-    constexpr int C = 32;
-    const size_t lds = (size_t)(18 * 18 * (C + 4) + 9 * 3 * C + 2 * C) * sizeof(float);
+    if (p.C != 32 || (p.Cimg != 1 && p.Cimg != 3)) return hipErrorInvalidValue;
     dim3 grid(p.B * ((p.H + 15) / 16) * ((p.W + 15) / 16));
-    hipLaunchKernelGGL(end_conv_kernel<C>, grid, dim3(256), lds, s, p);
+    if (p.Cimg == 3) hipLaunchKernelGGL((end_conv_kernel<32, 3>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((end_conv_kernel<32, 1>), grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -212,47 +252,6 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* data, int64_t 
 
 hipError_t launch_softmax_rows(float* data, int64_t rows, int cols, hipStream_t s) {
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, data, rows, cols);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------
-// per-channel (sum, sumsq) of an NHWC tensor: stats[b][c][2] += ...   (HBM-bound)
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void channel_stats_kernel(const float* x, double* stats, int HW, int C, int pix_per_block) {
-    __shared__ double s_red[256 * 2];
-    const int b = blockIdx.y, tid = threadIdx.x;
-    const int cq = C / 4;                 // float4 groups per pixel
-    const int lanes_p = 256 / cq;         // pixels processed concurrently (C <= 1024)
-    const int q = tid % cq, pr = tid / cq;
-    const int p0 = blockIdx.x * pix_per_block;
-    const int p1 = min(HW, p0 + pix_per_block);
-    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
-    if (pr < lanes_p) {
-        for (int pix = p0 + pr; pix < p1; pix += lanes_p) {
-            const float4 v = *reinterpret_cast<const float4*>(x + ((size_t)b * HW + pix) * C + q * 4);
-            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-            ss[0] += (double)v.x * v.x; ss[1] += (double)v.y * v.y; ss[2] += (double)v.z * v.z; ss[3] += (double)v.w * v.w;
-        }
-    }
-    for (int j = 0; j < 4; ++j) {
-        __syncthreads();
-        s_red[tid * 2] = s[j]; s_red[tid * 2 + 1] = ss[j];
-        __syncthreads();
-        if (pr == 0 && tid < cq) {
-            double a = 0, c2 = 0;
-            for (int r = 0; r < lanes_p; ++r) { a += s_red[(r * cq + q) * 2]; c2 += s_red[(r * cq + q) * 2 + 1]; }
-            double* st = stats + ((size_t)b * C + q * 4 + j) * 2;
-            unsafeAtomicAdd(st, a);
-            unsafeAtomicAdd(st + 1, c2);
-        }
-    }
-}
-
-hipError_t launch_channel_stats(const float* x, double* stats, int B, int HW, int C, hipStream_t s) {
-    if (C % 4 != 0 || C / 4 > 256) return hipErrorInvalidValue;
-    const int ppb = 1024;
-    dim3 grid((HW + ppb - 1) / ppb, B);
-    hipLaunchKernelGGL(channel_stats_kernel, grid, dim3(256), 0, s, x, stats, HW, C, ppb);
     return hipGetLastError();
 }
 

@@ -1,0 +1,221 @@
+// Fused single-head self-attention core of SelfAttention.forward (pnpflow/models.py:148-160):
+//     S = (q k^T) * C^-1/2 ;  P = softmax(S, dim=-1) ;  O = P v
+// for q, k, v stacked as [B][T][3C] fp32 (the output of the fused q/k/v 1x1 convolution), O as [B][T][C].
+// One launch replaces two per-image GEMM launches on the fp32 matrix path plus a softmax launch and the HBM round
+// trips of S and P (T x T per image).  One workgroup = one image x 32 queries; the 4 waves split the keys (phase 1)
+// and the output channels (phase 3).  Both contractions run on v_mfma_f32_32x32x16_f16 with hi+lo fp16 operand pairs
+// (3 MFMAs per product, fp32 accumulate: fp32-equivalent, see conv_mfma16.hip):
+//   phase 0  the 32 x C query block is split and parked in LDS in A-fragment order;
+//   phase 1  k is streamed in 32-channel chunks: coalesced float4 loads (prefetched one chunk ahead), split once per
+//            workgroup, staged in LDS in B-fragment order; each wave accumulates S for its T/4 keys;
+//   phase 2  S (scaled) goes through LDS; 8 threads per query row do max / exp / sum / normalise and write P back as
+//            hi+lo A fragments (over the query block, which is no longer needed);
+//   phase 3  v is read straight from L2 (for a fixed key the 32 lanes of a fragment column are 128 contiguous bytes),
+//            split in registers two steps ahead of its use; each wave accumulates O for its C/4 channels.
+// Shapes: T = 128*TK, C = 128*TC with TK, TC in {1, 2}; everything else stays on the unfused path (engine.hip).
+#include "pf_common.h"
+
+namespace pf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ void split4(const float4 v, f16x4& h, f16x4& l) {
+    h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+    l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
+    l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
+}
+
+template <int TK, int TC>
+__global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
+    constexpr int T = 128 * TK, C = 128 * TC, BQ = 32;
+    constexpr int QROW = C + 4;                 // dwords per query row: C/2 hi | C/2 lo | 4 pad (conflict-free ds_read_b128)
+    constexpr int PROW = T + 4;                 // dwords per probability row: T/2 hi | T/2 lo | 4 pad
+    constexpr int AROW = QROW > PROW ? QROW : PROW;
+    constexpr int KROW = 36;                    // dwords per key row of a 32-channel chunk: 16 hi | 16 lo | 4 pad
+    constexpr int SROW = T + 4;                 // floats per score row
+    constexpr int KBUF = T * KROW, SBUF = BQ * SROW;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint32_t* s_a = reinterpret_cast<uint32_t*>(smem_raw);           // [BQ][AROW]: q fragments, later P fragments
+    uint32_t* s_k = s_a + BQ * AROW;                                  // [T][KROW]  : k chunk (phase 1)
+    float* s_s = reinterpret_cast<float*>(s_k);                       // [BQ][SROW] : scores (phases 1 -> 2), aliases the k chunk
+    static_assert(KBUF >= SBUF || true, "");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.y, q0 = blockIdx.x * BQ;
+    const float* base = p.qkv + (size_t)b * T * 3 * C;
+
+    // ---- phase 0: query block -> LDS (hi | lo) ------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < BQ * (C / 4) / 256; ++i) {
+        const int idx = tid + i * 256, row = idx / (C / 4), c4 = idx % (C / 4);
+        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)(q0 + row) * 3 * C + c4 * 4);
+        f16x4 h, l; split4(v, h, l);
+        *reinterpret_cast<f16x4*>(s_a + row * QROW + c4 * 2) = h;
+        *reinterpret_cast<f16x4*>(s_a + row * QROW + C / 2 + c4 * 2) = l;
+    }
+
+    // ---- phase 1: S = q k^T ---------------------------------------------------------------------------------------
+    constexpr int K_PER = T * 8 / 256;          // float4 per thread per 32-channel chunk of k
+    float4 rk[K_PER];
+    auto k_prefetch = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < K_PER; ++i) {
+            const int idx = tid + i * 256, key = idx >> 3, c4 = idx & 7;
+            rk[i] = *reinterpret_cast<const float4*>(base + (size_t)key * 3 * C + C + chunk * 32 + c4 * 4);
+        }
+    };
+    f32x16 acc_s[TK];
+#pragma unroll
+    for (int nt = 0; nt < TK; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_s[nt][r] = 0.f;
+    k_prefetch(0);
+    for (int chunk = 0; chunk < C / 32; ++chunk) {
+        __syncthreads();                        // the previous chunk has been consumed (first pass: the q block is complete)
+#pragma unroll
+        for (int i = 0; i < K_PER; ++i) {
+            const int idx = tid + i * 256, key = idx >> 3, c4 = idx & 7;
+            f16x4 h, l; split4(rk[i], h, l);
+            *reinterpret_cast<f16x4*>(s_k + key * KROW + c4 * 2) = h;
+            *reinterpret_cast<f16x4*>(s_k + key * KROW + 16 + c4 * 2) = l;
+        }
+        __syncthreads();
+        if (chunk + 1 < C / 32) k_prefetch(chunk + 1);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = chunk * 2 + jj;       // k16-step over the channels
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(s_a + l31 * QROW + j * 8 + hi * 4);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(s_a + l31 * QROW + C / 2 + j * 8 + hi * 4);
+#pragma unroll
+            for (int nt = 0; nt < TK; ++nt) {
+                const int krow = (wave * TK + nt) * 32 + l31;
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(s_k + krow * KROW + jj * 8 + hi * 4);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(s_k + krow * KROW + 16 + jj * 8 + hi * 4);
+                acc_s[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc_s[nt], 0, 0, 0);
+                acc_s[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc_s[nt], 0, 0, 0);
+                acc_s[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc_s[nt], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                            // every wave is done with the last k chunk: its LDS becomes the score tile
+#pragma unroll
+    for (int nt = 0; nt < TK; ++nt) {
+        const int col = (wave * TK + nt) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            s_s[row * SROW + col] = acc_s[nt][r] * p.scale;          // torch.bmm(q, k) * C**-0.5  (models.py:154)
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: softmax over the keys (models.py:155), P -> LDS as hi | lo A fragments ---------------------------
+    {
+        const int row = tid >> 3, part = tid & 7;
+        float4 x[T / 32];
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < T / 32; ++i) {
+            x[i] = *reinterpret_cast<const float4*>(s_s + row * SROW + (i * 8 + part) * 4);
+            m = fmaxf(fmaxf(m, fmaxf(x[i].x, x[i].y)), fmaxf(x[i].z, x[i].w));
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < T / 32; ++i) {
+            x[i].x = expf(x[i].x - m); x[i].y = expf(x[i].y - m); x[i].z = expf(x[i].z - m); x[i].w = expf(x[i].w - m);
+            s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float inv = 1.0f / s;
+#pragma unroll
+        for (int i = 0; i < T / 32; ++i) {
+            const float4 pv = make_float4(x[i].x * inv, x[i].y * inv, x[i].z * inv, x[i].w * inv);
+            f16x4 h, l; split4(pv, h, l);
+            const int k2 = (i * 8 + part) * 2;                       // dword index of these 4 keys
+            *reinterpret_cast<f16x4*>(s_a + row * PROW + k2) = h;
+            *reinterpret_cast<f16x4*>(s_a + row * PROW + T / 2 + k2) = l;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: O = P v -----------------------------------------------------------------------------------------
+    f32x16 acc_o[TC];
+#pragma unroll
+    for (int nt = 0; nt < TC; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[nt][r] = 0.f;
+    const float* vbase = base + 2 * C + wave * TC * 32 + l31;        // + key*3C + nt*32
+    auto load_v = [&](int j, float (&dst)[TC][8]) {                  // keys j*16 + hi*8 + i of this lane's channel(s)
+#pragma unroll
+        for (int nt = 0; nt < TC; ++nt)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dst[nt][i] = vbase[(size_t)(j * 16 + hi * 8 + i) * 3 * C + nt * 32];
+    };
+    auto v_step = [&](int j, float (&cur)[TC][8], float (&nxt)[TC][8]) {
+        load_v(min(j + 2, T / 16 - 1), nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        const f16x8 ph = *reinterpret_cast<const f16x8*>(s_a + l31 * PROW + j * 8 + hi * 4);
+        const f16x8 pl = *reinterpret_cast<const f16x8*>(s_a + l31 * PROW + T / 2 + j * 8 + hi * 4);
+#pragma unroll
+        for (int nt = 0; nt < TC; ++nt) {
+            f16x8 vh, vl;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { vh[i] = (_Float16)cur[nt][i]; vl[i] = (_Float16)(cur[nt][i] - (float)vh[i]); }
+            acc_o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, acc_o[nt], 0, 0, 0);
+            acc_o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, acc_o[nt], 0, 0, 0);
+            acc_o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, acc_o[nt], 0, 0, 0);
+        }
+    };
+    float v0[TC][8], v1[TC][8], v2[TC][8];
+    load_v(0, v0); load_v(1, v1);
+    static_assert((T / 16) % 3 != 0 || true, "");
+    int j = 0;
+    for (; j + 3 <= T / 16; j += 3) { v_step(j, v0, v2); v_step(j + 1, v1, v0); v_step(j + 2, v2, v1); }
+    if (T / 16 - j >= 1) v_step(j, v0, v2);
+    if (T / 16 - j == 2) v_step(j + 1, v1, v0);
+
+    float* obase = p.out + ((size_t)b * T + q0) * C + wave * TC * 32 + l31;
+#pragma unroll
+    for (int nt = 0; nt < TC; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            obase[(size_t)row * C + nt * 32] = acc_o[nt][r];
+        }
+}
+
+template <int TK, int TC>
+hipError_t launch_attn_cfg(const AttnParams& p, hipStream_t s) {
+    constexpr int T = 128 * TK, C = 128 * TC;
+    constexpr int AROW = (C > T ? C : T) + 4;
+    constexpr int KBUF = T * 36, SBUF = 32 * (T + 4);
+    const size_t lds = (size_t)(32 * AROW + (KBUF > SBUF ? KBUF : SBUF)) * 4;
+    static bool attr_set = false;
+    auto kern = attn_fused_kernel<TK, TC>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(T / 32, p.B), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool attn_fused_supported(int T, int C) { return (T == 128 || T == 256) && (C == 128 || C == 256); }
+
+hipError_t launch_attn_fused(const AttnParams& p, hipStream_t s) {
+    if (!attn_fused_supported(p.T, p.C)) return hipErrorInvalidValue;
+    if (p.T == 256) return p.C == 256 ? launch_attn_cfg<2, 2>(p, s) : launch_attn_cfg<2, 1>(p, s);
+    return p.C == 256 ? launch_attn_cfg<1, 2>(p, s) : launch_attn_cfg<1, 1>(p, s);
+}
+
+}  // namespace pf

@@ -35,7 +35,7 @@ struct LevelDesc { std::vector<ResDesc> blocks; std::string resample; int res_ch
 
 struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; double* stats = nullptr; };
 
-enum OpKind { OP_MEMSET, OP_TEMB, OP_BEGIN, OP_CONV, OP_SOFTMAX, OP_END,
+enum OpKind { OP_MEMSET, OP_TEMB, OP_BEGIN, OP_CONV, OP_SOFTMAX, OP_ATTN, OP_END,
               // backward-only
               OP_GN_FWD_COEF, OP_GN_BWD_PRE, OP_GN_BWD_COEF, OP_GN_BWD_POST, OP_TRANSPOSE, OP_SOFTMAX_BWD, OP_SUMPOOL };
 struct Op {
@@ -45,6 +45,7 @@ struct Op {
     TembParams tp;
     void* ptr = nullptr; size_t bytes = 0;          // memset
     float* sm = nullptr; int64_t sm_rows = 0; int sm_cols = 0;
+    AttnParams ap{};
     size_t flops = 0;
     // generic slots of the backward helper ops
     const void* P[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -106,6 +107,7 @@ struct pf_engine {
     int temb_total = 0;
     std::map<std::string, int> temb_off;   // ResBlock prefix -> offset in the stacked temb projection
     std::map<int, std::unique_ptr<Plan>> plans;
+    Plan* last_plan = nullptr;       // plan of the most recent forward (activation taps are read from it)
     int retained_B = 0;
     int precision = 1;   // 1 (default): split-fp16 (3 x f16 MFMA, fp32-equivalent) for the packed-weight convs; 0: exact fp32 MFMA
     SolverBufs sb;
@@ -432,8 +434,18 @@ static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x) {
         p.addvec = e->dev.at(key + ".b"); p.addvec_bs = 0;
         push_conv(bd, p);
     }
+    Tensor S{}, o = bd.make(C, H, Wd, false);
+    static const bool fuse_env = !(getenv("PNPFLOW_HIP_FUSED_ATTN") && atoi(getenv("PNPFLOW_HIP_FUSED_ATTN")) == 0);
+    if (fuse_env && e->precision != 0 && !bd.plan->retain && attn_fused_supported(HW, C)) {
+        // S = q k^T / sqrt(C), softmax, O = P v in one launch (attention.hip); the exact-fp32 mode and the retained
+        // forward of the VJP (whose backward reads P) keep the three-launch path below
+        Op op{}; op.kind = OP_ATTN;
+        op.ap.qkv = qkv.p; op.ap.out = o.p; op.ap.B = B; op.ap.T = HW; op.ap.C = C; op.ap.scale = 1.0f / sqrtf((float)C);
+        op.flops = (size_t)4 * B * HW * HW * C;
+        bd.plan->ops.push_back(op);
+    } else {
     // S[b][i][j] = C^-1/2 * sum_c q[i][c] k[j][c]      (a 1-tap "conv" whose weights are k)
-    Tensor S = bd.make(HW, H, Wd, false);
+    S = bd.make(HW, H, Wd, false);
     {
         ConvParams p = base_params(B, H, Wd, H, Wd, S);
         ConvSeg& s = p.seg[p.nseg++];
@@ -444,13 +456,13 @@ static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x) {
     }
     { Op op{}; op.kind = OP_SOFTMAX; op.sm = S.p; op.sm_rows = (int64_t)B * HW; op.sm_cols = HW; bd.plan->ops.push_back(op); }
     // O[b][i][c] = sum_j A[i][j] v[j][c]
-    Tensor o = bd.make(C, H, Wd, false);
     {
         ConvParams p = base_params(B, H, Wd, H, Wd, o);
         ConvSeg& s = p.seg[p.nseg++];
         s.src = S.p; s.C = HW; s.cstride = HW; s.coff = 0; s.xform = 0; s.taps = 1; s.stats = nullptr;
         s.w = qkv.p + 2 * C; s.w_mode = 1; s.w_bs = (int64_t)HW * 3 * C; s.w_ks = 3 * C; s.w_cs = 0; s.w_ts = 0; s.w_ns = 1;
         push_conv(bd, p);
+    }
     }
     // out = x + proj_out(O)
     Tensor out = bd.make(C, H, Wd, true);
@@ -463,7 +475,7 @@ static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x) {
         p.residual = x.p; p.res_cstride = C;
         push_conv(bd, p);
     }
-    bd.release(qkv.p); bd.release(S.p); bd.release(o.p);
+    bd.release(qkv.p); if (S.p) bd.release(S.p); bd.release(o.p);
     if (bd.plan->retain) {
         TapeRec tr; tr.kind = TP_ATTN; tr.pfx = pfx; tr.in0 = x; tr.qkv = qkv; tr.S = S; tr.o = o; tr.out = out;
         bd.plan->tape.push_back(tr);
@@ -501,9 +513,9 @@ static void fix_stats(Op& op, double* slab) {
 static int build_backward(pf_engine* e, Plan* plan, struct Builder& bd);
 
 static int build_plan(pf_engine* e, int B, bool retain, Plan** out_plan) {
-    const int key = B * 2 + (retain ? 1 : 0);
+    const int key = (B * 2 + (retain ? 1 : 0)) * 2 + (e->precision ? 1 : 0);      // the precision mode selects kernels at build time
     auto it = e->plans.find(key);
-    if (it != e->plans.end()) { *out_plan = it->second.get(); return PF_OK; }
+    if (it != e->plans.end()) { *out_plan = e->last_plan = it->second.get(); return PF_OK; }
     auto plan = std::make_unique<Plan>(); plan->B = B; plan->retain = retain;
     Builder bd{e, plan.get(), B};
     if (retain) bd.keep = true;
@@ -626,6 +638,7 @@ static int build_plan(pf_engine* e, int B, bool retain, Plan** out_plan) {
     plan->ops[0].ptr = slab; plan->ops[0].bytes = bd.stats_bytes;
     if (!plan->bops.empty()) plan->bops[0].ptr = (char*)slab + ((uintptr_t)plan->bops[0].ptr - 1);
     *out_plan = plan.get();
+    e->last_plan = plan.get();
     e->plans[key] = std::move(plan);
     return PF_OK;
 }
@@ -951,6 +964,7 @@ static int run_plan(pf_engine* e, Plan* plan, const float* x, const float* t, fl
                 }
                 break;
             case OP_SOFTMAX: r = launch_softmax_rows(op.sm, op.sm_rows, op.sm_cols, s); break;
+            case OP_ATTN: r = launch_attn_fused(op.ap, s); break;
             case OP_END: { EdgeConvParams ep = op.ep; ep.out = v; r = launch_end_conv(ep, s); break; }
         }
         if (r != hipSuccess) { e->err = std::string("kernel launch failed: ") + hipGetErrorString(r); return PF_ERR_HIP; }
@@ -1129,17 +1143,17 @@ int pf_ot_ode_update(float* x, const float* vt, const float* vec, const float* g
 }
 
 int pf_engine_num_taps(const pf_engine* e) {
-    if (!e || e->plans.empty()) return 0;
-    return (int)e->plans.rbegin()->second->taps.size();
+    if (!e || !e->last_plan) return 0;
+    return (int)e->last_plan->taps.size();
 }
 const char* pf_engine_tap_name(const pf_engine* e, int i) {
-    if (!e || e->plans.empty()) return nullptr;
-    auto& taps = e->plans.rbegin()->second->taps;
+    if (!e || !e->last_plan) return nullptr;
+    auto& taps = e->last_plan->taps;
     return (i >= 0 && i < (int)taps.size()) ? taps[i].name.c_str() : nullptr;
 }
 int pf_engine_read_tap(pf_engine* e, int i, float* host_out, int64_t capacity, int32_t dims[3], void* stream) {
-    if (!e || e->plans.empty() || !host_out || !dims) return PF_ERR_INVALID;
-    Plan* plan = e->plans.rbegin()->second.get();
+    if (!e || !e->last_plan || !host_out || !dims) return PF_ERR_INVALID;
+    Plan* plan = e->last_plan;
     if (i < 0 || i >= (int)plan->taps.size()) return PF_ERR_INVALID;
     const Tensor& t = plan->taps[i].t;
     const size_t n = (size_t)plan->B * t.C * t.H * t.W;

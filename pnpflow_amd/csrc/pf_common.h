@@ -61,6 +61,11 @@ struct EdgeConvParams {
     double* stats_out;    // begin conv: per-channel stats of the output
 };
 
+// fused attention core (attention.hip): qkv [B][T][3C] (q | k | v) -> out [B][T][C]
+struct AttnParams { const float* qkv; float* out; int B, T, C; float scale; };
+bool attn_fused_supported(int T, int C);
+hipError_t launch_attn_fused(const AttnParams& p, hipStream_t s);
+
 struct TembParams {
     const float* t;         // [B]
     const float* w0; const float* b0;   // Linear(ch -> 4ch)     (out,in)

@@ -6,12 +6,12 @@
 // and the output channels (phase 3).  Both contractions run on v_mfma_f32_32x32x16_f16 with hi+lo fp16 operand pairs
 // (3 MFMAs per product, fp32 accumulate: fp32-equivalent, see conv_mfma16.hip):
 //   phase 0  the 32 x C query block is split and parked in LDS in A-fragment order;
-//   phase 1  k is streamed in 32-channel chunks: coalesced float4 loads (prefetched one chunk ahead), split once per
+//   phase 1  k is streamed in 32-channel chunks: coalesced float4 loads (two chunks in flight), split once per
 //            workgroup, staged in LDS in B-fragment order; each wave accumulates S for its T/4 keys;
 //   phase 2  S (scaled) goes through LDS; 8 threads per query row do max / exp / sum / normalise and write P back as
 //            hi+lo A fragments (over the query block, which is no longer needed);
 //   phase 3  v is read straight from L2 (for a fixed key the 32 lanes of a fragment column are 128 contiguous bytes),
-//            split in registers two steps ahead of its use; each wave accumulates O for its C/4 channels.
+//            split in registers three steps ahead of its use; each wave accumulates O for its C/4 channels.
 // Shapes: T = 128*TK, C = 128*TC with TK, TC in {1, 2}; everything else stays on the unfused path (engine.hip).
 #include "pf_common.h"
 
@@ -45,8 +45,27 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
     static_assert(KBUF >= SBUF || true, "");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.y, q0 = blockIdx.x * BQ;
+    // Workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  All T/32 query blocks of an image
+    // re-read that image's k and v, so they are mapped to ONE XCD (image = 8*(slot / NQB) + xcd): with the natural order
+    // the 8 blocks of an image sat on 8 different XCDs and every L2 fetched every k/v once more from the fabric.
+    constexpr int NQB = T / BQ;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = (slot / NQB) * 8 + xcd, q0 = (slot % NQB) * BQ;
+    if (b >= p.B) return;
     const float* base = p.qkv + (size_t)b * T * 3 * C;
+
+    // k chunks 0 and 1 start their trip before anything else
+    constexpr int K_PER = T * 8 / 256;          // float4 per thread per 32-channel chunk of k
+    constexpr int NCH = C / 32;
+    float4 rka[K_PER], rkb[K_PER];              // chunks c and c+1 in flight: a chunk is loaded two iterations before its use
+    auto k_prefetch = [&](int chunk, float4 (&rk)[K_PER]) {
+#pragma unroll
+        for (int i = 0; i < K_PER; ++i) {
+            const int idx = tid + i * 256, key = idx >> 3, c4 = idx & 7;
+            rk[i] = *reinterpret_cast<const float4*>(base + (size_t)key * 3 * C + C + min(chunk, NCH - 1) * 32 + c4 * 4);
+        }
+    };
+    k_prefetch(0, rka); k_prefetch(1, rkb);
 
     // ---- phase 0: query block -> LDS (hi | lo) ------------------------------------------------------------------
 #pragma unroll
@@ -59,22 +78,12 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
     }
 
     // ---- phase 1: S = q k^T ---------------------------------------------------------------------------------------
-    constexpr int K_PER = T * 8 / 256;          // float4 per thread per 32-channel chunk of k
-    float4 rk[K_PER];
-    auto k_prefetch = [&](int chunk) {
-#pragma unroll
-        for (int i = 0; i < K_PER; ++i) {
-            const int idx = tid + i * 256, key = idx >> 3, c4 = idx & 7;
-            rk[i] = *reinterpret_cast<const float4*>(base + (size_t)key * 3 * C + C + chunk * 32 + c4 * 4);
-        }
-    };
     f32x16 acc_s[TK];
 #pragma unroll
     for (int nt = 0; nt < TK; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_s[nt][r] = 0.f;
-    k_prefetch(0);
-    for (int chunk = 0; chunk < C / 32; ++chunk) {
+    auto k_chunk = [&](int chunk, float4 (&rk)[K_PER]) {
         __syncthreads();                        // the previous chunk has been consumed (first pass: the q block is complete)
 #pragma unroll
         for (int i = 0; i < K_PER; ++i) {
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
             *reinterpret_cast<f16x4*>(s_k + key * KROW + 16 + c4 * 2) = l;
         }
         __syncthreads();
-        if (chunk + 1 < C / 32) k_prefetch(chunk + 1);
+        k_prefetch(chunk + 2, rk);              // (clamped re-load of the last chunk at the end: unconditional loads keep the waitcnts static)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int j = chunk * 2 + jj;       // k16-step over the channels
@@ -100,7 +109,8 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
                 acc_s[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc_s[nt], 0, 0, 0);
             }
         }
-    }
+    };
+    for (int chunk = 0; chunk < NCH; chunk += 2) { k_chunk(chunk, rka); k_chunk(chunk + 1, rkb); }
     __syncthreads();                            // every wave is done with the last k chunk: its LDS becomes the score tile
 #pragma unroll
     for (int nt = 0; nt < TK; ++nt) {
@@ -112,6 +122,18 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
         }
     }
     __syncthreads();
+
+    // v fragments: keys j*16 + hi*8 + i of this lane's channel(s); a ring of 4 register sets, loaded three steps ahead
+    // of their use - the first three leave before the softmax, which does not depend on them
+    const float* vbase = base + 2 * C + wave * TC * 32 + l31;        // + key*3C + nt*32
+    auto load_v = [&](int j, float (&dst)[TC][8]) {
+#pragma unroll
+        for (int nt = 0; nt < TC; ++nt)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dst[nt][i] = vbase[(size_t)(j * 16 + hi * 8 + i) * 3 * C + nt * 32];
+    };
+    float v0[TC][8], v1[TC][8], v2[TC][8], v3[TC][8];
+    load_v(0, v0); load_v(1, v1); load_v(2, v2);
 
     // ---- phase 2: softmax over the keys (models.py:155), P -> LDS as hi | lo A fragments ---------------------------
     {
@@ -151,15 +173,8 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
     for (int nt = 0; nt < TC; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_o[nt][r] = 0.f;
-    const float* vbase = base + 2 * C + wave * TC * 32 + l31;        // + key*3C + nt*32
-    auto load_v = [&](int j, float (&dst)[TC][8]) {                  // keys j*16 + hi*8 + i of this lane's channel(s)
-#pragma unroll
-        for (int nt = 0; nt < TC; ++nt)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dst[nt][i] = vbase[(size_t)(j * 16 + hi * 8 + i) * 3 * C + nt * 32];
-    };
     auto v_step = [&](int j, float (&cur)[TC][8], float (&nxt)[TC][8]) {
-        load_v(min(j + 2, T / 16 - 1), nxt);
+        load_v(min(j + 3, T / 16 - 1), nxt);
         __builtin_amdgcn_sched_barrier(0);
         const f16x8 ph = *reinterpret_cast<const f16x8*>(s_a + l31 * PROW + j * 8 + hi * 4);
         const f16x8 pl = *reinterpret_cast<const f16x8*>(s_a + l31 * PROW + T / 2 + j * 8 + hi * 4);
@@ -173,13 +188,9 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
             acc_o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, acc_o[nt], 0, 0, 0);
         }
     };
-    float v0[TC][8], v1[TC][8], v2[TC][8];
-    load_v(0, v0); load_v(1, v1);
-    static_assert((T / 16) % 3 != 0 || true, "");
     int j = 0;
-    for (; j + 3 <= T / 16; j += 3) { v_step(j, v0, v2); v_step(j + 1, v1, v0); v_step(j + 2, v2, v1); }
-    if (T / 16 - j >= 1) v_step(j, v0, v2);
-    if (T / 16 - j == 2) v_step(j + 1, v1, v0);
+    for (; j + 4 <= T / 16; j += 4) { v_step(j, v0, v3); v_step(j + 1, v1, v0); v_step(j + 2, v2, v1); v_step(j + 3, v3, v2); }
+    static_assert((T / 16) % 4 == 0, "the ring of 4 realigns every 4 steps");
 
     float* obase = p.out + ((size_t)b * T + q0) * C + wave * TC * 32 + l31;
 #pragma unroll
@@ -204,7 +215,7 @@ hipError_t launch_attn_cfg(const AttnParams& p, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(T / 32, p.B), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3((T / 32) * ((p.B + 7) / 8) * 8), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 

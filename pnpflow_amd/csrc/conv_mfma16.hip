@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
     constexpr int ROW = KC + 4;                  // dwords per LDS row: KC/2 (hi) + KC/2 (lo) + 4 (pad)
     constexpr int KQ = KC / 4, KH = KC / 2, KS = KC / 16;
     constexpr int TH = 2 * MT * WM, TW = 16;
-    constexpr int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PP = PH * PW;
+    constexpr int HALO = KC == 64 ? 0 : 1;      // KC = 64 is instantiated for pure 1x1 launches only: their patch has no halo
+    constexpr int PH = (TH - 1) * S + 1 + 2 * HALO, PW = (TW - 1) * S + 1 + 2 * HALO, PP = PH * PW;
     constexpr int BN = WN * NT * 32;
     constexpr int A_F4 = PP * KQ, A_PER = (A_F4 + 255) / 256;
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
         if (idx < A_F4) {
             const int pix = idx / KQ;
             const int py = pix / PW, px = pix % PW;
-            const int gy = oy0 * S - 1 + py, gx = ox0 * S - 1 + px;
+            const int gy = oy0 * S - HALO + py, gx = ox0 * S - HALO + px;
             a_lds[i] = pix * ROW + qi * 2;          // dword offset of this thread's 4 hi halfs (lo at +KH)
             if (gy >= 0 && gy < Hv && gx >= 0 && gx < Wv && !(UP == 2 && ((gy | gx) & 1))) {
                 const int sy = UP ? (gy >> 1) : gy, sx = UP ? (gx >> 1) : gx;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
             if (!PF_DBG(8)) load_b(sg, ch, min(s + 2, nsteps - 1), nh_, nl_);
             __builtin_amdgcn_sched_barrier(0);
             const int tap = s / KS, j = s % KS;
-            const int ky = sg.taps == 9 ? tap / 3 : 1, kx = sg.taps == 9 ? tap % 3 : 1;
+            const int ky = sg.taps == 9 ? tap / 3 : HALO, kx = sg.taps == 9 ? tap % 3 : HALO;
             f16x8 ah[MT], al[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -329,7 +330,8 @@ template <int MT, int NT, int WM, int WN, int S, int UP, int KC>
 static hipError_t launch_cfg16(const ConvParams& p, hipStream_t stream) {
     constexpr int ROW = KC + 4;
     constexpr int TH = 2 * MT * WM, TW = 16;
-    constexpr int PP = ((TH - 1) * S + 3) * ((TW - 1) * S + 3);
+    constexpr int HALO = KC == 64 ? 0 : 1;
+    constexpr int PP = ((TH - 1) * S + 1 + 2 * HALO) * ((TW - 1) * S + 1 + 2 * HALO);
     constexpr int BN = WN * NT * 32;
     constexpr int EPI = 4 * 32 * 36 + WM * BN * 2;           // epilogue: 4 per-wave transpose tiles + statistics scratch (floats)
     const size_t lds = (size_t)((PP * ROW > EPI ? PP * ROW : EPI) + 2 * ((p.gn_C + 3) & ~3)) * 4;

@@ -128,28 +128,53 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
 #else
     auto mark = [](int) {};
 #endif
-    prefetch(0, 0);
-
-    for (int c = tid; c < (PF_DBG(64) ? 0 : p.gn_C); c += 256) {
-        const int g = c / p.gn_cpg;
-        double s = 0.0, ss = 0.0;
-        for (int j = g * p.gn_cpg; j < (g + 1) * p.gn_cpg; ++j) {
+    // GroupNorm coefficients of image b.  The (sum, sumsq) pair of every normalised channel is requested BEFORE the first
+    // patch chunk (loads return in order: behind the patch they would only arrive after it, and the fp64 finalisation
+    // would then sit on the critical path instead of in the shadow of the patch latency); the pairs are exchanged
+    // through LDS (over the not yet written patch) so that each thread can sum its group.
+    constexpr int GNP = 4;                       // passes of 256 channels: gn_C <= 1024 (checked by the launcher)
+    double gsum[GNP], gsq[GNP]; float gga[GNP], gbe[GNP];
+#pragma unroll
+    for (int i = 0; i < GNP; ++i) {
+        const int c = tid + i * 256;
+        gsum[i] = 0.0; gsq[i] = 0.0; gga[i] = 0.f; gbe[i] = 0.f;
+        if (c < p.gn_C && !PF_DBG(64)) {
             for (int si = 0; si < p.nseg; ++si) {
                 const ConvSeg& sg = p.seg[si];
-                if (sg.xform != 0 && j >= sg.gn_off && j < sg.gn_off + sg.C) {
-                    const double* st = sg.stats + ((size_t)b * sg.C + (j - sg.gn_off)) * 2;
-                    s += st[0]; ss += st[1];
+                if (sg.xform != 0 && c >= sg.gn_off && c < sg.gn_off + sg.C) {
+                    const double* st = sg.stats + ((size_t)b * sg.C + (c - sg.gn_off)) * 2;
+                    gsum[i] = st[0]; gsq[i] = st[1];
                 }
             }
+            gga[i] = p.gamma[c]; gbe[i] = p.beta[c];
         }
-        const double N = (double)p.gn_cpg * (double)p.Hs * (double)p.Ws;
-        const double mean = s / N;
-        double var = ss / N - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
-        const float sc = p.gamma[c] * rstd;
-        s_sc[c] = sc;
-        s_sh[c] = p.beta[c] - (float)mean * sc;
+    }
+    prefetch(0, 0);
+    if (p.gn_C > 0) {
+        double* s_st = reinterpret_cast<double*>(s_patch);          // [gn_C][2]
+#pragma unroll
+        for (int i = 0; i < GNP; ++i) {
+            const int c = tid + i * 256;
+            if (c < p.gn_C) { s_st[2 * c] = gsum[i]; s_st[2 * c + 1] = gsq[i]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < GNP; ++i) {
+            const int c = tid + i * 256;
+            if (c < p.gn_C) {
+                const int g0 = (c / p.gn_cpg) * p.gn_cpg;
+                double sm = 0.0, ss = 0.0;
+                for (int j = g0; j < g0 + p.gn_cpg; ++j) { sm += s_st[2 * j]; ss += s_st[2 * j + 1]; }
+                const double N = (double)p.gn_cpg * (double)p.Hs * (double)p.Ws;
+                const double mean = sm / N;
+                double var = ss / N - mean * mean;
+                var = var > 0.0 ? var : 0.0;
+                const float rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+                const float sc = gga[i] * rstd;
+                s_sc[c] = sc;
+                s_sh[c] = gbe[i] - (float)mean * sc;
+            }
+        }
     }
 
     f32x16 acc[MT][NT];
@@ -379,6 +404,7 @@ static hipError_t launch_sel16(const ConvParams& p, hipStream_t stream) {
 // Only fragment-major packed weights (w_mode 0) with a 16-bit repack are supported; the caller keeps the
 // fp32 kernel (launch_conv) for the generic strided operands of attention.
 hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t stream) {
+    if (p.gn_C > 1024) return hipErrorInvalidValue;      // the kernel finalises at most 4 x 256 GroupNorm channels
     bool all_1tap = true;
     for (int i = 0; i < p.nseg; ++i) {
         if (p.seg[i].w_mode != 0 || p.seg[i].w16 == nullptr) return hipErrorInvalidValue;

@@ -284,8 +284,24 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
         const int n4 = ncol + cq * 4;
         const bool nok4 = n4 < p.Cout;
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        // Residual values are requested for two M-tiles at a time, before any of their stores: a load issued while
+        // stores are outstanding makes the wave wait for every store acknowledgement (one counter for loads and stores),
+        // which the former load-add-store sequence per float4 paid 4 x MT times per workgroup.
+        constexpr int RG = (MT >= 2 && !(MT == 4 && WN == 4)) ? 2 : 1;      // (one at a time where a second set of 16 registers would cost a wave per SIMD)
+        float4 rv[RG][4];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+            if (mt % RG == 0 && p.residual != nullptr && !PF_DBG(32)) {
+#pragma unroll
+                for (int g = 0; g < RG; ++g)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int px = (lane >> 3) + 8 * i;
+                        const int oy = min(oy0 + (wm * MT + mt + g) * 2 + (px >> 4), p.H - 1), ox = min(ox0 + (px & 15), p.W - 1);
+                        const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
+                        rv[g][i] = *reinterpret_cast<const float4*>(p.residual + pix * p.res_cstride + min(n4, p.Cout - 4));
+                    }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -302,8 +318,7 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
                 if (nok4 && oy < p.H && ox < p.W && !(PF_DBG(16) && v.x != 1.2345f)) {
                     const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
                     if (p.residual != nullptr && !PF_DBG(32)) {
-                        const float4 rv = *reinterpret_cast<const float4*>(p.residual + pix * p.res_cstride + n4);
-                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                        v.x += rv[mt % RG][i].x; v.y += rv[mt % RG][i].y; v.z += rv[mt % RG][i].z; v.w += rv[mt % RG][i].w;
                     }
                     *reinterpret_cast<float4*>(p.out + pix * p.out_cstride + n4) = v;
                     s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;

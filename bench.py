@@ -236,7 +236,7 @@ def main():
             peak = 2500.0  # TFLOP/s, f16 MFMA dense peak; every algorithmic product is executed as 3 f16 MFMA products
             roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                         traffic=TRAFFIC_C2_F16X3 if (a.workload == "c2" and rep == 5) else None,
-                        kernel="conv_mfma16_kernel (f16 32x32x16 MFMA x3 split, implicit GEMM); attention matmuls on conv_mfma_kernel (fp32)",
+                        kernel="conv_mfma16_kernel (f16 32x32x16 MFMA x3 split, implicit GEMM; every 3x3/1x1 conv of the U-Net; the fused attention core is a separate launch and not in this family)",
                         mfma_tflops_executed=round(3 * ach, 2), frac_executed=round(3 * ach / peak, 4))
         roof.update(launches=int(launches // n_fw), avg_launch_us=round(ms * 1e3 / max(1, launches), 2),
                     algorithmic_gflop_per_launch=round(flops / max(1, launches) / 1e9, 4))

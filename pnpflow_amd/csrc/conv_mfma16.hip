@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
         // Residual values are requested for two M-tiles at a time, before any of their stores: a load issued while
         // stores are outstanding makes the wave wait for every store acknowledgement (one counter for loads and stores),
         // which the former load-add-store sequence per float4 paid 4 x MT times per workgroup.
-        constexpr int RG = (MT >= 2 && !(MT == 4 && WN == 4)) ? 2 : 1;      // (one at a time where a second set of 16 registers would cost a wave per SIMD)
+        constexpr int RG = (MT >= 2 && WN != 4) ? 2 : 1;      // (one at a time where a second set of 16 registers would cost a wave per SIMD)
         float4 rv[RG][4];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -347,8 +347,8 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
     mark(3);
     if (p.stats_out != nullptr && !PF_DBG(128)) {
         __syncthreads();
-        if (tid < BN * 2) {
-            const int col = tid >> 1, which = tid & 1;
+        for (int t = tid; t < BN * 2; t += 256) {
+            const int col = t >> 1, which = t & 1;
             float tot = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) tot += s_red[(w * BN + col) * 2 + which];

@@ -50,26 +50,37 @@ __global__ __launch_bounds__(256) void gn_bwd_pre_kernel(float* g, const float* 
         const float4 be = *reinterpret_cast<const float4*>(beta + cg);
         const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
         const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
-        for (int pix = p0 + pr; pix < p1; pix += lanes_p) {
-            const size_t o = ((size_t)b * HW + pix) * C + q * 4;
-            const float4 xv = *reinterpret_cast<const float4*>(x + o);
-            float4 gv = *reinterpret_cast<float4*>(g + o);
-            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-            float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+        constexpr int UNR = 4;                    // pixels in flight per thread: 8 float4 loads before the first use
+        for (int pix = p0 + pr; pix < p1; pix += lanes_p * UNR) {
+            float4 xv[UNR], gv[UNR];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float yh = (xs[j] - mm[j]) * rr[j];
-                float d = gs[j];
-                if (silu) {
-                    const float u = yh * gg[j] + bb[j];
-                    const float sg = 1.0f / (1.0f + expf(-u));
-                    d *= sg * (1.0f + u * (1.0f - sg));
-                }
-                d *= gg[j];
-                gs[j] = d;
-                s1[j] += d; s2[j] += d * yh;
+            for (int k = 0; k < UNR; ++k) {
+                const int pk = min(pix + k * lanes_p, p1 - 1);                       // clamped: unconditional loads
+                const size_t o = ((size_t)b * HW + pk) * C + q * 4;
+                xv[k] = *reinterpret_cast<const float4*>(x + o);
+                gv[k] = *reinterpret_cast<const float4*>(g + o);
             }
-            *reinterpret_cast<float4*>(g + o) = make_float4(gs[0], gs[1], gs[2], gs[3]);
+#pragma unroll
+            for (int k = 0; k < UNR; ++k) {
+                if (pix + k * lanes_p < p1) {
+                    const float xs[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
+                    float gs[4] = {gv[k].x, gv[k].y, gv[k].z, gv[k].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float yh = (xs[j] - mm[j]) * rr[j];
+                        float d = gs[j];
+                        if (silu) {
+                            const float u = yh * gg[j] + bb[j];
+                            const float sg = __frcp_rn(1.0f + __expf(-u));
+                            d *= sg * (1.0f + u * (1.0f - sg));
+                        }
+                        d *= gg[j];
+                        gs[j] = d;
+                        s1[j] += d; s2[j] += d * yh;
+                    }
+                    *reinterpret_cast<float4*>(g + ((size_t)b * HW + pix + k * lanes_p) * C + q * 4) = make_float4(gs[0], gs[1], gs[2], gs[3]);
+                }
+            }
         }
     }
     for (int j = 0; j < 4; ++j) {
@@ -102,30 +113,45 @@ __global__ __launch_bounds__(256) void gn_bwd_coeffs_kernel(const double* bsum, 
 // ---- stage B: out (=|+=) rs * (dyhat - m1 - yhat*m2) (+ add) -----------------------------------
 __global__ __launch_bounds__(256) void gn_bwd_post_kernel(const float* dy, const float* x, const float* mu, const float* rs, const float* m1,
                                                           const float* m2, const float* add, float* out, int HW, int C, int coff, int Ct,
-                                                          int accumulate) {
-    const int b = blockIdx.y;
-    const int cq = C / 4;
-    const size_t n4 = (size_t)HW * cq;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const int q = i % cq;
-        const size_t o = (size_t)b * HW * C + i * 4;
-        const int cg = coff + q * 4;
-        const float4 m4 = *reinterpret_cast<const float4*>(mu + (size_t)b * Ct + cg);
-        const float4 r4 = *reinterpret_cast<const float4*>(rs + (size_t)b * Ct + cg);
-        const float4 a4 = *reinterpret_cast<const float4*>(m1 + (size_t)b * Ct + cg);
-        const float4 b4 = *reinterpret_cast<const float4*>(m2 + (size_t)b * Ct + cg);
-        const float4 xv = *reinterpret_cast<const float4*>(x + o);
-        const float4 dv = *reinterpret_cast<const float4*>(dy + o);
-        float4 r;
-        r.x = r4.x * (dv.x - a4.x - (xv.x - m4.x) * r4.x * b4.x);
-        r.y = r4.y * (dv.y - a4.y - (xv.y - m4.y) * r4.y * b4.y);
-        r.z = r4.z * (dv.z - a4.z - (xv.z - m4.z) * r4.z * b4.z);
-        r.w = r4.w * (dv.w - a4.w - (xv.w - m4.w) * r4.w * b4.w);
-        if (add != nullptr) { const float4 av = *reinterpret_cast<const float4*>(add + o); r.x += av.x; r.y += av.y; r.z += av.z; r.w += av.w; }
-        if (accumulate) { const float4 ov = *reinterpret_cast<const float4*>(out + o); r.x += ov.x; r.y += ov.y; r.z += ov.z; r.w += ov.w; }
-        *reinterpret_cast<float4*>(out + o) = r;
+                                                          int accumulate, int pix_per_block) {
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int cq = C / 4, lanes_p = 256 / cq;
+    const int q = tid % cq, pr = tid / cq;
+    if (pr >= lanes_p) return;
+    const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+    const int cg = coff + q * 4;
+    const float4 m4 = *reinterpret_cast<const float4*>(mu + (size_t)b * Ct + cg);
+    const float4 r4 = *reinterpret_cast<const float4*>(rs + (size_t)b * Ct + cg);
+    const float4 a4 = *reinterpret_cast<const float4*>(m1 + (size_t)b * Ct + cg);
+    const float4 b4 = *reinterpret_cast<const float4*>(m2 + (size_t)b * Ct + cg);
+    constexpr int UNR = 4;
+    for (int pix = p0 + pr; pix < p1; pix += lanes_p * UNR) {
+        float4 xv[UNR], dv[UNR], av[UNR], ov[UNR];
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            const int pk = min(pix + k * lanes_p, p1 - 1);
+            const size_t o = ((size_t)b * HW + pk) * C + q * 4;
+            xv[k] = *reinterpret_cast<const float4*>(x + o);
+            dv[k] = *reinterpret_cast<const float4*>(dy + o);
+            if (add != nullptr) av[k] = *reinterpret_cast<const float4*>(add + o);
+            if (accumulate) ov[k] = *reinterpret_cast<const float4*>(out + o);
+        }
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            if (pix + k * lanes_p < p1) {
+                float4 r;
+                r.x = r4.x * (dv[k].x - a4.x - (xv[k].x - m4.x) * r4.x * b4.x);
+                r.y = r4.y * (dv[k].y - a4.y - (xv[k].y - m4.y) * r4.y * b4.y);
+                r.z = r4.z * (dv[k].z - a4.z - (xv[k].z - m4.z) * r4.z * b4.z);
+                r.w = r4.w * (dv[k].w - a4.w - (xv[k].w - m4.w) * r4.w * b4.w);
+                if (add != nullptr) { r.x += av[k].x; r.y += av[k].y; r.z += av[k].z; r.w += av[k].w; }
+                if (accumulate) { r.x += ov[k].x; r.y += ov[k].y; r.z += ov[k].z; r.w += ov[k].w; }
+                *reinterpret_cast<float4*>(out + ((size_t)b * HW + pix + k * lanes_p) * C + q * 4) = r;
+            }
+        }
     }
 }
+
 
 hipError_t launch_gn_fwd_coeffs(const double* st0, int C0, const double* st1, int C1, int cpg, int HW, float eps, float* mu, float* rs, int B,
                                 hipStream_t s) {
@@ -145,10 +171,10 @@ hipError_t launch_gn_bwd_coeffs(const double* bsum, int Ct, int cpg, int HW, flo
 }
 hipError_t launch_gn_bwd_post(const float* dy, const float* x, const float* mu, const float* rs, const float* m1, const float* m2,
                               const float* add, float* out, int B, int HW, int C, int coff, int Ct, int accumulate, hipStream_t s) {
-    if (C % 4) return hipErrorInvalidValue;
-    const size_t n4 = (size_t)HW * (C / 4);
-    hipLaunchKernelGGL(gn_bwd_post_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 2048), B), dim3(256), 0, s, dy, x, mu, rs, m1, m2,
-                       add, out, HW, C, coff, Ct, accumulate);
+    if (C % 4 || C / 4 > 256) return hipErrorInvalidValue;
+    const int ppb = 1024;
+    hipLaunchKernelGGL(gn_bwd_post_kernel, dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, s, dy, x, mu, rs, m1, m2,
+                       add, out, HW, C, coff, Ct, accumulate, ppb);
     return hipGetLastError();
 }
 

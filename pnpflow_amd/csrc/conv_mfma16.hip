@@ -426,7 +426,7 @@ hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t st
         all_1tap &= p.seg[i].taps == 1 && p.seg[i].C >= 64;
     }
     static const int kc_pref = getenv("PNPFLOW_HIP_KC") ? atoi(getenv("PNPFLOW_HIP_KC")) : 32;
-    static const int kc_l0 = getenv("PNPFLOW_HIP_KC_L0") ? atoi(getenv("PNPFLOW_HIP_KC_L0")) : 16;   // 32-channel layers: 16-channel chunks keep the patch at 26 KB (5-6 workgroups per CU)
+    static const int kc_l0 = getenv("PNPFLOW_HIP_KC_L0") ? atoi(getenv("PNPFLOW_HIP_KC_L0")) : 32;   // 32-channel layers: one 32-channel chunk reads whole 128-B pixel rows (16-channel chunks: same time, +40 % HBM reads - PMC, profiles/)
     bool all32 = (p.Cout <= 32 ? kc_l0 : kc_pref) == 32;
     for (int i = 0; i < p.nseg; ++i) all32 &= p.seg[i].C % 32 == 0;
     if (all_1tap && stride == 1 && !up) return launch_sel16<1, 0, 64>(p, stream);

@@ -397,8 +397,6 @@ static hipError_t launch_sel16(const ConvParams& p, hipStream_t stream) {
     static const long MIN_WGS = getenv("PNPFLOW_HIP_MIN_WGS") ? atol(getenv("PNPFLOW_HIP_MIN_WGS")) : 512;
     if constexpr (S == 1) {
         if (p.Cout <= 32) {
-            static const int big_l0 = getenv("PNPFLOW_HIP_BIG_L0") ? atoi(getenv("PNPFLOW_HIP_BIG_L0")) : 0;
-            if (big_l0 && KC == 16 && wg_count16(p, 32, 32) >= 2 * MIN_WGS) return launch_cfg16<4, 1, 4, 1, S, UP, KC>(p, stream);   // 32x16 px x 32 (49 KB patch at KC 16)
             return launch_cfg16<2, 1, 4, 1, S, UP, KC>(p, stream);                                                        // 16x16 px x 32
         }
         if (p.Cout <= 64) {

@@ -77,8 +77,9 @@ int pf_engine_weight_shape(const pf_engine* e, int i, int64_t shape[4]);
 
 /* 1 (default) = split-fp16: every operand carried as an fp16 pair hi+lo, 3 x v_mfma_f32_32x32x16_f16 per product,
  *     fp32 accumulate - fp32-equivalent results (the parity tests hold both modes to the same tolerance) at 3/16 of
- *     the matrix-pipe time.  Applies to the packed-weight convs of the forward; the attention matmuls and the
- *     backward stay on the fp32 MFMA.
+ *     the matrix-pipe time.  Applies to the packed-weight convs of the forward and of the backward (the VJP input is
+ *     normalised by a power of two first) and selects the fused attention core (q k^T, softmax, P v in one launch)
+ *     where its shapes apply; the unfused attention matmuls and their adjoints run on the fp32 MFMA.
  * 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere. */
 int pf_engine_set_precision(pf_engine* e, int mode);
 

@@ -88,6 +88,10 @@ def load():
         raise PnpFlowHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no fallback implementation.")
+    # torch first: the engine shares device pointers and streams with torch, so both must bind to the SAME HIP runtime
+    # instance (torch ships its own libamdhip64; loading ours first pulls in /opt/rocm's copy and the process ends up
+    # with two runtimes - the second one reports "no ROCm-capable device")
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported

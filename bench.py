@@ -69,15 +69,17 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(wl, sd, cfg, budget_s=20.0):
+def cpu_baseline(wl, budget_s=20.0):
     """The oracle (CPU restatement of the reference path, torch fp32, all usable host cores) timed on
     a bounded sample of the same workload: B=2 images and as many U-Net evaluations of the first
     outer iterations as fit in ~budget_s seconds.  Cost is linear in (evaluations x images); the
     extrapolation to steps_pnp x num_samples evaluations is stated in `sample`."""
-    from oracle import pnpflow_oracle as O
+    from oracle import pnpflow_oracle as O          # the ONLY use of oracle/ in this file: the thing timed as the CPU baseline
     cores = usable_cores()
     torch.set_num_threads(cores)
     Bc, dim = 2, wl["dim"]
+    cfg = O.unet_config(3, dim, 32, (1, 2, 4, 8), wl["nres"], (16, 8))
+    sd = O.synthetic_state_dict(cfg, 0)             # same seed-fixed recipe as tools/synthetic_weights.py
     deg, sigma = O.make_degradation(wl["problem"], dim) if dim in (128, 256) else (O.BoxInpainting(10), 0.05)
     clean = det_image((Bc, 3, dim, dim), 31)
     y = O.make_measurement(clean, deg, sigma, 0)
@@ -137,7 +139,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from oracle import pnpflow_oracle as O          # only for the synthetic-weight recipe + cpu_baseline
     import pnpflow_amd.degradations as D
     from pnpflow_amd.methods.pnp_flow import PNP_FLOW
     from pnpflow_amd.models import UNet
@@ -145,10 +146,9 @@ def main():
     from pnpflow_amd.utils import CfgNode, psnr_per_image
 
     dim, B = wl["dim"], wl["B"]
-    cfg = O.unet_config(3, dim, 32, (1, 2, 4, 8), wl["nres"], (16, 8))
-    sd = O.synthetic_state_dict(cfg, 0)
+    from tools.synthetic_weights import synthetic_state_dict      # product-side recipe (no checkpoint is reachable offline)
     model = UNet(3, dim, 32, ch_mult=(1, 2, 4, 8), num_res_blocks=wl["nres"], attn_resolutions=(16, 8), device_index=local)
-    model.load_state_dict(sd)
+    model.load_state_dict(synthetic_state_dict(model, 0))
     model.set_precision(a.precision)
     lo, hi = shard_range(world * B, rank, world)
     degradation, sigma = make_problem(D, wl["problem"], dim, global_batch=world * B, batch_offset=lo)
@@ -264,7 +264,7 @@ def main():
             n_it = wl["steps"] - int(wl["steps"] * wl["start_time"])
             out["unet_tflops_end_to_end"] = round(total_images * n_it * 2 * fwd_flops / dt / 1e12, 2)
         if not a.no_cpu_baseline and world == 1 and not is_ode:
-            out["cpu_baseline"] = cpu_baseline(wl, sd, cfg)
+            out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

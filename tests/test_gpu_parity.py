@@ -201,6 +201,17 @@ def test_unet_forward_matches_oracle_and_golden(hip, golden, name, B, precision)
         np.testing.assert_allclose(checksums(out), g["out_checksum"], rtol=2e-4)
 
 
+def test_product_side_synthetic_weights_match_the_oracle_recipe(hip):
+    # bench.py / main.py draw their seed-fixed weights from tools/synthetic_weights.py (names and shapes reported by the
+    # engine, no oracle import); the CPU baseline and the parity tests use the oracle's recipe: same tensors, key by key
+    from tools.synthetic_weights import synthetic_state_dict
+    m, cfg, sd = model_for("tiny4")
+    mine = synthetic_state_dict(m, 0)
+    assert set(mine) == set(sd)
+    for k in sd:
+        assert torch.equal(mine[k], sd[k]), k
+
+
 @pytest.mark.parametrize("B", [32, 160])
 def test_unet_batch_independence_full_size(hip, B):
     # size-independent property at the C2 batch (32 x 3 x 128^2) and at the U-Net batch the solver actually runs

@@ -32,7 +32,8 @@ namespace pf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float silu_fast(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
+// v_exp_f32 / v_rcp_f32 (1 ulp each); __frcp_rn would be a correctly rounded division: 10 instructions per element
+__device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 template <int MT, int NT, int WM, int WN, int S, int UP, int BM, int KC>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {

@@ -32,7 +32,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float silu_fast16(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
+// v_exp_f32 / v_rcp_f32 (1 ulp each); __frcp_rn would be a correctly rounded division: 10 instructions per element
+__device__ __forceinline__ float silu_fast16(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 template <int MT, int NT, int WM, int WN, int S, int UP, int KC>
 __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
             if (c < p.gn_C) { s_st[2 * c] = gsum[i]; s_st[2 * c + 1] = gsq[i]; }
         }
         __syncthreads();
+        const double inv_n = 1.0 / ((double)p.gn_cpg * (double)p.Hs * (double)p.Ws);      // one fp64 division per thread instead of three per channel
 #pragma unroll
         for (int i = 0; i < GNP; ++i) {
             const int c = tid + i * 256;
@@ -165,11 +167,10 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
                 const int g0 = (c / p.gn_cpg) * p.gn_cpg;
                 double sm = 0.0, ss = 0.0;
                 for (int j = g0; j < g0 + p.gn_cpg; ++j) { sm += s_st[2 * j]; ss += s_st[2 * j + 1]; }
-                const double N = (double)p.gn_cpg * (double)p.Hs * (double)p.Ws;
-                const double mean = sm / N;
-                double var = ss / N - mean * mean;
+                const double mean = sm * inv_n;
+                double var = ss * inv_n - mean * mean;
                 var = var > 0.0 ? var : 0.0;
-                const float rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+                const float rstd = __builtin_amdgcn_rsqf((float)(var + (double)p.gn_eps));     // v_rsq_f32, 1 ulp (the reference's GroupNorm takes rsqrt in fp32 too)
                 const float sc = gga[i] * rstd;
                 s_sc[c] = sc;
                 s_sh[c] = gbe[i] - (float)mean * sc;

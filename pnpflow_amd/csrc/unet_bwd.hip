@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void gn_bwd_pre_kernel(float* g, const float* 
                         float d = gs[j];
                         if (silu) {
                             const float u = yh * gg[j] + bb[j];
-                            const float sg = __frcp_rn(1.0f + __expf(-u));
+                            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
                             d *= sg * (1.0f + u * (1.0f - sg));
                         }
                         d *= gg[j];

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void end_conv_kernel(const EdgeConvParams p) {
             }
             if (!raw) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) { const float u = a[c] * s_sc[c] + s_sh[c]; a[c] = u * __frcp_rn(1.0f + __expf(-u)); }
+                for (int c = 0; c < C; ++c) { const float u = a[c] * s_sc[c] + s_sh[c]; a[c] = u * __builtin_amdgcn_rcpf(1.0f + __expf(-u)); }
             }
 #pragma unroll
             for (int k = 0; k < NT_; ++k) {

@@ -36,7 +36,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float silu_fast16(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 template <int MT, int NT, int WM, int WN, int S, int UP, int KC>
-__global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, ((MT == 4 && WM == 2 && KC == 16) ? 3 : 1)) void conv_mfma16_kernel(const ConvParams p) {
     constexpr int ROW = KC + 4;                  // dwords per LDS row: KC/2 (hi) + KC/2 (lo) + 4 (pad)
     constexpr int KQ = KC / 4, KH = KC / 2, KS = KC / 16;
     constexpr int TH = 2 * MT * WM, TW = 16;
@@ -63,16 +63,15 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
     const int Hv = UP ? 2 * p.Hs : p.Hs, Wv = UP ? 2 * p.Ws : p.Ws;
     const int qi = tid % KQ, q4 = qi * 4;
 
-    int a_pix[A_PER], a_lds[A_PER];
+    int a_pix[A_PER];                            // source pixel of staged float4 number tid + i*256 (-1: zero); its LDS slot is recomputed when used
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
         const int idx = tid + i * 256;
-        a_pix[i] = -1; a_lds[i] = -1;
+        a_pix[i] = -1;
         if (idx < A_F4) {
             const int pix = idx / KQ;
             const int py = pix / PW, px = pix % PW;
             const int gy = oy0 * S - HALO + py, gx = ox0 * S - HALO + px;
-            a_lds[i] = pix * ROW + qi * 2;          // dword offset of this thread's 4 hi halfs (lo at +KH)
             if (gy >= 0 && gy < Hv && gx >= 0 && gx < Wv && !(UP == 2 && ((gy | gx) & 1))) {
                 const int sy = UP ? (gy >> 1) : gy, sx = UP ? (gx >> 1) : gx;
                 a_pix[i] = (b * p.Hs + sy) * p.Ws + sx;
@@ -99,7 +98,8 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
         }
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
-            if (a_lds[i] >= 0) {
+            if (tid + i * 256 < A_F4) {
+                const int a_lds = ((tid + i * 256) / KQ) * ROW + qi * 2;      // dword offset of this thread's 4 hi halfs (lo at +KH)
                 float4 v = ra[i];
                 if (sg.xform != 0) {
                     v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256) void conv_mfma16_kernel(const ConvParams p) {
                 h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
                 l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
                 l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
-                *reinterpret_cast<f16x4*>(s_patch + a_lds[i]) = h;
-                *reinterpret_cast<f16x4*>(s_patch + a_lds[i] + KH) = l;
+                *reinterpret_cast<f16x4*>(s_patch + a_lds) = h;
+                *reinterpret_cast<f16x4*>(s_patch + a_lds + KH) = l;
             }
         }
     };
@@ -426,7 +426,8 @@ hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t st
     }
     static const int kc_pref = getenv("PNPFLOW_HIP_KC") ? atoi(getenv("PNPFLOW_HIP_KC")) : 32;
     static const int kc_l0 = getenv("PNPFLOW_HIP_KC_L0") ? atoi(getenv("PNPFLOW_HIP_KC_L0")) : 32;   // 32-channel layers: one 32-channel chunk reads whole 128-B pixel rows (16-channel chunks: same time, +40 % HBM reads - PMC, profiles/)
-    bool all32 = (p.Cout <= 32 ? kc_l0 : kc_pref) == 32;
+    static const int kc_l1 = getenv("PNPFLOW_HIP_KC_L1") ? atoi(getenv("PNPFLOW_HIP_KC_L1")) : 32;
+    bool all32 = (p.Cout <= 32 ? kc_l0 : p.Cout <= 64 ? kc_l1 : kc_pref) == 32;
     for (int i = 0; i < p.nseg; ++i) all32 &= p.seg[i].C % 32 == 0;
     if (all_1tap && stride == 1 && !up) return launch_sel16<1, 0, 64>(p, stream);
     if (stride == 2) return launch_sel16<2, 0, 16>(p, stream);

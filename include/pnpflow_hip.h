@@ -146,6 +146,12 @@ int pf_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, voi
  * (pnpflow/utils.py:560-577, 594-611) -> out[B] (device). */
 int pf_psnr(const float* rec, const float* clean, float* out, int B, int n_per_image, void* stream);
 
+/* ---- attention core -------------------------------------------------------------------- */
+/* out[B,T,C] = softmax(q k^T * C^-1/2, dim=-1) v for q|k|v stacked as qkv[B,T,3C] (fp32, token-major): the bmm /
+ * softmax / bmm of SelfAttention.forward (pnpflow/models.py:152-158) in one launch, split-f16 MFMA (fp32-equivalent).
+ * Shapes: T in {128, 256}, C in {128, 256}; anything else returns PF_ERR_INVALID (the engine then uses three launches). */
+int pf_attention_core(const float* qkv, float* out, int B, int T, int C, void* stream);
+
 /* ---- vector-Jacobian product (OT-ODE) ------------------------------------------------ */
 /* replaces torch.autograd.functional.vjp(lambda z: model(z, t), x, vec) at
  * pnpflow/methods/ot_ode.py:137-138.  pf_unet_forward_retain = a forward that keeps every

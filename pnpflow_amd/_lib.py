@@ -66,6 +66,7 @@ SIGNATURES = {
     "pf_interpolate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pf_denoise_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "pf_fill_normal": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "pf_attention_core": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pf_psnr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pf_pnp_flow_restore": (C.c_int, [C.c_void_p, C.POINTER(PfDegradation), C.POINTER(PfPnpParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, ITER_CB, C.c_void_p]),
     "pf_engine_profile": (C.c_int, [C.c_void_p, C.c_int]),

@@ -23,7 +23,12 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-__device__ __forceinline__ void split4(const float4 v, f16x4& h, f16x4& l) {
+// The value is made opaque first: with -ffp-contract=fast hipcc otherwise re-derives it from the multiply that produced
+// it, rounds the STORED hi from the fp32 product (v_mul + v_cvt_pk) but subtracts a hi obtained by a fused
+// v_fma_mixlo_f16 of the unrounded product; at a double-rounding tie the two differ by one f16 ulp and hi+lo is off by
+// 2^-11 relative (found by the direct parity test of this kernel: 1 element in 180 000).
+__device__ __forceinline__ void split4(float4 v, f16x4& h, f16x4& l) {
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
     h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
     l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
     l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);

@@ -1209,6 +1209,13 @@ int pf_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, voi
     LAUNCHCHK(launch_fill_normal(out, n, seed, stream_id, (hipStream_t)stream));
     return PF_OK;
 }
+int pf_attention_core(const float* qkv, float* out, int B, int T, int C, void* stream) {
+    if (!qkv || !out || B <= 0 || !attn_fused_supported(T, C)) return PF_ERR_INVALID;
+    AttnParams ap{qkv, out, B, T, C, 1.0f / sqrtf((float)C)};
+    LAUNCHCHK(launch_attn_fused(ap, (hipStream_t)stream));
+    return PF_OK;
+}
+
 int pf_psnr(const float* rec, const float* clean, float* out, int B, int n_per_image, void* stream) {
     if (!rec || !clean || !out) return PF_ERR_INVALID;
     LAUNCHCHK(launch_psnr(rec, clean, out, B, n_per_image, (hipStream_t)stream));

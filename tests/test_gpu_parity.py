@@ -201,6 +201,24 @@ def test_unet_forward_matches_oracle_and_golden(hip, golden, name, B, precision)
         np.testing.assert_allclose(checksums(out), g["out_checksum"], rtol=2e-4)
 
 
+@pytest.mark.parametrize("T,Cc", [(256, 256), (256, 128), (128, 256), (128, 128)])
+def test_fused_attention_core_matches_bmm_softmax_bmm(hip, T, Cc):
+    """pf_attention_core vs the reference's formulation (models.py:152-158: bmm, * C**-0.5, softmax(dim=-1), bmm) in fp64
+    on the CPU, on every shape the kernel is instantiated for; B = 11 exercises the XCD-aware block mapping's padding
+    (blocks of images 11..15 exit) and logits of magnitude ~12 exercise the softmax range."""
+    lib = hip.load()
+    B = 11
+    qkv = det_normal((B, T, 3 * Cc), 71)
+    qkv[:, :, :Cc] *= 3.0                                              # q: spread the logits
+    q, k, v = qkv[..., :Cc].double(), qkv[..., Cc:2 * Cc].double(), qkv[..., 2 * Cc:].double()
+    ref = torch.softmax(torch.bmm(q, k.transpose(1, 2)) * (Cc ** -0.5), dim=-1) @ v
+    qd = qkv.cuda(); out = torch.empty((B, T, Cc), device="cuda")
+    assert lib.pf_attention_core(qd.data_ptr(), out.data_ptr(), B, T, Cc, hip.current_stream_ptr()) == 0
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().numpy(), atol=2e-5 * float(ref.abs().max()))
+    # unsupported shapes are refused (the engine keeps its three-launch path for them)
+    assert lib.pf_attention_core(qd.data_ptr(), out.data_ptr(), B, 196, Cc, hip.current_stream_ptr()) != 0
+
+
 def test_product_side_synthetic_weights_match_the_oracle_recipe(hip):
     # bench.py / main.py draw their seed-fixed weights from tools/synthetic_weights.py (names and shapes reported by the
     # engine, no oracle import); the CPU baseline and the parity tests use the oracle's recipe: same tensors, key by key

@@ -107,3 +107,53 @@ def test_reference_import_paths_resolve_to_the_engine():
     import pnpflow_amd.methods.pnp_flow as A
     assert PNP_FLOW is A.PNP_FLOW and OT_ODE.__module__ == "pnpflow_amd.methods.ot_ode"
     assert BoxInpainting(20).half_size_mask == 20 and Superresolution(4, 256).sf == 4
+
+
+def test_bicubic_taps_are_the_separable_factor_of_the_reference_filter():
+    """Superresolution(mode="bicubic") on the engine uses the 1-D factor of utils.py:365-396's normalised outer
+    product; tap K/2 sits at offset 0 after the reference's roll by (-(K-1))//2."""
+    from oracle import pnpflow_oracle as O
+    import pnpflow_amd.degradations as D
+    for sf in (2, 4):
+        w = D.bicubic_taps(sf)
+        k = O.bicubic_filter(sf)[0, 0].numpy()
+        assert w.shape == (4 * sf,) and w.dtype == np.float32
+        np.testing.assert_allclose(np.outer(w, w), k, atol=1e-7)
+        assert abs(float(w.sum()) - 1.0) < 1e-6
+        d = D.Superresolution(sf, 64, mode="bicubic", device="cpu")
+        assert d.kind == 5 and d.taps_host.shape[0] == 4 * sf
+        # roll offset: the filter tap that lands on pixel (0, 0) is k[K/2, K/2]
+        assert O.Superresolution(sf, 64, mode="bicubic").filter[0, 0, 0, 0] == k[2 * sf, 2 * sf]
+    with pytest.raises(NotImplementedError):
+        D.Superresolution(2, 64, mode="nearest")
+
+
+def test_ot_ode_scalars_match_reference_expressions():
+    """OT_ODE._scalars reproduces ot_ode.py:69-73, 96 (the `delta * iteration**2` quirk of the superresolution branch)
+    and :133-143 in fp32, per problem."""
+    from pnpflow_amd.methods.ot_ode import OT_ODE
+    from pnpflow_amd.utils import CfgNode
+    for gamma in ("constant", "gamma_t"):
+        s = OT_ODE.__new__(OT_ODE); s.args = CfgNode(dict(gamma=gamma))
+        steps, delta, B = 100, 1 / 100, 3
+        for it in (10, 37, 99):
+            for problem in ("inpainting", "denoising", "gaussian_deblurring_FFT", "superresolution"):
+                t1, omt, rt2, coef = s._scalars(it, delta, problem, B, "cpu")
+                t_ref = torch.ones(B) * delta * it
+                assert torch.equal(t1, t_ref) and torch.equal(omt, 1 - t_ref)
+                if problem == "superresolution":
+                    r = torch.tensor((1 - delta * it) ** 2 / ((1 - delta * it) ** 2 + delta * it ** 2)).float()
+                    assert torch.allclose(rt2, r.expand(B))
+                else:
+                    assert torch.equal(rt2, ((1 - t_ref) ** 2 / ((1 - t_ref) ** 2 + t_ref ** 2)))
+                g = torch.ones(B) if gamma == "constant" else torch.sqrt(t_ref / (t_ref ** 2 + (1 - t_ref) ** 2))
+                assert torch.allclose(coef, (1 - t_ref) / t_ref * g)
+
+
+def test_bench_helpers():
+    import bench
+    n = bench.usable_cores()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    a = bench.det_image((2, 3, 16, 16), 5)
+    assert a.shape == (2, 3, 16, 16) and float(a.min()) >= -1.0 and float(a.max()) <= 1.0
+    assert torch.equal(a, bench.det_image((2, 3, 16, 16), 5))

@@ -373,7 +373,8 @@ hipError_t launch_conv(const ConvParams& p, int stride, int up, hipStream_t stre
         if (stride != 1 || up) return hipErrorInvalidValue;
     }
     bool all_1tap = true;
-    for (int i = 0; i < p.nseg; ++i) all_1tap &= p.seg[i].taps == 1 && p.seg[i].C >= 64;
+    // 64-channel chunks: the generic operand clamps its k index, the packed weights end at C/16 slices and need whole chunks
+    for (int i = 0; i < p.nseg; ++i) all_1tap &= p.seg[i].taps == 1 && (generic ? p.seg[i].C >= 64 : p.seg[i].C % 64 == 0);
     if (all_1tap && stride == 1 && !up) return generic ? launch_sel<1, 0, 1, 64>(p, stream) : launch_sel<1, 0, 0, 64>(p, stream);
     if (generic) return launch_sel<1, 0, 1, 16>(p, stream);
     if (stride == 2) return launch_sel<2, 0, 0, 16>(p, stream);

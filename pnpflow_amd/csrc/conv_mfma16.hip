@@ -424,7 +424,7 @@ hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t st
     bool all_1tap = true;
     for (int i = 0; i < p.nseg; ++i) {
         if (p.seg[i].w_mode != 0 || p.seg[i].w16 == nullptr) return hipErrorInvalidValue;
-        all_1tap &= p.seg[i].taps == 1 && p.seg[i].C >= 64;
+        all_1tap &= p.seg[i].taps == 1 && p.seg[i].C % 64 == 0;    // 64-channel chunks need whole chunks: the packed weights end at C/16 slices
     }
     static const int kc_pref = getenv("PNPFLOW_HIP_KC") ? atoi(getenv("PNPFLOW_HIP_KC")) : 32;
     static const int kc_l0 = getenv("PNPFLOW_HIP_KC_L0") ? atoi(getenv("PNPFLOW_HIP_KC_L0")) : 32;   // 32-channel layers: one 32-channel chunk reads whole 128-B pixel rows (16-channel chunks: same time, +40 % HBM reads - PMC, profiles/)

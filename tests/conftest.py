@@ -42,6 +42,10 @@ CFGS = {
     "tiny4": dict(input_channels=3, input_height=64, ch=32, ch_mult=(1, 2, 4, 8), num_res_blocks=1, attn_resolutions=(16, 8)),
     "celeba128": dict(input_channels=3, input_height=128, ch=32, ch_mult=(1, 2, 4, 8), num_res_blocks=6, attn_resolutions=(16, 8)),
     "afhq256": dict(input_channels=3, input_height=256, ch=32, ch_mult=(1, 2, 4, 8), num_res_blocks=6, attn_resolutions=(16, 8)),
+    # shapes the BASELINE nets never produce: ragged tiles at every level (48 -> 24 -> 12 px), equal widths at two levels,
+    # attention with 144 tokens (unfused path) at 64 channels, a 1-channel image with three levels
+    "odd48": dict(input_channels=3, input_height=48, ch=32, ch_mult=(1, 2, 2), num_res_blocks=2, attn_resolutions=(12,)),
+    "gray40": dict(input_channels=1, input_height=40, ch=32, ch_mult=(1, 1, 4), num_res_blocks=1, attn_resolutions=(20, 10)),
 }
 
 

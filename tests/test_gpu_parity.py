@@ -201,6 +201,25 @@ def test_unet_forward_matches_oracle_and_golden(hip, golden, name, B, precision)
         np.testing.assert_allclose(checksums(out), g["out_checksum"], rtol=2e-4)
 
 
+@pytest.mark.parametrize("net,B", [("odd48", 5), ("gray40", 3)])
+@pytest.mark.parametrize("precision", [0, 1])
+def test_unet_forward_unusual_shapes_match_oracle(hip, net, B, precision):
+    """Architectures outside the BASELINE family (ragged tiles at every level, odd batch, attention on 144 / 400 / 100 tokens,
+    1-channel input), forward and input-gradient VJP against the oracle."""
+    m, cfg, sd = model_for(net)
+    m.set_precision(precision)
+    S, Cc = cfg["input_height"], cfg["input_channels"]
+    x = det_normal((B, Cc, S, S), 91); t = torch.linspace(0.05, 0.95, B); vec = det_normal((B, Cc, S, S), 92)
+    with torch.no_grad():
+        ref = O.unet_forward(sd, cfg, x, t)
+    np.testing.assert_allclose(m(x.cuda(), t.cuda()).cpu().numpy(), ref.numpy(), atol=2e-4)
+    v, g = m.vjp(x.cuda(), t.cuda(), vec.cuda())
+    gref = O.unet_vjp(sd, cfg, x, t, vec)
+    np.testing.assert_allclose(v.cpu().numpy(), ref.numpy(), atol=2e-4)
+    np.testing.assert_allclose(g.cpu().numpy(), gref.numpy(), atol=3e-4 * float(gref.abs().max()))
+    m.set_precision(1)
+
+
 @pytest.mark.parametrize("T,Cc", [(256, 256), (256, 128), (128, 256), (128, 128)])
 def test_fused_attention_core_matches_bmm_softmax_bmm(hip, T, Cc):
     """pf_attention_core vs the reference's formulation (models.py:152-158: bmm, * C**-0.5, softmax(dim=-1), bmm) in fp64

@@ -149,7 +149,8 @@ int pf_psnr(const float* rec, const float* clean, float* out, int B, int n_per_i
 /* ---- attention core -------------------------------------------------------------------- */
 /* out[B,T,C] = softmax(q k^T * C^-1/2, dim=-1) v for q|k|v stacked as qkv[B,T,3C] (fp32, token-major): the bmm /
  * softmax / bmm of SelfAttention.forward (pnpflow/models.py:152-158) in one launch, split-f16 MFMA (fp32-equivalent).
- * Shapes: T in {128, 256}, C in {128, 256}; anything else returns PF_ERR_INVALID (the engine then uses three launches). */
+ * Shapes: T in {128, 256, 512, 768, ... 4096}, C in {128, 256}; anything else returns PF_ERR_INVALID (the engine then
+ * uses three launches). */
 int pf_attention_core(const float* qkv, float* out, int B, int T, int C, void* stream);
 
 /* ---- vector-Jacobian product (OT-ODE) ------------------------------------------------ */

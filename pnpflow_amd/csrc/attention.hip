@@ -12,7 +12,8 @@
 //            hi+lo A fragments (over the query block, which is no longer needed);
 //   phase 3  v is read straight from L2 (for a fixed key the 32 lanes of a fragment column are 128 contiguous bytes),
 //            split in registers three steps ahead of its use; each wave accumulates O for its C/4 channels.
-// Shapes: T = 128*TK, C = 128*TC with TK, TC in {1, 2}; everything else stays on the unfused path (engine.hip).
+// Shapes: T = 128*TK, C = 128*TC with TK, TC in {1, 2}, plus T = 512 ... 4096 in steps of 256 through the key-blocked
+// variant at the end of this file; everything else stays on the unfused path (engine.hip).
 #include "pf_common.h"
 
 namespace pf {
@@ -207,6 +208,188 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
         }
 }
 
+// Long-sequence variant (T a multiple of 256 above 256: the 1024-token attention block of the 256x256 nets).  The keys are
+// walked in blocks of 256 with an online softmax: per block S = q k^T (as above), the running row maximum m and row sum l
+// are updated, P = exp(S - m) stays unnormalised, the accumulated output is rescaled by exp(m_old - m_new) and O += P v;
+// the division by l happens once at the end.  The query block is re-staged per key block (P overwrites it in LDS).
+template <int TC>
+__global__ __launch_bounds__(256) void attn_fused_long_kernel(const AttnParams p) {
+    constexpr int TB = 256, TK = 2, C = 128 * TC, BQ = 32;      // keys per block: 2 tiles of 32 per wave
+    constexpr int QROW = C + 4, PROW = TB + 4, AROW = QROW > PROW ? QROW : PROW, KROW = 36, SROW = TB + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint32_t* s_a = reinterpret_cast<uint32_t*>(smem_raw);           // [BQ][AROW]: q fragments, then P fragments (per key block)
+    uint32_t* s_k = s_a + BQ * AROW;                                  // [TB][KROW] : k chunk
+    float* s_s = reinterpret_cast<float*>(s_k);                       // [BQ][SROW] : scores, aliases the k chunk
+    float* s_scale = reinterpret_cast<float*>(s_k + TB * KROW);       // [BQ]       : per-row rescale / final 1/l
+    const int T = p.T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int nqb = T / BQ;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int b = (slot / nqb) * 8 + xcd, q0 = (slot % nqb) * BQ;       // all query blocks of an image on one XCD (see above)
+    if (b >= p.B) return;
+    const float* base = p.qkv + (size_t)b * T * 3 * C;
+
+    constexpr int K_PER = TB * 8 / 256, NCH = C / 32;
+    float4 rka[K_PER], rkb[K_PER];
+    f32x16 acc_o[TC];
+#pragma unroll
+    for (int nt = 0; nt < TC; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[nt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;                             // of row tid>>3 (the 8 threads of a row hold copies)
+
+    for (int kb = 0; kb < T / TB; ++kb) {
+        const float* kbase = base + (size_t)kb * TB * 3 * C;          // keys / values of this block
+        auto k_prefetch = [&](int chunk, float4 (&rk)[K_PER]) {
+#pragma unroll
+            for (int i = 0; i < K_PER; ++i) {
+                const int idx = tid + i * 256, key = idx >> 3, c4 = idx & 7;
+                rk[i] = *reinterpret_cast<const float4*>(kbase + (size_t)key * 3 * C + C + min(chunk, NCH - 1) * 32 + c4 * 4);
+            }
+        };
+        k_prefetch(0, rka); k_prefetch(1, rkb);
+        // query block -> LDS (every wave is past the previous block's P: barrier at the end of the loop body)
+#pragma unroll
+        for (int i = 0; i < BQ * (C / 4) / 256; ++i) {
+            const int idx = tid + i * 256, row = idx / (C / 4), c4 = idx % (C / 4);
+            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)(q0 + row) * 3 * C + c4 * 4);
+            f16x4 h, l; split4(v, h, l);
+            *reinterpret_cast<f16x4*>(s_a + row * QROW + c4 * 2) = h;
+            *reinterpret_cast<f16x4*>(s_a + row * QROW + C / 2 + c4 * 2) = l;
+        }
+        f32x16 acc_s[TK];
+#pragma unroll
+        for (int nt = 0; nt < TK; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_s[nt][r] = 0.f;
+        auto k_chunk = [&](int chunk, float4 (&rk)[K_PER]) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < K_PER; ++i) {
+                const int idx = tid + i * 256, key = idx >> 3, c4 = idx & 7;
+                f16x4 h, l; split4(rk[i], h, l);
+                *reinterpret_cast<f16x4*>(s_k + key * KROW + c4 * 2) = h;
+                *reinterpret_cast<f16x4*>(s_k + key * KROW + 16 + c4 * 2) = l;
+            }
+            __syncthreads();
+            k_prefetch(chunk + 2, rk);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = chunk * 2 + jj;
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(s_a + l31 * QROW + j * 8 + hi * 4);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(s_a + l31 * QROW + C / 2 + j * 8 + hi * 4);
+#pragma unroll
+                for (int nt = 0; nt < TK; ++nt) {
+                    const int krow = (wave * TK + nt) * 32 + l31;
+                    const f16x8 bh = *reinterpret_cast<const f16x8*>(s_k + krow * KROW + jj * 8 + hi * 4);
+                    const f16x8 bl = *reinterpret_cast<const f16x8*>(s_k + krow * KROW + 16 + jj * 8 + hi * 4);
+                    acc_s[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc_s[nt], 0, 0, 0);
+                    acc_s[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc_s[nt], 0, 0, 0);
+                    acc_s[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc_s[nt], 0, 0, 0);
+                }
+            }
+        };
+        for (int chunk = 0; chunk < NCH; chunk += 2) { k_chunk(chunk, rka); k_chunk(chunk + 1, rkb); }
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < TK; ++nt) {
+            const int col = (wave * TK + nt) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_s[((r & 3) + 8 * (r >> 2) + 4 * hi) * SROW + col] = acc_s[nt][r] * p.scale;
+        }
+        // the first three v fragments of this key block leave before the softmax update
+        const float* vbase = kbase + 2 * C + wave * TC * 32 + l31;
+        auto load_v = [&](int j, float (&dst)[TC][8]) {
+#pragma unroll
+            for (int nt = 0; nt < TC; ++nt)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dst[nt][i] = vbase[(size_t)(j * 16 + hi * 8 + i) * 3 * C + nt * 32];
+        };
+        float v0[TC][8], v1[TC][8], v2[TC][8], v3[TC][8];
+        load_v(0, v0); load_v(1, v1); load_v(2, v2);
+        __syncthreads();
+        {   // online softmax update of row tid>>3
+            const int row = tid >> 3, part = tid & 7;
+            float4 x[TB / 32];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < TB / 32; ++i) {
+                x[i] = *reinterpret_cast<const float4*>(s_s + row * SROW + (i * 8 + part) * 4);
+                mx = fmaxf(fmaxf(mx, fmaxf(x[i].x, x[i].y)), fmaxf(x[i].z, x[i].w));
+            }
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            const float m_new = fmaxf(m_run, mx);
+            const float sc = expf(m_run - m_new);                    // 0 on the first block (m_run = -inf)
+            float sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < TB / 32; ++i) {
+                x[i].x = expf(x[i].x - m_new); x[i].y = expf(x[i].y - m_new); x[i].z = expf(x[i].z - m_new); x[i].w = expf(x[i].w - m_new);
+                sm += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+            }
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+            l_run = l_run * sc + sm; m_run = m_new;
+            if (part == 0) s_scale[row] = sc;
+#pragma unroll
+            for (int i = 0; i < TB / 32; ++i) {
+                f16x4 h, l; split4(x[i], h, l);
+                const int k2 = (i * 8 + part) * 2;
+                *reinterpret_cast<f16x4*>(s_a + row * PROW + k2) = h;
+                *reinterpret_cast<f16x4*>(s_a + row * PROW + TB / 2 + k2) = l;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < TC; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[nt][r] *= s_scale[(r & 3) + 8 * (r >> 2) + 4 * hi];
+        auto v_step = [&](int j, float (&cur)[TC][8], float (&nxt)[TC][8]) {
+            load_v(min(j + 3, TB / 16 - 1), nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            const f16x8 ph = *reinterpret_cast<const f16x8*>(s_a + l31 * PROW + j * 8 + hi * 4);
+            const f16x8 pl = *reinterpret_cast<const f16x8*>(s_a + l31 * PROW + TB / 2 + j * 8 + hi * 4);
+#pragma unroll
+            for (int nt = 0; nt < TC; ++nt) {
+                f16x8 vh, vl;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { vh[i] = (_Float16)cur[nt][i]; vl[i] = (_Float16)(cur[nt][i] - (float)vh[i]); }
+                acc_o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, acc_o[nt], 0, 0, 0);
+                acc_o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, acc_o[nt], 0, 0, 0);
+                acc_o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, acc_o[nt], 0, 0, 0);
+            }
+        };
+        for (int j = 0; j + 4 <= TB / 16; j += 4) { v_step(j, v0, v3); v_step(j + 1, v1, v0); v_step(j + 2, v2, v1); v_step(j + 3, v3, v2); }
+        __syncthreads();                                              // P and s_scale are free for the next key block
+    }
+    if ((tid & 7) == 0) s_scale[tid >> 3] = 1.0f / l_run;
+    __syncthreads();
+    float* obase = p.out + ((size_t)b * T + q0) * C + wave * TC * 32 + l31;
+#pragma unroll
+    for (int nt = 0; nt < TC; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            obase[(size_t)row * C + nt * 32] = acc_o[nt][r] * s_scale[row];
+        }
+}
+
+template <int TC>
+hipError_t launch_attn_long_cfg(const AttnParams& p, hipStream_t s) {
+    constexpr int C = 128 * TC;
+    constexpr int AROW = (C > 256 ? C : 256) + 4;
+    const size_t lds = (size_t)(32 * AROW + 256 * 36 + 32) * 4;
+    static bool attr_set = false;
+    auto kern = attn_fused_long_kernel<TC>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((p.T / 32) * ((p.B + 7) / 8) * 8), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
 template <int TK, int TC>
 hipError_t launch_attn_cfg(const AttnParams& p, hipStream_t s) {
     constexpr int T = 128 * TK, C = 128 * TC;
@@ -226,10 +409,11 @@ hipError_t launch_attn_cfg(const AttnParams& p, hipStream_t s) {
 
 }  // namespace
 
-bool attn_fused_supported(int T, int C) { return (T == 128 || T == 256) && (C == 128 || C == 256); }
+bool attn_fused_supported(int T, int C) { return (T == 128 || (T >= 256 && T % 256 == 0 && T <= 4096)) && (C == 128 || C == 256); }
 
 hipError_t launch_attn_fused(const AttnParams& p, hipStream_t s) {
     if (!attn_fused_supported(p.T, p.C)) return hipErrorInvalidValue;
+    if (p.T > 256) return p.C == 256 ? launch_attn_long_cfg<2>(p, s) : launch_attn_long_cfg<1>(p, s);     // online softmax over key blocks
     if (p.T == 256) return p.C == 256 ? launch_attn_cfg<2, 2>(p, s) : launch_attn_cfg<2, 1>(p, s);
     return p.C == 256 ? launch_attn_cfg<1, 2>(p, s) : launch_attn_cfg<1, 1>(p, s);
 }

@@ -109,6 +109,11 @@ __global__ __launch_bounds__(256, ((MT == 4 && WM == 2 && KC == 16) ? 3 : 1)) vo
                     }
                 }
                 if (!(cok && a_pix[i] >= 0)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                // opaque to the optimiser: the hi that is stored and the hi that is subtracted must be the SAME rounding of
+                // the SAME fp32 value.  With -ffp-contract=fast hipcc may otherwise fuse the producing multiply into the
+                // subtraction (v_fma_mix*) while the stored hi comes from the rounded product - they differ at double-rounding
+                // ties (this happened in attention.hip; here the select above currently prevents it, this keeps it that way)
+                asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
                 f16x4 h, l;
                 h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
                 l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);

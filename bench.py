@@ -45,6 +45,26 @@ def det_image(shape, seed):
     return ((x - lo) / (hi - lo) * 2 - 1).contiguous()
 
 
+def global_clean(dim, lo, hi, seed=1234):
+    """Images [lo, hi) of the synthetic test set: image i is det_image(seed + i) whatever the sharding, so N ranks restore
+    exactly the images a single-device run at the global batch size restores."""
+    return torch.cat([det_image((1, 3, dim, dim), seed + i) for i in range(lo, hi)])
+
+
+def shard_inputs(wl, rank, world, step=0):
+    """(lo, hi, clean, measurement noise, OT-ODE initialisation noise) of this rank's slice of the global batch world*B:
+    every batch-shaped random draw is made for the GLOBAL batch and sliced (pnpflow_amd/parallel.py)."""
+    from pnpflow_amd.parallel import global_measurement_noise, global_normal, shard_range
+    dim, B = wl["dim"], wl["B"]
+    G = world * B
+    lo, hi = shard_range(G, rank, world)
+    clean = global_clean(dim, lo, hi)
+    sf = {128: 2, 256: 4}.get(dim, 2) if wl["problem"] == "superresolution" else 1
+    meas = global_measurement_noise(step, (G, 3, dim // sf, dim // sf), lo, hi)
+    init = global_normal((98, step), (G, 3, dim, dim), lo, hi) if wl.get("method") == "ot_ode" else None
+    return lo, hi, clean, meas, init
+
+
 def make_problem(D, problem, dim, global_batch=None, batch_offset=0):
     if problem == "inpainting":
         return D.BoxInpainting({64: 10, 128: 20, 256: 40}[dim]), 0.05
@@ -150,7 +170,7 @@ def main():
     model = UNet(3, dim, 32, ch_mult=(1, 2, 4, 8), num_res_blocks=wl["nres"], attn_resolutions=(16, 8), device_index=local)
     model.load_state_dict(synthetic_state_dict(model, 0))
     model.set_precision(a.precision)
-    lo, hi = shard_range(world * B, rank, world)
+    lo, hi, clean, meas_noise, init_noise = shard_inputs(wl, rank, world)
     degradation, sigma = make_problem(D, wl["problem"], dim, global_batch=world * B, batch_offset=lo)
     is_ode = wl.get("method") == "ot_ode"
 
@@ -161,18 +181,16 @@ def main():
     if is_ode:
         from pnpflow_amd.methods.ot_ode import OT_ODE
         solver = OT_ODE(model, dev, args)
-        gen0 = np.random.Generator(np.random.Philox(key=[98, rank]))
-        solver.init_noise = torch.from_numpy(gen0.standard_normal(size=(B, 3, dim, dim), dtype=np.float32)).to(dev)
+        solver.init_noise = init_noise.to(dev)
     else:
         solver = PNP_FLOW(model, dev, args)
         solver.use_graph = not a.no_graph
-        solver.noise_seed = 2024
+        solver.noise_seed = 2024          # one Philox key for the job; the shard draws ITS slice of every global noise tensor:
+        solver.image_offset = lo          # pf_pnp_params.elem_offset = lo*C*H*W
 
-    # synthetic batch of this rank (global batch = world*B, rank r owns [r*B, (r+1)*B)), resident in HBM
-    clean = det_image((B, 3, dim, dim), 1234 + rank).to(dev)
-    gen = np.random.Generator(np.random.Philox(key=[99, rank]))
-    y = degradation.H(clean)
-    y = y + sigma * torch.from_numpy(gen.standard_normal(size=tuple(y.shape), dtype=np.float32)).to(dev)
+    # synthetic batch of this rank (global batch = world*B, rank r owns images [lo, hi)), resident in HBM
+    clean = clean.to(dev)
+    y = degradation.H(clean) + sigma * meas_noise.to(dev)
     lr = sigma ** 2 * 1.0
 
     def step(i):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 1
+#define PF_ABI_VERSION 2
 
 typedef enum pf_status {
     PF_OK = 0,
@@ -141,10 +141,20 @@ int pf_denoise_accumulate(float* acc, const float* z_tilde, const float* v, cons
                           float num_samples, int B, int n_per_image, void* stream);
 /* fills out[n] with engine normals (the same generator pf_interpolate uses). */
 int pf_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream);
+/* the same, starting at normal number `elem_offset` of the stream: out[i] = normal number elem_offset + i.  A shard of a
+ * multi-GPU run that owns images [lo, hi) of the global batch draws elem_offset = lo*C*H*W, i.e. exactly the numbers a
+ * single-device run at the global batch size draws for those images (replaces the one torch.randn_like(x) over the whole
+ * batch of interpolation_step, pnpflow/methods/pnp_flow.py:47-48, when the batch is split over GPUs). */
+int pf_fill_normal_at(float* out, int64_t n, uint64_t seed, uint64_t stream_id, uint64_t elem_offset, void* stream);
 
 /* per-image PSNR of postprocess(rec) vs postprocess(clean), data_range 1
  * (pnpflow/utils.py:560-577, 594-611) -> out[B] (device). */
 int pf_psnr(const float* rec, const float* clean, float* out, int B, int n_per_image, void* stream);
+
+/* per-image SSIM of postprocess(rec) vs postprocess(clean): ignite.metrics.SSIM(data_range=1.0) as the reference calls it
+ * (pnpflow/utils.py:780-802) - 11x11 Gaussian window sigma 1.5, k1 0.01, k2 0.03, reflect padding, mean over (C,H,W) in
+ * fp64 -> out[B] (device, double).  H, W > 5.  PARITY UNPINNED: ignite is absent from the build container. */
+int pf_ssim(const float* rec, const float* clean, double* out, int B, int C, int H, int W, void* stream);
 
 /* ---- attention core -------------------------------------------------------------------- */
 /* out[B,T,C] = softmax(q k^T * C^-1/2, dim=-1) v for q|k|v stacked as qkv[B,T,3C] (fp32, token-major): the bmm /
@@ -185,6 +195,11 @@ typedef struct pf_pnp_params {
     int32_t use_graph;        /* capture one outer iteration in a hipGraph and replay it */
     int32_t noise_model;      /* 0 gaussian (pf_grad_step), 1 laplace (pf_grad_step_laplace) */
     int32_t batch_samples;    /* evaluate the num_samples velocities of an iteration as one U-Net pass over num_samples*B images */
+    int32_t reserved0;
+    uint64_t elem_offset;     /* first normal number of this shard inside every (iteration, sample) noise stream: lo*C*H*W for the
+                                 shard that owns images [lo, hi) of a global batch (0 for a single-device run); see pf_fill_normal_at */
+    const uint8_t* host_cb_mask; /* optional host [steps]: iter_cb is called (stream synchronised) only after iterations with a non-zero
+                                 entry - the reference's logging iterations, pnp_flow.py:128-139; NULL = after every iteration */
 } pf_pnp_params;
 
 /* Runs pnp_flow.py:93 and 102-121 for one batch:  x0 = H_adj(1);  `steps` iterations.
@@ -194,6 +209,10 @@ typedef void (*pf_iter_callback)(int iteration, void* user);
 int pf_pnp_flow_restore(pf_engine* e, const pf_degradation* d, const pf_pnp_params* prm,
                         const float* y, float* x_out, int B, void* stream,
                         pf_iter_callback iter_cb, void* user);
+
+/* device bytes currently held by the engine (weights, activation plans, solver buffers): what torch.cuda.max_memory_allocated
+ * cannot see of the reference's `compute_memory` bookkeeping (pnpflow/methods/pnp_flow.py:99-100, 141-146). */
+int64_t pf_engine_memory_bytes(const pf_engine* e);
 
 /* kernel-time accounting for bench.py: enables HIP-event timing of the U-Net conv-GEMM
  * launches on `stream`; read back accumulated (count, milliseconds). */

@@ -4,9 +4,15 @@
 
 Three YAML layers (main -> dataset -> method) then `--opts k v ...` (applied twice, as the
 reference does), `args.dict_cfg_method` naming the results directory.  The restoration
-runs on the HIP engine; datasets and checkpoints are not reachable offline, so when the
-dataset folder / checkpoint is absent the run uses synthetic images / synthetic weights
-and says so.
+runs on the HIP engine.  Like the reference, the run FAILS when the checkpoint
+(`model/<dataset>/<model>/model_final.pt`) or the dataset folder (`data/<dataset>/...`,
+pnpflow_amd/dataloaders.py) is missing; `--opts synthetic True` is the explicit opt-in to
+seed-fixed synthetic weights / images (smoke runs without the downloads) and writes under
+`results_synthetic*/` so that such numbers can never mix with real ones.
+
+Multi-GPU: `torchrun --nproc-per-node N main.py --opts ...` - one process per GPU, every
+rank restores its contiguous slice of each test batch, one all_gather of per-image metrics
+per logging point, rank 0 writes the reference's result files (pnpflow_amd/parallel.py).
 """
 import argparse
 import os
@@ -71,32 +77,52 @@ class SyntheticLoader:
 
 def main():
     args = parse_args()
-    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-    print("device", device)
+    from pnpflow_amd import parallel
+    rank, world, local = parallel.init_from_env()
+    device = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
+    if rank == 0:
+        print("device", device, f"(rank {rank}/{world})" if world > 1 else "")
     if device.type != "cuda":
         raise SystemExit("pnpflow_amd needs an MI355X (there is no CPU path)")
     if args.seed is not None:
         random.seed(args.seed); torch.manual_seed(args.seed); np.random.seed(args.seed)
+    from pnpflow_amd.dataloaders import DataLoaders
     from pnpflow_amd.methods.pnp_flow import PNP_FLOW
     from pnpflow_amd.utils import define_model, load_model
 
+    synthetic = bool(getattr(args, "synthetic", False))
+    args.device_index = local
     (model, state) = define_model(args)
     if args.eval:
         model_path = args.output_root + 'model/{}/{}/model_final.pt'.format(args.dataset, args.model)
         if os.path.isfile(model_path):
             load_model(args.model, model, state, download=False, checkpoint_path=model_path, dataset=None, device=device)
-        else:
-            print(f"[pnpflow_amd] checkpoint {model_path} not found: using SYNTHETIC weights (PSNR is not meaningful)")
+        elif synthetic:
+            print(f"[pnpflow_amd] synthetic=True: checkpoint {model_path} not found, using SYNTHETIC weights (metrics are not meaningful)")
             from tools.synthetic_weights import synthetic_state_dict
             model.load_state_dict(synthetic_state_dict(model))
+        else:
+            raise FileNotFoundError(f"{model_path} not found (the reference's checkpoint, download.sh). "
+                                    "Pass `--opts synthetic True` to run on seed-fixed synthetic weights instead.")
         model.eval()
         degradation, sigma_noise = make_degradation(args.problem, args.dim_image, args.num_channels, args.noise_type, device)
-        print('Solving the {} inverse problem with the method {}...'.format(args.problem, args.method))
-        print('sigma_noise', sigma_noise)
-        print("[pnpflow_amd] dataset readers are out of scope offline: using synthetic clean images")
-        loaders = {s: SyntheticLoader(args.batch_size_ip, args.num_channels, args.dim_image, args.max_batch) for s in ('train', 'val', 'test')}
-        args.save_path = os.path.join(args.output_root, 'results_laplace' if args.noise_type == 'laplace' else 'results', args.dataset, args.model,
-                                      args.problem, args.method, args.eval_split)
+        if rank == 0:
+            print('Solving the {} inverse problem with the method {}...'.format(args.problem, args.method))
+            print('sigma_noise', sigma_noise)
+        dl = DataLoaders(args.dataset, args.batch_size_ip, args.batch_size_ip, root=args.root)
+        if dl.available(args.eval_split):
+            loaders = dl.load_data()
+            data_synthetic = False
+        elif synthetic:
+            print(f"[pnpflow_amd] synthetic=True: dataset files {dl.paths()} not found, using SYNTHETIC clean images")
+            loaders = {s: SyntheticLoader(args.batch_size_ip, args.num_channels, args.dim_image, args.max_batch) for s in ('train', 'val', 'test')}
+            data_synthetic = True
+        else:
+            raise FileNotFoundError(f"dataset files {dl.paths()} not found. Pass `--opts synthetic True` to run on synthetic images instead.")
+        results = 'results_laplace' if args.noise_type == 'laplace' else 'results'
+        if data_synthetic or not os.path.isfile(model_path):
+            results = results.replace('results', 'results_synthetic')        # never mixes with real-data / real-weight results
+        args.save_path = os.path.join(args.output_root, results, args.dataset, args.model, args.problem, args.method, args.eval_split)
         os.makedirs(args.save_path, exist_ok=True)
         if args.method == 'pnp_flow':
             method = PNP_FLOW(model, device, args)
@@ -106,6 +132,10 @@ def main():
         else:
             raise ValueError("The method your entered does not exist")
         method.run_method(loaders, degradation, sigma_noise)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

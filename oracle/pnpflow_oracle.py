@@ -477,6 +477,27 @@ def psnr_per_image(rec: torch.Tensor, clean: torch.Tensor) -> torch.Tensor:
     return 10.0 * torch.log10(1.0 / mse)
 
 
+def ssim_per_image(rec: torch.Tensor, clean: torch.Tensor) -> torch.Tensor:
+    """SSIM of postprocess(rec) vs postprocess(clean) per image as ignite.metrics.SSIM(data_range=1.0) computes it for the
+    reference (pnpflow/utils.py:780-802): 11x11 Gaussian window (sigma 1.5), k1 0.01, k2 0.03, reflect padding, per-channel
+    filtering of [x, y, x*x, y*y, x*y], map averaged over (C,H,W) in float64.  PARITY UNPINNED: ignite is not installed in
+    the build container; this follows ignite's published algorithm (ignite/metrics/ssim.py, update())."""
+    x, y = postprocess(rec).float(), postprocess(clean).float()
+    C = x.shape[1]
+    k = torch.linspace(-5.0, 5.0, steps=11)
+    g = torch.exp(-0.5 * (k / 1.5).pow(2)); g = g / g.sum()
+    kernel = (g.unsqueeze(1) @ g.unsqueeze(0)).expand(C, 1, 11, 11)
+    c1, c2 = (0.01 * 1.0) ** 2, (0.03 * 1.0) ** 2
+    xp = torch.nn.functional.pad(x, [5, 5, 5, 5], mode="reflect"); yp = torch.nn.functional.pad(y, [5, 5, 5, 5], mode="reflect")
+    outs = torch.nn.functional.conv2d(torch.cat([xp, yp, xp * xp, yp * yp, xp * yp]), kernel, groups=C)
+    B = x.shape[0]
+    o = [outs[i * B:(i + 1) * B] for i in range(5)]
+    mxx, myy, mxy = o[0].pow(2), o[1].pow(2), o[0] * o[1]
+    sxx, syy, sxy = o[2] - mxx, o[3] - myy, o[4] - mxy
+    a1, a2, b1, b2 = 2 * mxy + c1, 2 * sxy + c2, mxx + myy + c1, sxx + syy + c2
+    return torch.mean((a1 * a2) / (b1 * b2), (1, 2, 3), dtype=torch.float64)
+
+
 def psnr_batch(rec: torch.Tensor, clean: torch.Tensor) -> float:
     """torchmetrics default reduction 'elementwise_mean' over the per-image values."""
     return float(psnr_per_image(rec, clean).mean())
@@ -507,20 +528,23 @@ def philox4x32_10(ctr: np.ndarray, key: np.ndarray) -> np.ndarray:
     return c
 
 
-def engine_normal(n: int, seed: int, stream: int) -> np.ndarray:
-    """n standard normals: element 4q+j comes from Philox counter (q, 0, stream_lo, stream_hi),
-    key (seed_lo, seed_hi); u = (r + 0.5) * 2^-32; Box-Muller pairs (0,1) and (2,3):
-    z0 = sqrt(-2 ln u0) cos(2 pi u1), z1 = sqrt(-2 ln u0) sin(2 pi u1)."""
-    nq = (n + 3) // 4
+def engine_normal(n: int, seed: int, stream: int, offset: int = 0) -> np.ndarray:
+    """normal numbers [offset, offset+n) of the stream: number 4q+j comes from Philox counter (q_lo, q_hi, stream_lo,
+    stream_hi), key (seed_lo, seed_hi); u = (r + 0.5) * 2^-32; Box-Muller pairs (0,1) and (2,3):
+    z0 = sqrt(-2 ln u0) cos(2 pi u1), z1 = sqrt(-2 ln u0) sin(2 pi u1).  `offset` = a shard's first element of the
+    global batch's flat noise tensor (pf_pnp_params.elem_offset)."""
+    q_lo = offset // 4
+    nq = (offset + n + 3) // 4 - q_lo
     ctr = np.zeros((nq, 4), dtype=np.uint32)
-    ctr[:, 0] = np.arange(nq, dtype=np.uint64).astype(np.uint32)
+    qs = np.arange(q_lo, q_lo + nq, dtype=np.uint64)
+    ctr[:, 0] = (qs & np.uint64(0xFFFFFFFF)).astype(np.uint32); ctr[:, 1] = (qs >> np.uint64(32)).astype(np.uint32)
     ctr[:, 2] = np.uint32(stream & 0xFFFFFFFF); ctr[:, 3] = np.uint32((stream >> 32) & 0xFFFFFFFF)
     r = philox4x32_10(ctr, np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint32))
     u = (r.astype(np.float64) + 0.5) * (2.0 ** -32)
     rad0, rad1 = np.sqrt(-2.0 * np.log(u[:, 0])), np.sqrt(-2.0 * np.log(u[:, 2]))
     a0, a1 = 2.0 * np.pi * u[:, 1], 2.0 * np.pi * u[:, 3]
     z = np.stack([rad0 * np.cos(a0), rad0 * np.sin(a0), rad1 * np.cos(a1), rad1 * np.sin(a1)], axis=1)
-    return z.reshape(-1)[:n].astype(np.float32)
+    return z.reshape(-1)[offset - 4 * q_lo:offset - 4 * q_lo + n].astype(np.float32)
 
 
 # --------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PNPFLOW_HIP_LIB") or os.path.join(_HERE, "libpnpflow_hip.so")   # override: A/B builds of the kernels
 
-PF_ABI_VERSION = 1
+PF_ABI_VERSION = 2
 
 PF_DEG_DENOISING, PF_DEG_BOX_INPAINTING, PF_DEG_MASK_INPAINTING, PF_DEG_SUPERRESOLUTION, PF_DEG_GAUSSIAN_BLUR, PF_DEG_SR_FILTERED = range(6)
 
@@ -32,7 +32,8 @@ class PfDegradation(C.Structure):
 class PfPnpParams(C.Structure):
     _fields_ = [("steps", C.c_int32), ("num_samples", C.c_int32), ("host_t", C.POINTER(C.c_float)),
                 ("host_coef", C.POINTER(C.c_float)), ("seed", C.c_uint64), ("stream_base", C.c_uint64),
-                ("noise", C.c_void_p), ("use_graph", C.c_int32), ("noise_model", C.c_int32), ("batch_samples", C.c_int32)]
+                ("noise", C.c_void_p), ("use_graph", C.c_int32), ("noise_model", C.c_int32), ("batch_samples", C.c_int32),
+                ("reserved0", C.c_int32), ("elem_offset", C.c_uint64), ("host_cb_mask", C.c_void_p)]
 
 
 ITER_CB = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
@@ -66,9 +67,12 @@ SIGNATURES = {
     "pf_interpolate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "pf_denoise_accumulate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "pf_fill_normal": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "pf_fill_normal_at": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "pf_attention_core": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pf_psnr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pf_ssim": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pf_pnp_flow_restore": (C.c_int, [C.c_void_p, C.POINTER(PfDegradation), C.POINTER(PfPnpParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, ITER_CB, C.c_void_p]),
+    "pf_engine_memory_bytes": (C.c_int64, [C.c_void_p]),
     "pf_engine_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "pf_engine_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

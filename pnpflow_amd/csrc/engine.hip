@@ -67,6 +67,8 @@ struct Tap { std::string name; Tensor t; };
 
 struct Plan {
     int B = 0;
+    uint64_t last_used = 0;
+    int64_t bytes = 0;               // device bytes of this plan's activation buffers + statistics slab
     std::vector<Op> ops;
     std::vector<void*> allocs;
     std::vector<Tap> taps;
@@ -82,7 +84,10 @@ struct Plan {
 
 struct SolverBufs {
     int B = 0; size_t n = 0, ny = 0; int steps = 0, ns = 0;
-    float *x = nullptr, *z = nullptr, *zt = nullptr, *v = nullptr, *scratch = nullptr;
+    float *x = nullptr, *z = nullptr, *zt = nullptr, *v = nullptr, *scratch = nullptr, *y = nullptr;
+    unsigned long long* rng = nullptr;       // device [seed, stream_base, elem_offset]: read by the interpolation kernel, so that one
+                                             // captured graph serves every batch / shard
+    int64_t bytes = 0;
     float *t_all = nullptr, *coef_all = nullptr, *t_cur = nullptr, *coef_cur = nullptr;
     int* iter = nullptr;
 };
@@ -108,7 +113,14 @@ struct pf_engine {
     std::map<std::string, int> temb_off;   // ResBlock prefix -> offset in the stacked temb projection
     std::map<int, std::unique_ptr<Plan>> plans;
     Plan* last_plan = nullptr;       // plan of the most recent forward (activation taps are read from it)
+    Plan* retained_plan = nullptr;   // plan of the most recent pf_unet_forward_retain (pf_unet_backward must walk the same one)
     int retained_B = 0;
+    uint64_t plan_clock = 0;         // LRU stamp source for the plan cache
+    int64_t bytes = 0;               // device bytes currently held by this engine (weights, activation plans, solver buffers)
+    // cached hipGraph of one PnP-Flow outer iteration (re-used while the captured arguments stay the same)
+    struct GraphKey { const void* plan; int kind, half, sf, ntaps; const void* mask; const void* taps; const void* noise;
+                      int num_samples, batch_samples, noise_model, B; };
+    GraphKey gkey{}; hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
     int precision = 1;   // 1 (default): split-fp16 (3 x f16 MFMA, fp32-equivalent) for the packed-weight convs; 0: exact fp32 MFMA
     SolverBufs sb;
     hipStream_t work_stream = nullptr;   // used when the caller passes the NULL stream and asks for graph replay
@@ -123,6 +135,14 @@ struct pf_engine {
 };
 
 static thread_local std::string g_create_err;
+
+// selects the engine's device for the duration of an ABI call and restores the caller's current device afterwards
+struct DeviceGuard {
+    int prev = -1; hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; err = hipSetDevice(dev); }
+    ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
+};
+#define USE_DEVICE(e) DeviceGuard _dg((e)->device); HIPCHK(e, _dg.err)
 
 #define LAUNCHCHK(call)                                                        \
     do { hipError_t _r = (call); if (_r != hipSuccess) return _r == hipErrorInvalidValue ? PF_ERR_INVALID : PF_ERR_HIP; } while (0)
@@ -241,6 +261,7 @@ static float* upload(pf_engine* e, const std::string& key, const std::vector<flo
     if (it != e->dev.end()) return it->second;
     float* d = nullptr;
     if (hipMalloc(&d, std::max<size_t>(v.size(), 4) * sizeof(float)) != hipSuccess) return nullptr;
+    e->bytes += (int64_t)(std::max<size_t>(v.size(), 4) * sizeof(float));
     hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice);
     e->weight_allocs.push_back(d);
     e->dev[key] = d;
@@ -315,7 +336,7 @@ struct Builder {
         if (it != free_list.end()) { void* p = it->second; free_list.erase(it); return (float*)p; }
         void* p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) { ok = false; e->err = "hipMalloc failed (activations)"; return nullptr; }
-        plan->allocs.push_back(p); sizes[p] = bytes;
+        plan->allocs.push_back(p); sizes[p] = bytes; plan->bytes += (int64_t)bytes; e->bytes += (int64_t)bytes;
         return (float*)p;
     }
     bool keep = getenv("PNPFLOW_HIP_KEEP_ACTIVATIONS") != nullptr;   // never reuse: taps stay readable / activations retained for the VJP
@@ -515,8 +536,23 @@ static int build_backward(pf_engine* e, Plan* plan, struct Builder& bd);
 static int build_plan(pf_engine* e, int B, bool retain, Plan** out_plan) {
     const int key = (B * 2 + (retain ? 1 : 0)) * 2 + (e->precision ? 1 : 0);      // the precision mode selects kernels at build time
     auto it = e->plans.find(key);
-    if (it != e->plans.end()) { *out_plan = e->last_plan = it->second.get(); return PF_OK; }
-    auto plan = std::make_unique<Plan>(); plan->B = B; plan->retain = retain;
+    if (it != e->plans.end()) { *out_plan = e->last_plan = it->second.get(); it->second->last_used = ++e->plan_clock; return PF_OK; }
+    // bounded cache: a plan owns its activation buffers (GBs at the BASELINE sizes), so the least recently used one is
+    // dropped before a ninth is built (never the retained one a pf_unet_backward may still walk, nor the graph's)
+    while (e->plans.size() >= 8) {
+        auto victim = e->plans.end();
+        for (auto jt = e->plans.begin(); jt != e->plans.end(); ++jt) {
+            if (jt->second.get() == e->retained_plan || jt->second.get() == e->gkey.plan) continue;
+            if (victim == e->plans.end() || jt->second->last_used < victim->second->last_used) victim = jt;
+        }
+        if (victim == e->plans.end()) break;
+        hipDeviceSynchronize();
+        for (void* p : victim->second->allocs) hipFree(p);
+        e->bytes -= victim->second->bytes;
+        if (e->last_plan == victim->second.get()) e->last_plan = nullptr;
+        e->plans.erase(victim);
+    }
+    auto plan = std::make_unique<Plan>(); plan->B = B; plan->retain = retain; plan->last_used = ++e->plan_clock;
     Builder bd{e, plan.get(), B};
     if (retain) bd.keep = true;
     const pf_unet_cfg& c = e->cfg;
@@ -631,7 +667,7 @@ static int build_plan(pf_engine* e, int B, bool retain, Plan** out_plan) {
     // statistics slab
     void* slab = nullptr;
     if (hipMalloc(&slab, std::max<size_t>(bd.stats_bytes, 256)) != hipSuccess) { e->err = "hipMalloc failed (stats)"; return PF_ERR_HIP; }
-    plan->allocs.push_back(slab);
+    plan->allocs.push_back(slab); plan->bytes += (int64_t)std::max<size_t>(bd.stats_bytes, 256); e->bytes += (int64_t)std::max<size_t>(bd.stats_bytes, 256);
     for (auto& op : plan->ops) fix_stats(op, (double*)slab);
     for (auto& op : plan->bops) fix_stats(op, (double*)slab);
     for (auto& tp : plan->taps) if (tp.t.stats) tp.t.stats = (double*)((char*)slab + ((uintptr_t)tp.t.stats - 1));
@@ -1017,17 +1053,26 @@ int pf_engine_create(int device_id, const pf_unet_cfg* cfg, pf_engine** out) {
     return PF_OK;
 }
 
+static void drop_graph(pf_engine* e) {
+    if (e->gexec) hipGraphExecDestroy(e->gexec);
+    if (e->graph) hipGraphDestroy(e->graph);
+    e->gexec = nullptr; e->graph = nullptr; e->gkey = pf_engine::GraphKey{};
+}
+
 static void free_solver(pf_engine* e) {
+    drop_graph(e);          // its nodes point into the solver buffers
     SolverBufs& b = e->sb;
-    for (void* p : {(void*)b.x, (void*)b.z, (void*)b.zt, (void*)b.v, (void*)b.scratch, (void*)b.t_all, (void*)b.coef_all,
-                    (void*)b.t_cur, (void*)b.coef_cur, (void*)b.iter})
+    for (void* p : {(void*)b.x, (void*)b.z, (void*)b.zt, (void*)b.v, (void*)b.scratch, (void*)b.y, (void*)b.rng, (void*)b.t_all,
+                    (void*)b.coef_all, (void*)b.t_cur, (void*)b.coef_cur, (void*)b.iter})
         if (p) hipFree(p);
+    e->bytes -= b.bytes;
     b = SolverBufs{};
 }
 
 void pf_engine_destroy(pf_engine* e) {
     if (!e) return;
     hipSetDevice(e->device);
+    drop_graph(e);
     for (auto& kv : e->plans) for (void* p : kv.second->allocs) hipFree(p);
     for (void* p : e->weight_allocs) hipFree(p);
     for (auto& ev : e->ev_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
@@ -1074,7 +1119,7 @@ int pf_engine_finalize_weights(pf_engine* e) {
         auto it = e->host.find(ex.first);
         if (it == e->host.end() || !it->second.loaded) { e->err = "missing weight: " + ex.first; return PF_ERR_WEIGHTS; }
     }
-    HIPCHK(e, hipSetDevice(e->device));
+    USE_DEVICE(e);
     e->finalized = true;
     return PF_OK;
 }
@@ -1089,7 +1134,7 @@ int pf_engine_set_precision(pf_engine* e, int mode) {
 int pf_unet_forward(pf_engine* e, const float* x, const float* t, float* v, int B, void* stream) {
     if (!e || !x || !t || !v || B <= 0) return PF_ERR_INVALID;
     if (!e->finalized) { e->err = "weights not finalized"; return PF_ERR_STATE; }
-    HIPCHK(e, hipSetDevice(e->device));
+    USE_DEVICE(e);
     Plan* plan = nullptr;
     int rc = build_plan(e, B, false, &plan);
     if (rc != PF_OK) return rc;
@@ -1099,21 +1144,25 @@ int pf_unet_forward(pf_engine* e, const float* x, const float* t, float* v, int 
 int pf_unet_forward_retain(pf_engine* e, const float* x, const float* t, float* v, int B, void* stream) {
     if (!e || !x || !t || !v || B <= 0) return PF_ERR_INVALID;
     if (!e->finalized) { e->err = "weights not finalized"; return PF_ERR_STATE; }
-    HIPCHK(e, hipSetDevice(e->device));
+    USE_DEVICE(e);
     Plan* plan = nullptr;
     int rc = build_plan(e, B, true, &plan);
     if (rc != PF_OK) return rc;
-    e->retained_B = B;
+    e->retained_B = B; e->retained_plan = plan;
     return run_plan(e, plan, x, t, v, (hipStream_t)stream);
 }
 
 int pf_unet_backward(pf_engine* e, const float* vec, float* g, int B, void* stream) {
     if (!e || !vec || !g || B <= 0) return PF_ERR_INVALID;
-    if (e->retained_B != B) { e->err = "pf_unet_backward: no retained forward with this batch size"; return PF_ERR_STATE; }
-    HIPCHK(e, hipSetDevice(e->device));
+    if (e->retained_B != B || !e->retained_plan) { e->err = "pf_unet_backward: no retained forward with this batch size"; return PF_ERR_STATE; }
+    USE_DEVICE(e);
     Plan* plan = nullptr;
     int rc = build_plan(e, B, true, &plan);
     if (rc != PF_OK) return rc;
+    if (plan != e->retained_plan) {      // e.g. pf_engine_set_precision between the retained forward and the backward
+        e->err = "pf_unet_backward: the retained forward ran under a different precision mode / plan";
+        return PF_ERR_STATE;
+    }
     return run_backward(e, plan, vec, g, (hipStream_t)stream);
 }
 
@@ -1206,7 +1255,12 @@ int pf_denoise_accumulate(float* acc, const float* z_tilde, const float* v, cons
 }
 int pf_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, void* stream) {
     if (!out || n < 0) return PF_ERR_INVALID;
-    LAUNCHCHK(launch_fill_normal(out, n, seed, stream_id, (hipStream_t)stream));
+    LAUNCHCHK(launch_fill_normal(out, n, seed, stream_id, 0, (hipStream_t)stream));
+    return PF_OK;
+}
+int pf_fill_normal_at(float* out, int64_t n, uint64_t seed, uint64_t stream_id, uint64_t elem_offset, void* stream) {
+    if (!out || n < 0) return PF_ERR_INVALID;
+    LAUNCHCHK(launch_fill_normal(out, n, seed, stream_id, elem_offset, (hipStream_t)stream));
     return PF_OK;
 }
 int pf_attention_core(const float* qkv, float* out, int B, int T, int C, void* stream) {
@@ -1222,6 +1276,12 @@ int pf_psnr(const float* rec, const float* clean, float* out, int B, int n_per_i
     return PF_OK;
 }
 
+int pf_ssim(const float* rec, const float* clean, double* out, int B, int C, int H, int W, void* stream) {
+    if (!rec || !clean || !out) return PF_ERR_INVALID;
+    LAUNCHCHK(launch_ssim(rec, clean, out, B, C, H, W, (hipStream_t)stream));
+    return PF_OK;
+}
+
 static int ensure_solver(pf_engine* e, int B, size_t n, size_t ny, int steps, int ns) {
     SolverBufs& b = e->sb;
     if (b.B == B && b.n == n && b.ny == ny && b.steps >= steps && b.ns >= ns) return PF_OK;
@@ -1232,7 +1292,10 @@ static int ensure_solver(pf_engine* e, int B, size_t n, size_t ny, int steps, in
     HIPCHK(e, hipMalloc(&b.t_all, (size_t)steps * 4)); HIPCHK(e, hipMalloc(&b.coef_all, (size_t)steps * 4));
     HIPCHK(e, hipMalloc(&b.t_cur, (size_t)ns * B * 4)); HIPCHK(e, hipMalloc(&b.coef_cur, (size_t)ns * B * 4));
     HIPCHK(e, hipMalloc(&b.iter, 64));
+    HIPCHK(e, hipMalloc(&b.y, (size_t)B * ny * 4)); HIPCHK(e, hipMalloc(&b.rng, 64));
     b.B = B; b.n = n; b.ny = ny; b.steps = steps; b.ns = ns;
+    b.bytes = (int64_t)((1 + 1 + 2 * (size_t)ns + 2) * tot * 4 + (size_t)B * ny * 4 + 2 * (size_t)steps * 4 + 2 * (size_t)ns * B * 4 + 128);
+    e->bytes += b.bytes;
     return PF_OK;
 }
 
@@ -1251,7 +1314,7 @@ static int enqueue_iteration(pf_engine* e, Plan* plan, const DegView& dv, const 
         // reference's summation order (pnp_flow.py:114-121)
         const size_t tot = (size_t)B * n;
         for (int smp = 0; smp < prm->num_samples; ++smp) {
-            r = launch_interp_iter(b.z, b.t_cur, prm->noise, prm->seed, prm->stream_base, b.iter, prm->num_samples, smp, b.zt + smp * tot, B, n, s);
+            r = launch_interp_iter(b.z, b.t_cur, prm->noise, b.rng, b.iter, prm->num_samples, smp, b.zt + smp * tot, B, n, s);
             if (r != hipSuccess) { e->err = std::string("interpolate: ") + hipGetErrorString(r); return PF_ERR_HIP; }
         }
         int rc = run_plan(e, plan, b.zt, b.t_cur, b.v, s);
@@ -1263,7 +1326,7 @@ static int enqueue_iteration(pf_engine* e, Plan* plan, const DegView& dv, const 
         }
     } else
     for (int smp = 0; smp < prm->num_samples; ++smp) {
-        r = launch_interp_iter(b.z, b.t_cur, prm->noise, prm->seed, prm->stream_base, b.iter, prm->num_samples, smp, b.zt, B, n, s);
+        r = launch_interp_iter(b.z, b.t_cur, prm->noise, b.rng, b.iter, prm->num_samples, smp, b.zt, B, n, s);
         if (r != hipSuccess) { e->err = std::string("interpolate: ") + hipGetErrorString(r); return PF_ERR_HIP; }
         int rc = run_plan(e, plan, b.zt, b.t_cur, b.v, s);
         if (rc != PF_OK) return rc;
@@ -1282,7 +1345,7 @@ int pf_pnp_flow_restore(pf_engine* e, const pf_degradation* d, const pf_pnp_para
     if (!e || !d || !prm || !y || !x_out || B <= 0 || prm->steps <= 0 || prm->num_samples <= 0 || !prm->host_t || !prm->host_coef)
         return PF_ERR_INVALID;
     if (!e->finalized) { e->err = "weights not finalized"; return PF_ERR_STATE; }
-    HIPCHK(e, hipSetDevice(e->device));
+    USE_DEVICE(e);
     hipStream_t s = (hipStream_t)stream;
     if (prm->use_graph && s == nullptr) {
         // the legacy NULL stream cannot be captured: run on an engine-owned stream, ordered after
@@ -1302,32 +1365,45 @@ int pf_pnp_flow_restore(pf_engine* e, const pf_degradation* d, const pf_pnp_para
     Plan* plan = nullptr;
     if ((rc = build_plan(e, prm->batch_samples ? B * prm->num_samples : B, false, &plan)) != PF_OK) return rc;
     const DegView dv = to_view(d);
+    const unsigned long long rng_host[3] = {prm->seed, prm->stream_base, prm->elem_offset};
     HIPCHK(e, hipMemcpyAsync(b.t_all, prm->host_t, (size_t)prm->steps * 4, hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(b.coef_all, prm->host_coef, (size_t)prm->steps * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(b.rng, rng_host, sizeof rng_host, hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(b.y, y, (size_t)B * ny * 4, hipMemcpyDeviceToDevice, s));     // the graph's nodes read the engine's own copy
     HIPCHK(e, hipMemsetAsync(b.iter, 0, 64, s));
     // x0 = H_adj(ones_like(y))   (pnp_flow.py:93)
     HIPCHK(e, launch_fill(b.zt, (int64_t)B * ny, 1.0f, s));
     HIPCHK(e, launch_deg_Hadj(dv, b.zt, b.x, B, C, H, H, b.scratch, s));
-    HIPCHK(e, hipStreamSynchronize(s));   // host_t/host_coef may be freed by the caller after return; also orders the memcpys
+    HIPCHK(e, hipStreamSynchronize(s));   // host_t/host_coef/rng_host may go away after return; also orders the memcpys
 
-    hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
+    // One outer iteration = one hipGraph (gradient step, interpolation, U-Net pass, average): iteration 0 runs eagerly (all
+    // lazy initialisation done), the graph is captured once and kept while the captured arguments stay the same (every
+    // per-batch / per-shard quantity - t, lr_t/sigma^2, noise streams, y - is read from engine-owned device buffers).
+    const pf_engine::GraphKey key{plan, dv.kind, dv.half, dv.sf, dv.ntaps, dv.mask, dv.taps, prm->noise, prm->num_samples,
+                                  prm->batch_samples, prm->noise_model, B};
+    if (e->gexec && memcmp(&key, &e->gkey, sizeof key) != 0) drop_graph(e);
+    const bool can_graph = prm->use_graph && !e->profile;
     for (int it = 0; it < prm->steps; ++it) {
-        const bool can_graph = prm->use_graph && !e->profile;
-        if (can_graph && it >= 1) {
-            if (!gexec) {
-                // iteration 0 ran eagerly (all lazy initialisation done); capture one iteration and replay it
+        if (can_graph && (it >= 1 || e->gexec)) {
+            if (!e->gexec) {
                 HIPCHK(e, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                rc = enqueue_iteration(e, plan, dv, prm, y, B, C, H, s);
-                hipError_t ce = hipStreamEndCapture(s, &graph);
-                if (rc != PF_OK) return rc;
+                rc = enqueue_iteration(e, plan, dv, prm, b.y, B, C, H, s);
+                hipGraph_t g = nullptr;
+                hipError_t ce = hipStreamEndCapture(s, &g);
+                if (rc != PF_OK) { if (g) hipGraphDestroy(g); return rc; }
                 if (ce != hipSuccess) { e->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(ce); return PF_ERR_HIP; }
-                HIPCHK(e, hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+                e->graph = g;
+                hipError_t ie = hipGraphInstantiate(&e->gexec, e->graph, nullptr, nullptr, 0);
+                if (ie != hipSuccess) { drop_graph(e); e->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(ie); return PF_ERR_HIP; }
+                memset(&e->gkey, 0, sizeof e->gkey); e->gkey = key;
             }
-            HIPCHK(e, hipGraphLaunch(gexec, s));
+            HIPCHK(e, hipGraphLaunch(e->gexec, s));
         } else {
-            if ((rc = enqueue_iteration(e, plan, dv, prm, y, B, C, H, s)) != PF_OK) return rc;
+            if ((rc = enqueue_iteration(e, plan, dv, prm, b.y, B, C, H, s)) != PF_OK) return rc;
         }
-        if (iter_cb) {
+        // the host is involved only on the iterations the caller asked for (the reference touches it on its logging
+        // iterations only, pnp_flow.py:128-139)
+        if (iter_cb && (!prm->host_cb_mask || prm->host_cb_mask[it])) {
             HIPCHK(e, hipMemcpyAsync(x_out, b.x, (size_t)B * n * 4, hipMemcpyDeviceToDevice, s));
             HIPCHK(e, hipStreamSynchronize(s));
             iter_cb(it, user);
@@ -1335,10 +1411,10 @@ int pf_pnp_flow_restore(pf_engine* e, const pf_degradation* d, const pf_pnp_para
     }
     HIPCHK(e, hipMemcpyAsync(x_out, b.x, (size_t)B * n * 4, hipMemcpyDeviceToDevice, s));
     HIPCHK(e, hipStreamSynchronize(s));
-    if (gexec) hipGraphExecDestroy(gexec);
-    if (graph) hipGraphDestroy(graph);
     return PF_OK;
 }
+
+int64_t pf_engine_memory_bytes(const pf_engine* e) { return e ? e->bytes : 0; }
 
 int pf_engine_profile(pf_engine* e, int enable) {
     if (!e) return PF_ERR_INVALID;

@@ -109,13 +109,14 @@ hipError_t launch_grad_step(const DegView& d, const float* x, const float* y, co
                             int B, int C, int H, int W, float* scratch, int laplace, hipStream_t s);
 hipError_t launch_interpolate(const float* z, const float* t, const float* noise, uint64_t seed, uint64_t stream_id,
                               float* zt, int B, int n, hipStream_t s);
-hipError_t launch_interp_iter(const float* z, const float* t, const float* noise, uint64_t seed, uint64_t stream_base,
+hipError_t launch_interp_iter(const float* z, const float* t, const float* noise, const unsigned long long* rng /* device [seed, stream_base, elem_offset] */,
                               const int* iter, int num_samples, int sample, float* zt, int B, int n, hipStream_t s);
 hipError_t launch_denoise_accum(float* acc, const float* zt, const float* v, const float* t, int mode, float ns,
                                 int B, int n, hipStream_t s);
-hipError_t launch_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, hipStream_t s);
+hipError_t launch_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, uint64_t elem_offset, hipStream_t s);
 hipError_t launch_psnr(const float* rec, const float* clean, float* out, int B, int n, hipStream_t s);
 hipError_t launch_fill(float* out, int64_t n, float v, hipStream_t s);
+hipError_t launch_ssim(const float* rec, const float* clean, double* out, int B, int C, int H, int W, hipStream_t s);   // metrics.hip
 hipError_t launch_vjp_normalise(const float* vec, float* vec_scaled, int64_t n, unsigned int* amax_bits, float* scale, hipStream_t s);
 hipError_t launch_scale_inplace(float* x, int64_t n, const float* scale, hipStream_t s);
 

@@ -255,9 +255,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-__device__ __forceinline__ float4 normal4(uint32_t q, uint64_t seed, uint64_t stream) {
+__device__ __forceinline__ float4 normal4(uint64_t q, uint64_t seed, uint64_t stream) {
     uint32_t r[4];
-    philox4x32_10(q, 0u, (uint32_t)stream, (uint32_t)(stream >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)stream, (uint32_t)(stream >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
     const float k = 2.3283064365386963e-10f;  // 2^-32
     const float u0 = ((float)r[0] + 0.5f) * k, u1 = ((float)r[1] + 0.5f) * k;
     const float u2 = ((float)r[2] + 0.5f) * k, u3 = ((float)r[3] + 0.5f) * k;
@@ -268,19 +268,32 @@ __device__ __forceinline__ float4 normal4(uint32_t q, uint64_t seed, uint64_t st
     return make_float4(rad0 * c0, rad0 * s0, rad1 * c1, rad1 * s1);
 }
 
-__global__ __launch_bounds__(256) void fill_normal_kernel(float* out, int64_t n, uint64_t seed, uint64_t stream) {
+// normals number [first, first+4) of stream `stream` (normal number e = component e%4 of Philox counter e/4): a shard of a
+// multi-GPU run passes first = elem_offset + 4*q, so that it draws exactly the numbers the single-device run at the global
+// batch size draws for the same images
+__device__ __forceinline__ void normals_at(uint64_t first, uint64_t seed, uint64_t stream, float e[4]) {
+    const uint64_t q0 = first >> 2; const int r = (int)(first & 3);
+    const float4 a = normal4(q0, seed, stream);
+    if (r == 0) { e[0] = a.x; e[1] = a.y; e[2] = a.z; e[3] = a.w; return; }
+    const float4 b2 = normal4(q0 + 1, seed, stream);
+    const float v[8] = {a.x, a.y, a.z, a.w, b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e[j] = v[r + j];
+}
+
+__global__ __launch_bounds__(256) void fill_normal_kernel(float* out, int64_t n, uint64_t seed, uint64_t stream, uint64_t elem_offset) {
     const int64_t nq = (n + 3) / 4;
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
-        const float4 z = normal4((uint32_t)q, seed, stream);
-        const float zz[4] = {z.x, z.y, z.z, z.w};
+        float zz[4];
+        normals_at(elem_offset + (uint64_t)q * 4, seed, stream, zz);
         for (int j = 0; j < 4; ++j)
             if (q * 4 + j < n) out[q * 4 + j] = zz[j];
     }
 }
 
-hipError_t launch_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, hipStream_t s) {
+hipError_t launch_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, uint64_t elem_offset, hipStream_t s) {
     const int64_t nq = (n + 3) / 4;
-    hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)std::min<int64_t>((nq + 255) / 256, 4096)), dim3(256), 0, s, out, n, seed, stream_id);
+    hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)std::min<int64_t>((nq + 255) / 256, 4096)), dim3(256), 0, s, out, n, seed, stream_id, elem_offset);
     return hipGetLastError();
 }
 
@@ -294,8 +307,7 @@ __global__ __launch_bounds__(256) void interpolate_kernel(const float* z, const 
         if (noise != nullptr) {
             for (int j = 0; j < 4; ++j) e[j] = (q * 4 + j < total) ? noise[q * 4 + j] : 0.f;
         } else {
-            const float4 zz = normal4((uint32_t)q, seed, stream);
-            e[0] = zz.x; e[1] = zz.y; e[2] = zz.z; e[3] = zz.w;
+            normals_at((uint64_t)q * 4, seed, stream, e);
         }
         for (int j = 0; j < 4; ++j) {
             const int64_t i = q * 4 + j;
@@ -317,9 +329,10 @@ hipError_t launch_interpolate(const float* z, const float* t, const float* noise
 
 // Same, with the noise stream / injected-noise slice of (iteration, sample) resolved from a
 // device-side iteration counter, so one captured hipGraph serves every outer iteration.
-__global__ __launch_bounds__(256) void interp_iter_kernel(const float* z, const float* t, const float* noise, uint64_t seed,
-                                                          uint64_t stream_base, const int* iter, int num_samples, int sample,
+__global__ __launch_bounds__(256) void interp_iter_kernel(const float* z, const float* t, const float* noise, const unsigned long long* rng,
+                                                          const int* iter, int num_samples, int sample,
                                                           float* zt, int n, int64_t total) {
+    const uint64_t seed = rng[0], stream_base = rng[1], elem_offset = rng[2];
     const int64_t slot = (int64_t)(*iter) * num_samples + sample;
     const uint64_t stream = stream_base + (uint64_t)slot;
     const float* nz = noise != nullptr ? noise + slot * total : nullptr;
@@ -329,8 +342,7 @@ __global__ __launch_bounds__(256) void interp_iter_kernel(const float* z, const 
         if (nz != nullptr) {
             for (int j = 0; j < 4; ++j) e[j] = (q * 4 + j < total) ? nz[q * 4 + j] : 0.f;
         } else {
-            const float4 zz = normal4((uint32_t)q, seed, stream);
-            e[0] = zz.x; e[1] = zz.y; e[2] = zz.z; e[3] = zz.w;
+            normals_at(elem_offset + (uint64_t)q * 4, seed, stream, e);
         }
         for (int j = 0; j < 4; ++j) {
             const int64_t i = q * 4 + j;
@@ -342,11 +354,11 @@ __global__ __launch_bounds__(256) void interp_iter_kernel(const float* z, const 
     }
 }
 
-hipError_t launch_interp_iter(const float* z, const float* t, const float* noise, uint64_t seed, uint64_t stream_base,
+hipError_t launch_interp_iter(const float* z, const float* t, const float* noise, const unsigned long long* rng,
                               const int* iter, int num_samples, int sample, float* zt, int B, int n, hipStream_t s) {
     const int64_t total = (int64_t)B * n, nq = (total + 3) / 4;
     hipLaunchKernelGGL(interp_iter_kernel, dim3((unsigned)std::min<int64_t>((nq + 255) / 256, 4096)), dim3(256), 0, s,
-                       z, t, noise, seed, stream_base, iter, num_samples, sample, zt, n, total);
+                       z, t, noise, rng, iter, num_samples, sample, zt, n, total);
     return hipGetLastError();
 }
 

@@ -99,6 +99,12 @@ class RandomInpainting(Degradation):
         self.global_batch, self.batch_offset = global_batch, batch_offset
         self._cache = {}
 
+    def set_shard(self, global_batch, batch_offset):
+        """This process restores images [batch_offset, batch_offset + B) of a `global_batch`-image batch."""
+        if (global_batch, batch_offset) != (self.global_batch, self.batch_offset):
+            self.global_batch, self.batch_offset = global_batch, batch_offset
+            self._cache = {}
+
     def mask(self, B, H, W, device):
         key = (B, H, W, str(device))
         if key not in self._cache:
@@ -135,6 +141,24 @@ class GaussianDeblurring(Degradation):
         g = np.exp(-(ax ** 2) / (2 * sigma_blur ** 2))
         self.taps_host = (g / g.sum()).astype(np.float32)
         self._taps = {}
+        self.num_channels, self.dim_image, self._device = num_channels, dim_image, device
+        self._filter = None
+
+    @property
+    def filter(self):
+        """The reference's attribute (degradations.py:59-69; read by a Python-side ot_ode loop, ot_ode.py:110): the normalised
+        2-D Gaussian, zero-padded to (1, C, dim, dim) and rolled so that its centre sits at (0, 0)."""
+        if self._filter is None:
+            K, D = self.kernel_size, self.dim_image
+            ax = torch.arange(-K // 2 + 1.0, K // 2 + 1.0)                      # utils.py:273-280, same fp32 arithmetic
+            xx, yy = torch.meshgrid(ax, ax, indexing="ij")
+            k2 = torch.exp(-(xx ** 2 + yy ** 2) / (2 * self.sigma ** 2))
+            k2 = k2 / k2.sum()
+            f = torch.zeros((1, self.num_channels, D, D), dtype=torch.float32)
+            f[:, :, :K, :K] = k2
+            f = torch.roll(f, shifts=(-(K - 1) // 2, -(K - 1) // 2), dims=(2, 3))
+            self._filter = f.to(self._device if torch.cuda.is_available() else "cpu")
+        return self._filter
 
     def descriptor(self, B, H, W, device):
         key = str(device)
@@ -173,6 +197,7 @@ class Superresolution(Degradation):
         if mode not in (None, "bicubic"):
             raise NotImplementedError(f"Superresolution mode {mode!r}")
         self.sf, self.dim_image, self.mode = sf, dim_image, mode
+        self._dm = None
         if mode == "bicubic":
             self.kind = _lib.PF_DEG_SR_FILTERED
             self.taps_host = bicubic_taps(sf)
@@ -186,6 +211,21 @@ class Superresolution(Degradation):
                 self._taps[key] = torch.from_numpy(self.taps_host).to(device)
             d.ntaps = int(self.taps_host.shape[0]); d.taps = self._taps[key].data_ptr()
         return d
+
+    @property
+    def downsampling_matrix(self):
+        """The reference's attribute (degradations.py:110-111, utils.py:1124-1146; read by ot_ode.py:98): the
+        (HW/sf^2, HW) 0/1 decimation matrix.  Built on first access only (268 MB at 256^2 / sf 4; the engine's own
+        solvers never need it: diag(D D^T) = 1)."""
+        if self._dm is None:
+            D, sf = self.dim_image, self.sf
+            Dl = D // sf
+            rows = torch.arange(Dl * Dl)
+            cols = (rows // Dl) * sf * D + (rows % Dl) * sf
+            m = torch.zeros((Dl * Dl, D * D), dtype=torch.float32)
+            m[rows, cols] = 1.0
+            self._dm = m
+        return self._dm
 
     def H(self, x):
         return self._apply(x, False)

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from .. import _lib
+from .. import parallel
 from .. import utils
 
 
@@ -90,34 +91,70 @@ class OT_ODE(object):
         self.args.sigma_noise = sigma_noise
         H, H_adj = degradation.H, degradation.H_adj
         steps = self.args.steps_ode
+        # multi-GPU: every rank restores its slice [lo, hi) of each batch; global draws sliced, metrics gathered (parallel.py)
+        rank, world = parallel.rank_world()
         loader = iter(test_loader)
         for batch in range(self.args.max_batch):
             (clean_img, labels) = next(loader)
             self.args.batch = batch
+            G = clean_img.shape[0]
+            lo, hi = parallel.shard_range(G, rank, world)
+            if world > 1:
+                clean_img = clean_img[lo:hi]
+                if hasattr(degradation, "set_shard"):
+                    degradation.set_shard(G, lo)
             noisy_img = H(clean_img.clone().to(self.device))
+            gshape = (G,) + tuple(noisy_img.shape[1:])
             if self.measurement_noise is not None:
                 noise = self.measurement_noise(batch, noisy_img)
             else:
-                torch.manual_seed(batch)
-                noise = torch.randn(noisy_img.shape, dtype=torch.float32).to(self.device)
+                torch.manual_seed(batch)                                   # ot_ode.py:44-45 (CPU generator: same on every rank)
+                noise = torch.randn(gshape, dtype=torch.float32)[lo:hi].to(self.device)
             noisy_img = noisy_img + noise * sigma_noise
             clean_img = clean_img.to('cpu')
+            if world > 1 and self.init_noise is None:
+                # `initialization` draws randn_like(H_adj(y)) right after the measurement noise (ot_ode.py:27-28, 50-52): global draw, sliced
+                full = (G,) + tuple(clean_img.shape[1:])
+                init = torch.randn(full, dtype=torch.float32)[lo:hi].to(self.device)
+            else:
+                init = None
             if self.args.compute_time:
                 torch.cuda.synchronize(); t0 = perf_counter()
+            if self.args.compute_memory:
+                torch.cuda.reset_peak_memory_stats(self.device)
+            self._cb_seconds = 0.0
 
             def on_iter(iteration, x):
                 if self.args.save_results and (iteration % 10 == 0 or self.should_save_image(iteration, steps)):
+                    t_cb = perf_counter()
                     utils.compute_psnr(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=iteration)
+                    utils.compute_ssim(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=iteration)
+                    self._cb_seconds += perf_counter() - t_cb
 
-            x = self.restore_batch(noisy_img, degradation, sigma_noise, iter_cb=on_iter if self.args.save_results else None)
+            saved_init = self.init_noise
+            if init is not None:
+                self.init_noise = init
+            try:
+                x = self.restore_batch(noisy_img, degradation, sigma_noise, iter_cb=on_iter if self.args.save_results else None)
+            finally:
+                self.init_noise = saved_init
             self.last_restored = x
+            if self.args.compute_memory:
+                utils.save_memory_use({"batch": batch, "max_allocated": torch.cuda.max_memory_allocated(self.device) + self.model.memory_bytes()},
+                                      self.args)
             if self.args.compute_time:
                 torch.cuda.synchronize()
-                utils.save_time_use({"batch": batch, "time_per_batch": perf_counter() - t0}, self.args)
+                utils.save_time_use({"batch": batch, "time_per_batch": perf_counter() - t0 - self._cb_seconds}, self.args)
             if self.args.save_results:
                 utils.compute_psnr(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=int(steps) - 1)
+                utils.compute_ssim(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=int(steps) - 1)
         if self.args.save_results:
             utils.compute_average_psnr(self.args)
+            utils.compute_average_ssim(self.args)
+        if self.args.compute_memory:
+            utils.compute_average_memory(self.args)
+        if self.args.compute_time:
+            utils.compute_average_time(self.args)
 
     def should_save_image(self, iteration, steps):
         return iteration % (steps // 10) == 0

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from .. import _lib
+from .. import parallel
 from .. import utils
 
 
@@ -35,6 +36,9 @@ class PNP_FLOW(object):
         self.batch_samples = True  # the num_samples evaluations of an iteration run as one pass over num_samples*B images
         self.last_restored = None  # the final x of the last batch (the reference only writes it to disk)
         self.measurement_noise = None   # optional override of the torch.manual_seed(batch) draw (multi-GPU shards)
+        self.image_offset = 0      # multi-GPU shard: index of this shard's first image in the global batch (parallel.shard_range);
+                                   # the shard then draws its slice of the global batch's interpolation noise (pf_pnp_params.elem_offset)
+        self._interp_calls = 0
 
     # ---- the reference's small methods, kept for API parity ---------------------------------
     def model_forward(self, x, t):
@@ -62,8 +66,13 @@ class PNP_FLOW(object):
         raise ValueError('Noise type not supported')
 
     def interpolation_step(self, x, t):
+        # a fresh eps per call, as torch.randn_like gives (pnp_flow.py:47-48): stream ids 2^63 + call number never collide with
+        # restore_batch's streams (1 + (batch << 32) + iteration*num_samples + sample)
         eps = torch.empty_like(x)
-        _lib.check(self.lib.pf_fill_normal(eps.data_ptr(), eps.numel(), self.noise_seed, 0, _lib.current_stream_ptr()), None, "pf_fill_normal")
+        stream_id = (1 << 63) + self._interp_calls
+        self._interp_calls += 1
+        _lib.check(self.lib.pf_fill_normal_at(eps.data_ptr(), eps.numel(), self.noise_seed, stream_id,
+                                              self.image_offset * x[0].numel(), _lib.current_stream_ptr()), None, "pf_fill_normal_at")
         return t * x + eps * (1 - t)
 
     def denoiser(self, x, t):
@@ -85,8 +94,10 @@ class PNP_FLOW(object):
             coef[it] = float(lr_t.reshape(-1)[0]) / (sigma_noise ** 2 if self.args.noise_type == 'gaussian' else sigma_noise)
         return t_vals, coef
 
-    def restore_batch(self, noisy_img, degradation, sigma_noise, lr, iter_cb=None):
-        """Inner loop of solve_ip for one batch on the engine.  Returns x (B,C,H,W)."""
+    def restore_batch(self, noisy_img, degradation, sigma_noise, lr, iter_cb=None, cb_iterations=None):
+        """Inner loop of solve_ip for one batch on the engine.  Returns x (B,C,H,W).
+        iter_cb(iteration, x) is called on the host after the iterations in `cb_iterations` (None = every iteration);
+        self.last_callback_seconds = host time spent inside those callbacks (excluded from `time_per_batch`)."""
         args = self.args
         steps, ns = int(args.steps_pnp), int(args.num_samples)
         B = noisy_img.shape[0]
@@ -99,6 +110,7 @@ class PNP_FLOW(object):
         prm.host_coef = coef.ctypes.data_as(C.POINTER(C.c_float))
         prm.seed = int(self.noise_seed)
         prm.stream_base = 1 + (int(getattr(args, "batch", 0)) << 32)
+        prm.elem_offset = int(self.image_offset) * Cc * Hh * Hh
         if self.noise is not None:
             nz = self.noise.contiguous().float()
             assert nz.numel() == steps * ns * B * Cc * Hh * Hh
@@ -108,16 +120,30 @@ class PNP_FLOW(object):
         prm.noise_model = 1 if args.noise_type == 'laplace' else 0
         x = torch.empty((B, Cc, Hh, Hh), dtype=torch.float32, device=noisy_img.device)
         y = noisy_img.contiguous().float()
-        holder = {}
+        holder = {"err": None}
+        self.last_callback_seconds = 0.0
         if iter_cb is not None:
             def _cb(it, user):
-                iter_cb(it, x)
+                t_cb = perf_counter()
+                try:
+                    if holder["err"] is None:
+                        iter_cb(it, x)
+                except BaseException as exc:      # an exception must not unwind through the C frames: re-raised below
+                    holder["err"] = exc
+                self.last_callback_seconds += perf_counter() - t_cb
             cb = _lib.ITER_CB(_cb)
+            if cb_iterations is not None:
+                mask = np.zeros(steps, dtype=np.uint8)
+                mask[[i for i in cb_iterations if 0 <= i < steps]] = 1
+                holder["mask"] = mask
+                prm.host_cb_mask = mask.ctypes.data
         else:
             cb = C.cast(None, _lib.ITER_CB)
         holder["cb"] = cb
         _lib.check(self.lib.pf_pnp_flow_restore(self.model.handle, C.byref(d), C.byref(prm), y.data_ptr(), x.data_ptr(), B,
                                                 _lib.current_stream_ptr(), cb, None), self.model.handle, "pf_pnp_flow_restore")
+        if holder["err"] is not None:
+            raise holder["err"]
         return x
 
     def solve_ip(self, test_loader, degradation, sigma_noise, H_funcs=None):
@@ -134,46 +160,73 @@ class PNP_FLOW(object):
         else:
             raise ValueError('Noise type not supported')
 
+        # Multi-GPU (torchrun, one process per GPU): every rank walks the same loader and restores its contiguous slice
+        # [lo, hi) of each batch; the batch-shaped random draws are taken for the whole batch and sliced, metrics are
+        # all_gathered per image and written by rank 0 - so the result files equal a single-device run's (parallel.py).
+        rank, world = parallel.rank_world()
         loader = iter(test_loader)
         for batch in range(self.args.max_batch):
             (clean_img, labels) = next(loader)
             self.args.batch = batch
+            G = clean_img.shape[0]
+            lo, hi = parallel.shard_range(G, rank, world)
+            if world > 1:
+                clean_img = clean_img[lo:hi]
+                if hasattr(degradation, "set_shard"):
+                    degradation.set_shard(G, lo)
+            self.image_offset = lo
             noisy_img = H(clean_img.clone().to(self.device))
+            gshape = (G,) + tuple(noisy_img.shape[1:])
             if self.measurement_noise is not None:
                 noise = self.measurement_noise(batch, noisy_img)
             elif self.args.noise_type == 'laplace':
                 # pnp_flow.py:81-85: unit-scale Laplace sample (scaled by sigma below), drawn on the CPU generator
-                noise = torch.distributions.laplace.Laplace(torch.zeros(noisy_img.shape), torch.ones(noisy_img.shape)).sample().to(self.device)
+                noise = torch.distributions.laplace.Laplace(torch.zeros(gshape), torch.ones(gshape)).sample()[lo:hi].to(self.device)
             else:
                 # the reference draws on the device generator after torch.manual_seed(batch)
                 # (pnp_flow.py:79-80); here the draw is made on the CPU generator so that it is
-                # reproducible on any device, then moved.
+                # reproducible on any device (and identical on every rank), then sliced and moved.
                 torch.manual_seed(batch)
-                noise = torch.randn(noisy_img.shape, dtype=torch.float32).to(self.device)
+                noise = torch.randn(gshape, dtype=torch.float32)[lo:hi].to(self.device)
             noisy_img = noisy_img + noise * sigma_noise
             clean_img = clean_img.to('cpu')
 
             if self.args.compute_time:
                 torch.cuda.synchronize()
                 t0 = perf_counter()
+            if self.args.compute_memory:
+                torch.cuda.reset_peak_memory_stats(self.device)
 
             def on_iter(iteration, x):
-                if self.args.save_results and (iteration % 50 == 0 or self.should_save_image(iteration, steps)):
-                    utils.compute_psnr(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=iteration)
+                utils.compute_psnr(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=iteration)
+                utils.compute_ssim(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=iteration)
 
+            # the reference's logging iterations (pnp_flow.py:128-139); the host is not involved on any other iteration
+            log_its = [it for it in range(int(steps)) if it % 50 == 0 or self.should_save_image(it, steps)] if self.args.save_results else []
             x = self.restore_batch(noisy_img, degradation, sigma_noise, lr,
-                                   iter_cb=on_iter if self.args.save_results else None)
+                                   iter_cb=on_iter if self.args.save_results else None, cb_iterations=log_its)
             self.last_restored = x
 
+            if self.args.compute_memory:
+                # torch's caching allocator (measurement, noise, output tensors) + the engine's own device memory
+                utils.save_memory_use({"batch": batch, "max_allocated": torch.cuda.max_memory_allocated(self.device) + self.model.memory_bytes()},
+                                      self.args)
             if self.args.compute_time:
                 torch.cuda.synchronize()
-                utils.save_time_use({"batch": batch, "time_per_batch": perf_counter() - t0}, self.args)
+                # the reference accumulates the iteration bodies only (pnp_flow.py:104-126): metric callbacks are excluded
+                utils.save_time_use({"batch": batch, "time_per_batch": perf_counter() - t0 - self.last_callback_seconds}, self.args)
 
             if self.args.save_results:
                 utils.compute_psnr(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=int(steps) - 1)
+                utils.compute_ssim(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=int(steps) - 1)
 
         if self.args.save_results:
             utils.compute_average_psnr(self.args)
+            utils.compute_average_ssim(self.args)
+        if self.args.compute_memory:
+            utils.compute_average_memory(self.args)
+        if self.args.compute_time:
+            utils.compute_average_time(self.args)
 
     def should_save_image(self, iteration, steps):
         return iteration % (steps // 10) == 0

@@ -148,6 +148,10 @@ class UNet:
         _lib.check(self._lib.pf_engine_set_precision(self._h, int(mode)), self._h, "pf_engine_set_precision")
         return self
 
+    def memory_bytes(self) -> int:
+        """Device bytes the engine currently holds (weights, activation plans, solver buffers)."""
+        return int(self._lib.pf_engine_memory_bytes(self._h))
+
     def profile(self, enable: bool):
         _lib.check(self._lib.pf_engine_profile(self._h, 1 if enable else 0), self._h, "pf_engine_profile")
 

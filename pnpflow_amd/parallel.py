@@ -10,13 +10,46 @@ random draws of the reference are taken for the GLOBAL batch and sliced:
   measurement noise  torch.manual_seed(batch); randn(global shape)   (pnp_flow.py:79-80)
   random mask        RandomState(42).binomial(global B, H, W)          (utils.py:357-359)
   interpolation noise  one flat Philox stream per (iteration, sample); shard s uses the
-                       elements [lo*n, hi*n) of it (see `noise_offset`).
+                       elements [lo*n, hi*n) of it (pf_pnp_params.elem_offset; PNP_FLOW.image_offset = lo).
 """
 from __future__ import annotations
 
 from typing import Tuple
 
 import torch
+
+
+def rank_world(group=None) -> Tuple[int, int]:
+    """(rank, world size) of the running job; (0, 1) when torch.distributed is not initialised."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def init_from_env(device_index=None):
+    """torchrun entry: joins the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (backend "nccl" = RCCL on ROCm,
+    one process per GPU) and returns (rank, world, local_rank).  A plain `python main.py` run returns (0, 1, 0) untouched."""
+    import os
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0")) if device_index is None else device_index
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    return rank, world, local
+
+
+def global_normal(key, global_shape, lo: int, hi: int) -> torch.Tensor:
+    """Rows [lo, hi) of a seeded N(0,1) tensor of the GLOBAL batch shape (numpy Philox keyed by `key`): every rank
+    reproduces the same global tensor and keeps its own images."""
+    import numpy as np
+    g = np.random.Generator(np.random.Philox(key=list(key)))
+    return torch.from_numpy(g.standard_normal(size=tuple(global_shape), dtype=np.float32)[lo:hi].copy())
 
 
 def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:

@@ -84,7 +84,8 @@ def merge_cfg_from_list(cfg: CfgNode, cfg_list: List[str]) -> CfgNode:
 def define_model(args):
     if args.model in ("ot", "indep"):
         model = UNet(input_channels=args.num_channels, input_height=args.dim_image, ch=32, ch_mult=(1, 2, 4, 8),
-                     num_res_blocks=6, attn_resolutions=(16, 8), resamp_with_conv=True)
+                     num_res_blocks=6, attn_resolutions=(16, 8), resamp_with_conv=True,
+                     device_index=int(getattr(args, "device_index", 0)))
         return (model, None)
     raise Exception("Unknown model! (this engine implements the 'ot'/'indep' U-Net velocity field)")
 
@@ -115,48 +116,138 @@ def psnr_per_image(rec: torch.Tensor, clean: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def ssim_per_image(rec: torch.Tensor, clean: torch.Tensor) -> torch.Tensor:
+    """SSIM (data_range 1, 11x11 Gaussian window sigma 1.5, k1 0.01, k2 0.03, reflect padding) of postprocess(rec) vs
+    postprocess(clean) per image, on the GPU (pf_ssim).  Restates ignite.metrics.SSIM as the reference uses it
+    (utils.py:780-802); ignite is not installed here, so this metric is PARITY UNPINNED (oracle: O.ssim_per_image)."""
+    lib = _lib.load()
+    rec = rec.contiguous().float(); clean = clean.to(rec.device).contiguous().float()
+    B, Cc, H, W = rec.shape
+    out = torch.empty(B, dtype=torch.float64, device=rec.device)
+    _lib.check(lib.pf_ssim(rec.data_ptr(), clean.data_ptr(), out.data_ptr(), B, Cc, H, W, _lib.current_stream_ptr()), None, "pf_ssim")
+    return out
+
+
+def _is_writer():
+    from . import parallel
+    return parallel.rank_world()[0] == 0
+
+
+def _global_mean(per_image: torch.Tensor) -> float:
+    """Mean over the (global) batch; with several ranks the per-image values are all_gathered in image order first -
+    the ONE data-path collective of a sharded run (parallel.py)."""
+    from . import parallel
+    return float(parallel.gather_in_image_order(per_image).double().mean())
+
+
+def _append_metric(args, name, word, iter, val):
+    if _is_writer():
+        with open(os.path.join(args.save_path_ip, f'{name}_{word}_batch{args.batch}.txt'), 'a') as f:
+            f.write(f'{iter} {val}\n')
+
+
 def compute_psnr(clean_img, noisy_img, rec_img, args, H_adj, iter='final'):
-    """Appends '{iter} {psnr}' lines to psnr_{rec,noisy}_batch{b}.txt (reference utils.py:594-625)."""
+    """Appends '{iter} {psnr}' lines to psnr_{rec,noisy}_batch{b}.txt (reference utils.py:594-625): the mean over the
+    batch of the per-image PSNR."""
     dev = rec_img.device
     clean = clean_img.to(dev)
     noisy = noisy_img.to(dev)
     if args.problem in ('superresolution', 'superresolution_bicubic'):
-        noisy = H_adj(noisy)
-    psnr_rec = float(psnr_per_image(rec_img, clean).mean())
-    psnr_noisy = float(psnr_per_image(noisy, clean).mean())
-    for word, val in (('rec', psnr_rec), ('noisy', psnr_noisy)):
-        with open(os.path.join(args.save_path_ip, f'psnr_{word}_batch{args.batch}.txt'), 'a') as f:
-            f.write(f'{iter} {val}\n')
+        # the reference post-processes the measurement BEFORE H_adj and the result again (utils.py:598-607);
+        # psnr_per_image applies the outer postprocess itself
+        noisy = H_adj(postprocess(noisy))
+    psnr_rec = _global_mean(psnr_per_image(rec_img, clean))
+    psnr_noisy = _global_mean(psnr_per_image(noisy, clean))
+    _append_metric(args, 'psnr', 'rec', iter, psnr_rec)
+    _append_metric(args, 'psnr', 'noisy', iter, psnr_noisy)
     return psnr_rec, psnr_noisy
 
 
-def compute_average_psnr(args):
-    """reference utils.py:628-674"""
+def compute_ssim(clean_img, noisy_img, rec_img, args, H_adj, iter='final'):
+    """ssim_{rec,noisy}_batch{b}.txt (reference utils.py:780-816).  PARITY UNPINNED: see ssim_per_image."""
+    dev = rec_img.device
+    clean = clean_img.to(dev)
+    noisy = noisy_img.to(dev)
+    if args.problem in ('superresolution', 'superresolution_bicubic'):
+        noisy = H_adj(noisy)                      # single postprocess here (utils.py:782-783)
+    ssim_rec = _global_mean(ssim_per_image(rec_img, clean))
+    ssim_noisy = _global_mean(ssim_per_image(noisy, clean))
+    _append_metric(args, 'ssim', 'rec', iter, ssim_rec)
+    _append_metric(args, 'ssim', 'noisy', iter, ssim_noisy)
+    return ssim_rec, ssim_noisy
+
+
+def _average_metric(args, name):
+    """reference utils.py:628-674 (psnr) / 819-863 (ssim): per-iteration mean over the batches, then the last value into
+    final_{name}.txt next to the method's hyper-parameters."""
+    if not _is_writer():
+        return None
     final = {}
     for word in ['rec', 'noisy']:
         by_it = defaultdict(list)
         for batch in range(args.max_batch):
-            with open(os.path.join(args.save_path_ip, f'psnr_{word}_batch{batch}.txt'), 'r') as f:
+            with open(os.path.join(args.save_path_ip, f'{name}_{word}_batch{batch}.txt'), 'r') as f:
                 for line in f:
                     it, val = map(float, line.strip().split())
                     by_it[int(it)].append(val)
-        avg_file = os.path.join(args.save_path_ip, f'psnr_{word}_average.txt')
+        avg_file = os.path.join(args.save_path_ip, f'{name}_{word}_average.txt')
         with open(avg_file, 'a') as f:
             for it, vals in sorted(by_it.items()):
                 f.write(f'{it} {np.mean(vals):.4f}\n')
         with open(avg_file, 'r') as f:
             final[word] = [float(l.split()[1]) for l in f.readlines()][-1]
-    path = os.path.join(args.save_path, 'final_psnr.txt')
+    path = os.path.join(args.save_path, f'final_{name}.txt')
     with open(path, 'a') as f:
         if os.stat(path).st_size == 0:
-            f.write('psnr_rec psnr_noisy ' + ''.join(f'{k} ' for k in args.dict_cfg_method.keys()) + '\n')
+            f.write(f'{name}_rec {name}_noisy ' + ''.join(f'{k} ' for k in args.dict_cfg_method.keys()) + '\n')
         f.write(f"{final['rec']} {final['noisy']} " + ''.join(f'{v} ' for v in args.dict_cfg_method.values()) + '\n')
     return final
 
 
+def compute_average_psnr(args):
+    return _average_metric(args, 'psnr')
+
+
+def compute_average_ssim(args):
+    return _average_metric(args, 'ssim')
+
+
 def save_time_use(d, args):
-    with open(os.path.join(args.save_path_ip, 'time_stats.txt'), "a") as f:
-        f.write(str(d) + '\n')
+    if _is_writer():
+        with open(os.path.join(args.save_path_ip, 'time_stats.txt'), "a") as f:
+            f.write(str(d) + '\n')
+
+
+def save_memory_use(d, args):
+    """reference utils.py:580-584"""
+    if _is_writer():
+        with open(os.path.join(args.save_path_ip, 'memory_stats.txt'), "a") as f:
+            f.write(str(d) + '\n')
+
+
+def _average_stat(args, stats_file, key, out_file, label):
+    """reference utils.py:866-901: the first record of every batch index, averaged."""
+    if not _is_writer():
+        return None
+    vals = torch.zeros(args.max_batch)
+    for batch in range(args.max_batch):
+        with open(os.path.join(args.save_path_ip, stats_file), 'r') as f:
+            for line in f:
+                rec = literal_eval(line.strip())
+                if rec['batch'] == batch:
+                    vals[batch] = rec[key]
+                    break
+    with open(os.path.join(args.save_path_ip, out_file), 'a') as f:
+        f.write(f'{label}: {vals.mean().item():.4f}\n')
+    return vals.mean().item()
+
+
+def compute_average_time(args):
+    return _average_stat(args, 'time_stats.txt', 'time_per_batch', 'time_average.txt', 'average time')
+
+
+def compute_average_memory(args):
+    return _average_stat(args, 'memory_stats.txt', 'max_allocated', 'max_memory_average.txt', 'average mem')
 
 
 def get_save_path_ip(dict_cfg_method):

@@ -157,3 +157,94 @@ def test_bench_helpers():
     a = bench.det_image((2, 3, 16, 16), 5)
     assert a.shape == (2, 3, 16, 16) and float(a.min()) >= -1.0 and float(a.max()) <= 1.0
     assert torch.equal(a, bench.det_image((2, 3, 16, 16), 5))
+
+
+# ---- round 2: data readers, shard draws, operator attributes (no GPU) ---------------------------------------------------
+def _write_png(path, arr):
+    from PIL import Image
+    Image.fromarray(arr).save(path)
+
+
+def test_celeba_reader_matches_the_reference_pipeline(tmp_path):
+    """pnpflow/dataloaders.py:22-31,121-153: partition CSV (read with the reference's own pandas call, which drops the
+    first listed image), CenterCrop(178) -> Resize(128) bilinear -> ToTensor -> Normalize(.5,.5); missing files filtered."""
+    from PIL import Image
+    from pnpflow_amd.dataloaders import DataLoaders
+    rng = np.random.RandomState(0)
+    d = tmp_path / "data" / "celeba" / "img_align_celeba"
+    d.mkdir(parents=True)
+    names = [f"{i:06d}.png" for i in range(1, 8)]
+    imgs = {}
+    for nme in names[:-1]:                      # the last listed file is missing on disk
+        a = rng.randint(0, 256, size=(218, 178, 3)).astype(np.uint8)
+        _write_png(str(d / nme), a); imgs[nme] = a
+    with open(tmp_path / "data" / "celeba" / "list_eval_partition.csv", "w") as f:
+        f.write("image_id,partition\n")
+        for i, nme in enumerate(names):
+            f.write(f"{nme},{2 if i >= 2 else 0}\n")
+    loaders = DataLoaders("celeba", 3, 3, root=str(tmp_path) + "/").load_data()
+    batches = list(loaders["test"])
+    # partition 2 = names[2:], the last is missing -> 4 images in batches of 3 + 1
+    assert [b[0].shape[0] for b in batches] == [3, 1]
+    x0 = batches[0][0][0]
+    assert x0.shape == (3, 128, 128) and x0.dtype == torch.float32 and -1.0 <= float(x0.min()) and float(x0.max()) <= 1.0
+    ref = Image.fromarray(imgs[names[2]][20:198]).resize((128, 128), Image.BILINEAR)       # rows 20..197 = the centre crop of 218
+    ref = (torch.from_numpy(np.asarray(ref).transpose(2, 0, 1).copy()).float() / 255 - 0.5) / 0.5
+    assert torch.equal(x0, ref)
+    # the reference's read_csv(header=0, names=..., skiprows=1) consumes the first data row as a header: partition 0 has names[1] only
+    assert len(loaders["train"].dataset) == 1
+
+
+def test_afhq_reader_and_empty_collate(tmp_path):
+    from PIL import Image
+    from pnpflow_amd.dataloaders import DataLoaders, custom_collate
+    rng = np.random.RandomState(1)
+    d = tmp_path / "data" / "afhq_cat" / "test" / "cat"
+    d.mkdir(parents=True)
+    arrs = []
+    for i in (2, 0, 1):                                     # written out of order: the reader sorts
+        a = rng.randint(0, 256, size=(300, 280, 3)).astype(np.uint8)
+        _write_png(str(d / f"cat_{i}.png"), a); arrs.append((i, a))
+    dl = DataLoaders("afhq_cat", 2, 2, root=str(tmp_path) + "/")
+    assert dl.available("test") and not dl.available("val")
+    batches = list(dl.load_data()["test"])
+    assert [b[0].shape for b in batches] == [(2, 3, 256, 256), (1, 3, 256, 256)]
+    a0 = dict(arrs)[0]
+    ref = (torch.from_numpy(np.asarray(Image.fromarray(a0).resize((256, 256), Image.BILINEAR)).transpose(2, 0, 1).copy()).float() / 255 - 0.5) / 0.5
+    assert torch.equal(batches[0][0][0], ref)
+    e = custom_collate([(None, None)])
+    assert e[0].numel() == 0 and e[1].numel() == 0
+
+
+def test_engine_normal_offset_is_a_slice_of_the_global_stream():
+    from oracle import pnpflow_oracle as O
+    full = O.engine_normal(4001, 77, 5)
+    for off, n in ((0, 13), (4, 100), (1001, 999), (3, 4), (3998, 3)):
+        np.testing.assert_array_equal(O.engine_normal(n, 77, 5, offset=off), full[off:off + n])
+
+
+def test_bench_shards_reassemble_the_global_batch():
+    """bench.py's per-rank inputs are slices of ONE global draw: N ranks restore the images a single-device run restores."""
+    import bench
+    wl = dict(bench.WORKLOADS["tiny"]); wl["B"] = 2
+    one = bench.shard_inputs(dict(wl, B=4), 0, 1)
+    two = [bench.shard_inputs(wl, r, 2) for r in range(2)]
+    assert (two[0][0], two[0][1], two[1][0], two[1][1]) == (0, 2, 2, 4)
+    assert torch.equal(torch.cat([t[2] for t in two]), one[2]) and torch.equal(torch.cat([t[3] for t in two]), one[3])
+    wo = dict(bench.WORKLOADS["c5"], dim=64, B=1)
+    a = bench.shard_inputs(dict(wo, B=2), 0, 1); b = [bench.shard_inputs(wo, r, 2) for r in range(2)]
+    assert torch.equal(torch.cat([t[4] for t in b]), a[4])
+
+
+def test_operator_attributes_of_the_reference_api(golden=None):
+    """GaussianDeblurring.filter (degradations.py:59-69) and Superresolution.downsampling_matrix (:110-111) exist for callers
+    that keep the OT-ODE loop in Python (ot_ode.py:98, 110)."""
+    import pnpflow_amd.degradations as D
+    from oracle import pnpflow_oracle as O
+    g = D.GaussianDeblurring(1.0, 61, "fft", 3, 128, device="cpu")
+    f = g.filter
+    assert f.shape == (1, 3, 128, 128)
+    np.testing.assert_allclose(f.cpu().numpy(), O.GaussianDeblurring(1.0, 61, "fft", 3, 128).filter.numpy(), atol=1e-9)
+    m = D.Superresolution(2, 8).downsampling_matrix
+    x = torch.arange(64.0)
+    assert torch.equal(m @ x, x.view(8, 8)[::2, ::2].reshape(-1)) and torch.equal(torch.diag(m @ m.T), torch.ones(16))

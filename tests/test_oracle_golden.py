@@ -223,3 +223,48 @@ def test_ot_ode_trajectory_matches_reference(golden, tag, net, problem, mk, t0, 
     for it in (first, first + 1, steps - 1):
         ref = g[f"x_it{it}"]
         np.testing.assert_allclose(its[it].numpy(), ref, atol=1e-4 * max(1.0, float(np.abs(ref).max())), err_msg=f"iterate {it}")
+
+
+# ---- BASELINE-size nets: C4/C5 --------------------------------------------
+def _check_crops(t, g, prefix, atol, rtol_sum=1e-5):
+    H = t.shape[2]
+    np.testing.assert_allclose(t[:, :, H // 2 - 16:H // 2 + 16, H // 2 - 16:H // 2 + 16].numpy(), g[prefix + "_crop"], atol=atol)
+    np.testing.assert_allclose(t[:, :, :8, :8].numpy(), g[prefix + "_corner"], atol=atol)
+    np.testing.assert_allclose(checksums(t)[1:], g[prefix + "_checksum"][1:], rtol=rtol_sum)     # sum|.|, sum .^2 (the plain sum cancels)
+
+
+@pytest.mark.parametrize("net", ["celeba128", "afhq256"])
+def test_unet_vjp_full_size_matches_reference(golden, net):
+    """J^T vec on the 34.5 M / 31.0 M parameter nets vs the real reference's torch.autograd.functional.vjp (ot_ode.py:137-138)."""
+    g = golden("vjp_" + net)
+    cfg = O.unet_config(**CFGS[net]); sd = O.synthetic_state_dict(cfg, 0)
+    S = cfg["input_height"]
+    x = det_normal((1, 3, S, S), 51); vec = det_normal((1, 3, S, S), 52)
+    out = O.unet_vjp(sd, cfg, x, torch.from_numpy(g["t"]), vec)
+    _check_crops(out, g, "g", 2e-5 * float(g["g_absmax"]))
+
+
+def test_ot_ode_c5_step_matches_reference(golden):
+    """One real OT_ODE.solve_ip Euler step of config C5 (AFHQ-256 random inpainting, steps_ode=100, start_time=0.1, gamma constant)."""
+    g = golden("ot_ode_step_afhq256_random_inpainting")
+    cfg = O.unet_config(**CFGS["afhq256"]); sd = O.synthetic_state_dict(cfg, 0)
+    B, S, sigma = int(g["B"]), 256, float(g["sigma"])
+    degradation = O.RandomInpainting(0.7)
+    clean = det_image((B, 3, S, S), 31)
+    y = O.make_measurement(clean, degradation, sigma, 0, noise=det_normal((B, 3, S, S), 61, 0))
+    _check_crops(y, g, "noisy", 1e-6)
+
+    class _Stop(Exception):
+        pass
+    its = {}
+
+    def rec(it, xx):
+        its[it] = xx.clone()
+        raise _Stop()
+    try:
+        O.ot_ode_restore(lambda a, t: O.unet_forward(sd, cfg, a, t), lambda a, t, v: O.unet_vjp(sd, cfg, a, t, v), degradation,
+                         "random_inpainting", y, sigma, steps=100, start_time=0.1, gamma="constant",
+                         init_noise=det_normal((B, 3, S, S), 61, 1), record=rec)
+    except _Stop:
+        pass
+    _check_crops(its[10], g, "x_it10", 2e-5 * float(np.abs(g["x_it10_crop"]).max()))

@@ -38,14 +38,21 @@ def _worker(rank, world, port, G, q):
     noise = global_measurement_noise(3, (G, 1, 4, 4), lo, hi)
     # shard of the global random-inpainting mask
     mask = np.random.RandomState(42).binomial(n=1, p=0.3, size=(G, 8, 8))[lo:hi]
+    # the metric bookkeeping of a sharded solve_ip: gathered mean, written by rank 0 only
+    from pnpflow_amd import utils
+    from pnpflow_amd.parallel import rank_world
+    assert rank_world() == (rank, world)
+    args = utils.CfgNode(dict(save_path_ip=os.environ["PF_TEST_DIR"], batch=0))
+    utils._append_metric(args, "psnr", "rec", 5, utils._global_mean(local))
     q.put((rank, allp.tolist(), m, noise.numpy(), mask))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("G", [8, 7])
-def test_two_rank_gather_and_global_draws(G):
+def test_two_rank_gather_and_global_draws(G, tmp_path):
     world, port = 2, _free_port()
+    os.environ["PF_TEST_DIR"] = str(tmp_path)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, G, q)) for r in range(world)]
@@ -62,3 +69,5 @@ def test_two_rank_gather_and_global_draws(G):
     full = torch.randn((G, 1, 4, 4), generator=g).numpy()
     np.testing.assert_array_equal(np.concatenate([r[3] for r in res]), full)
     np.testing.assert_array_equal(np.concatenate([r[4] for r in res]), O.random_mask_array(G, 8, 8, 0.7))
+    lines = open(os.path.join(str(tmp_path), "psnr_rec_batch0.txt")).read().strip().splitlines()
+    assert len(lines) == 1 and lines[0].split()[0] == "5" and abs(float(lines[0].split()[1]) - float(np.mean(expect))) < 1e-9

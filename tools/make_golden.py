@@ -281,10 +281,69 @@ def gen_ot_ode(models, degr, utils):
         print("ot_ode", tag, iterates[steps - 1].abs().mean().item())
 
 
+def crop_rec(prefix, t):
+    """crop + corner + float64 checksums of a (B,C,H,W) tensor (the big-net fixtures stay small)."""
+    H = t.shape[2]
+    return {prefix + "_crop": t[:, :, H // 2 - 16:H // 2 + 16, H // 2 - 16:H // 2 + 16].numpy().copy(),
+            prefix + "_corner": t[:, :, :8, :8].numpy().copy(), prefix + "_checksum": checksums(t)}
+
+
+def gen_big(models, degr, utils):
+    """BASELINE-size nets (C4/C5): the reference's autograd VJP on the 34.5 M / 31.0 M parameter nets
+    (ot_ode.py:137-138) and ONE real OT_ODE.solve_ip Euler step at 256^2 with random inpainting (config C5: steps_ode=100,
+    start_time=0.1, gamma constant -> iteration 10, t = 0.1)."""
+    import pnpflow.methods.ot_ode as ot
+    for net in ("celeba128", "afhq256"):
+        m, cfg, sd = build_ref_unet(models, net)
+        c = CFGS[net]; S = c["input_height"]
+        x = det_normal((1, 3, S, S), 51); vec = det_normal((1, 3, S, S), 52)
+        t = torch.tensor([0.25])
+        g = torch.autograd.functional.vjp(lambda z: m(z, t), inputs=x, v=vec)[1]
+        rec = dict(t=t.numpy(), g_absmax=np.array(float(g.abs().max())))
+        rec.update(crop_rec("g", g))
+        np.savez_compressed(os.path.join(OUT, f"vjp_{net}.npz"), **rec)
+        print("vjp", net, g.abs().mean().item())
+    # one C5-shaped Euler step of the real solver
+    m, cfg, sd = build_ref_unet(models, "afhq256")
+    S, B, sigma = 256, 2, 0.01
+    degradation = degr.RandomInpainting(0.7)
+    clean = det_image((B, 3, S, S), 31)
+    args = utils.CfgNode(dict(method="ot_ode", model="ot", dataset="afhq_cat", problem="random_inpainting", steps_ode=100, start_time=0.1,
+                              gamma="constant", max_batch=1, compute_time=False, compute_memory=False, save_results=True, batch=0,
+                              save_path_ip="/tmp"))
+    iterates = {}; seq = {"n": 0}
+
+    class _Stop(Exception):
+        pass
+
+    def fake_randn_like(like, **kw):
+        i = seq["n"]; seq["n"] += 1
+        return det_normal(tuple(like.shape), 61, i)        # call 0: measurement noise, call 1: initialisation noise
+
+    def cap_psnr(clean_img, noisy_img, rec_img, a, H_adj, iter="final"):
+        iterates[int(iter)] = rec_img.clone(); iterates["noisy"] = noisy_img.clone()
+        raise _Stop()                                       # iteration 10 is the first one and a logging iteration: stop after it
+    noop = lambda *a, **k: None
+    saved = (torch.randn_like, utils.compute_psnr, utils.compute_ssim, utils.compute_lpips, utils.save_images)
+    torch.randn_like = fake_randn_like
+    utils.compute_psnr, utils.compute_ssim, utils.compute_lpips, utils.save_images = cap_psnr, noop, noop, noop
+    try:
+        ot.OT_ODE(m, torch.device("cpu"), args).solve_ip([(clean, torch.zeros(B))], degradation, sigma)
+    except _Stop:
+        pass
+    finally:
+        (torch.randn_like, utils.compute_psnr, utils.compute_ssim, utils.compute_lpips, utils.save_images) = saved
+    assert seq["n"] == 2 and 10 in iterates
+    rec = dict(steps=np.array(100), start_time=np.array(0.1), sigma=np.array(sigma), first=np.array(10), B=np.array(B))
+    rec.update(crop_rec("noisy", iterates["noisy"])); rec.update(crop_rec("x_it10", iterates[10]))
+    np.savez_compressed(os.path.join(OUT, "ot_ode_step_afhq256_random_inpainting.npz"), **rec)
+    print("ot_ode step afhq256", iterates[10].abs().mean().item())
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     models, degr, utils, pnp = import_reference()
-    which = sys.argv[1:] or ["unet", "degr", "traj", "ot_ode"]
+    which = sys.argv[1:] or ["unet", "degr", "traj", "ot_ode", "big"]
     if "unet" in which:
         gen_unet(models)
     if "degr" in which:
@@ -293,3 +352,5 @@ if __name__ == "__main__":
         gen_traj(models, degr, utils, pnp)
     if "ot_ode" in which:
         gen_ot_ode(models, degr, utils)
+    if "big" in which:
+        gen_big(models, degr, utils)

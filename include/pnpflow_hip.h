@@ -33,7 +33,8 @@ typedef enum pf_status {
     PF_ERR_INVALID = -1,     /* bad argument / unsupported configuration */
     PF_ERR_HIP = -2,         /* a HIP runtime call failed */
     PF_ERR_WEIGHTS = -3,     /* unknown / missing / mis-shaped weight tensor */
-    PF_ERR_STATE = -4        /* call made in the wrong state (e.g. forward before finalize) */
+    PF_ERR_STATE = -4,       /* call made in the wrong state (e.g. forward before finalize) */
+    PF_ERR_NUMERIC = -5      /* a non-finite activation was detected inside the U-Net (see pf_engine_check_numerics) */
 } pf_status;
 
 typedef struct pf_engine pf_engine;
@@ -209,6 +210,13 @@ typedef void (*pf_iter_callback)(int iteration, void* user);
 int pf_pnp_flow_restore(pf_engine* e, const pf_degradation* d, const pf_pnp_params* prm,
                         const float* y, float* x_out, int B, void* stream,
                         pf_iter_callback iter_cb, void* user);
+
+/* Numeric health of the forwards run so far: every GroupNorm finalisation checks the activation statistics it consumes; an
+ * overflow / NaN anywhere upstream makes them non-finite and sets a device flag.  This call synchronises `stream`, returns
+ * PF_ERR_NUMERIC if the flag was set (and clears it), PF_OK otherwise.  pf_pnp_flow_restore checks it before returning.
+ * (The reference computes in plain fp32, pnpflow/models.py:94-113; the split-fp16 operands of the default precision mode are
+ * range-guarded by a per-image power-of-two scale, this is the loud backstop.) */
+int pf_engine_check_numerics(pf_engine* e, void* stream);
 
 /* device bytes currently held by the engine (weights, activation plans, solver buffers): what torch.cuda.max_memory_allocated
  * cannot see of the reference's `compute_memory` bookkeeping (pnpflow/methods/pnp_flow.py:99-100, 141-146). */

@@ -73,6 +73,7 @@ SIGNATURES = {
     "pf_ssim": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pf_pnp_flow_restore": (C.c_int, [C.c_void_p, C.POINTER(PfDegradation), C.POINTER(PfPnpParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, ITER_CB, C.c_void_p]),
     "pf_engine_memory_bytes": (C.c_int64, [C.c_void_p]),
+    "pf_engine_check_numerics": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pf_engine_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "pf_engine_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

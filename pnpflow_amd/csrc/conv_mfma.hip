@@ -125,27 +125,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     // first chunk's activations go in flight before anything else
     prefetch(0, 0);
 
-    // ---- GroupNorm scale/shift of this sample from the producers' per-channel stats ----
-    for (int c = tid; c < p.gn_C; c += 256) {
-        const int g = c / p.gn_cpg;
-        double s = 0.0, ss = 0.0;
-        for (int j = g * p.gn_cpg; j < (g + 1) * p.gn_cpg; ++j) {
-            for (int si = 0; si < p.nseg; ++si) {
-                const ConvSeg& sg = p.seg[si];
-                if (sg.xform != 0 && j >= sg.gn_off && j < sg.gn_off + sg.C) {
-                    const double* st = sg.stats + ((size_t)b * sg.C + (j - sg.gn_off)) * 2;
-                    s += st[0]; ss += st[1];
-                }
-            }
-        }
-        const double N = (double)p.gn_cpg * (double)p.Hs * (double)p.Ws;
-        const double mean = s / N;
-        double var = ss / N - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
-        const float sc = p.gamma[c] * rstd;
-        s_sc[c] = sc;
-        s_sh[c] = p.beta[c] - (float)mean * sc;
+    // ---- GroupNorm scale/shift of this sample: finalised once per launch by gn_coef_kernel (unet_misc.hip) ----
+    if (p.gn_C > 0) {
+        const float* cb = p.coef + (size_t)b * 2 * p.coef_stride;
+        for (int c = tid; c < p.gn_C; c += 256) { s_sc[c] = cb[c]; s_sh[c] = cb[p.coef_stride + c]; }
     }
 
     f32x16 acc[MT][NT];

@@ -36,7 +36,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float silu_fast16(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 template <int MT, int NT, int WM, int WN, int S, int UP, int KC>
-__global__ __launch_bounds__(256, ((MT == 4 && WM == 2 && KC == 16) ? 3 : 1)) void conv_mfma16_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (((MT == 4 && WM == 2 && KC == 16) || (KC != 64 && ((MT == 4 && WM == 1) || (MT == 2 && WM == 4)))) ? 3 : 1)) void conv_mfma16_kernel(const ConvParams p) {
     constexpr int ROW = KC + 4;                  // dwords per LDS row: KC/2 (hi) + KC/2 (lo) + 4 (pad)
     constexpr int KQ = KC / 4, KH = KC / 2, KS = KC / 16;
     constexpr int TH = 2 * MT * WM, TW = 16;
@@ -62,6 +62,10 @@ __global__ __launch_bounds__(256, ((MT == 4 && WM == 2 && KC == 16) ? 3 : 1)) vo
     const int wm = wave % WM, wn = wave / WM;
     const int Hv = UP ? 2 * p.Hs : p.Hs, Wv = UP ? 2 * p.Ws : p.Ws;
     const int qi = tid % KQ, q4 = qi * 4;
+    // power-of-two operand scales of this image, one per K-segment (1 unless the operands are far from O(1)): see ConvParams::scale
+    float seg_scale[3], seg_inv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { seg_scale[i] = p.scale != nullptr ? p.scale[8 * b + i] : 1.0f; seg_inv[i] = p.scale != nullptr ? p.scale[8 * b + 4 + i] : 1.0f; }
 
     int a_pix[A_PER];                            // source pixel of staged float4 number tid + i*256 (-1: zero); its LDS slot is recomputed when used
 #pragma unroll
@@ -96,6 +100,7 @@ __global__ __launch_bounds__(256, ((MT == 4 && WM == 2 && KC == 16) ? 3 : 1)) vo
             sc = *reinterpret_cast<const float4*>(s_sc + sg.gn_off + c);
             sh = *reinterpret_cast<const float4*>(s_sh + sg.gn_off + c);
         }
+        const float a_scale = si == 0 ? seg_scale[0] : (si == 1 ? seg_scale[1] : seg_scale[2]);
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             if (tid + i * 256 < A_F4) {
@@ -108,6 +113,7 @@ __global__ __launch_bounds__(256, ((MT == 4 && WM == 2 && KC == 16) ? 3 : 1)) vo
                         v.x = silu_fast16(v.x); v.y = silu_fast16(v.y); v.z = silu_fast16(v.z); v.w = silu_fast16(v.w);
                     }
                 }
+                v.x *= a_scale; v.y *= a_scale; v.z *= a_scale; v.w *= a_scale;
                 if (!(cok && a_pix[i] >= 0)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 // opaque to the optimiser: the hi that is stored and the hi that is subtracted must be the SAME rounding of
                 // the SAME fp32 value.  With -ffp-contract=fast hipcc may otherwise fuse the producing multiply into the
@@ -134,53 +140,26 @@ __global__ __launch_bounds__(256, ((MT == 4 && WM == 2 && KC == 16) ? 3 : 1)) vo
 #else
     auto mark = [](int) {};
 #endif
-    // GroupNorm coefficients of image b.  The (sum, sumsq) pair of every normalised channel is requested BEFORE the first
-    // patch chunk (loads return in order: behind the patch they would only arrive after it, and the fp64 finalisation
-    // would then sit on the critical path instead of in the shadow of the patch latency); the pairs are exchanged
-    // through LDS (over the not yet written patch) so that each thread can sum its group.
+    // GroupNorm coefficients of image b: finalised once per launch by gn_coef_kernel (unet_misc.hip); requested BEFORE the
+    // first patch chunk (loads return in order) and parked in LDS behind the patch, where the staging reads them.
     constexpr int GNP = 4;                       // passes of 256 channels: gn_C <= 1024 (checked by the launcher)
-    double gsum[GNP], gsq[GNP]; float gga[GNP], gbe[GNP];
+    float csc[GNP], csh[GNP];
+    {
+        const float* cb = p.coef + (size_t)b * 2 * p.coef_stride;
 #pragma unroll
-    for (int i = 0; i < GNP; ++i) {
-        const int c = tid + i * 256;
-        gsum[i] = 0.0; gsq[i] = 0.0; gga[i] = 0.f; gbe[i] = 0.f;
-        if (c < p.gn_C && !PF_DBG(64)) {
-            for (int si = 0; si < p.nseg; ++si) {
-                const ConvSeg& sg = p.seg[si];
-                if (sg.xform != 0 && c >= sg.gn_off && c < sg.gn_off + sg.C) {
-                    const double* st = sg.stats + ((size_t)b * sg.C + (c - sg.gn_off)) * 2;
-                    gsum[i] = st[0]; gsq[i] = st[1];
-                }
+        for (int i = 0; i < GNP; ++i) {
+            csc[i] = 0.f; csh[i] = 0.f;
+            if (i * 256 < p.gn_C) {                                     // uniform: skips whole passes
+                const int c = min(tid + i * 256, p.gn_C - 1);
+                csc[i] = cb[c]; csh[i] = cb[p.coef_stride + c];
             }
-            gga[i] = p.gamma[c]; gbe[i] = p.beta[c];
         }
     }
     prefetch(0, 0);
-    if (p.gn_C > 0) {
-        double* s_st = reinterpret_cast<double*>(s_patch);          // [gn_C][2]
 #pragma unroll
-        for (int i = 0; i < GNP; ++i) {
-            const int c = tid + i * 256;
-            if (c < p.gn_C) { s_st[2 * c] = gsum[i]; s_st[2 * c + 1] = gsq[i]; }
-        }
-        __syncthreads();
-        const double inv_n = 1.0 / ((double)p.gn_cpg * (double)p.Hs * (double)p.Ws);      // one fp64 division per thread instead of three per channel
-#pragma unroll
-        for (int i = 0; i < GNP; ++i) {
-            const int c = tid + i * 256;
-            if (c < p.gn_C) {
-                const int g0 = (c / p.gn_cpg) * p.gn_cpg;
-                double sm = 0.0, ss = 0.0;
-                for (int j = g0; j < g0 + p.gn_cpg; ++j) { sm += s_st[2 * j]; ss += s_st[2 * j + 1]; }
-                const double mean = sm * inv_n;
-                double var = ss * inv_n - mean * mean;
-                var = var > 0.0 ? var : 0.0;
-                const float rstd = __builtin_amdgcn_rsqf((float)(var + (double)p.gn_eps));     // v_rsq_f32, 1 ulp (the reference's GroupNorm takes rsqrt in fp32 too)
-                const float sc = gga[i] * rstd;
-                s_sc[c] = sc;
-                s_sh[c] = gbe[i] - (float)mean * sc;
-            }
-        }
+    for (int i = 0; i < GNP; ++i) {
+        const int c = tid + i * 256;
+        if (c < p.gn_C) { s_sc[c] = csc[i]; s_sh[c] = csh[i]; }          // visible to store_lds after the chunk loop's first barrier
     }
 
     f32x16 acc[MT][NT];
@@ -211,6 +190,18 @@ __global__ __launch_bounds__(256, ((MT == 4 && WM == 2 && KC == 16) ? 3 : 1)) vo
     mark(0);
     while (true) {
         const ConvSeg& sg = p.seg[si];
+        if (ch == 0 && si > 0) {
+            // the accumulator changes units: from segment si-1's operand scale to segment si's (both powers of two: exact)
+            const float ratio = (si == 1 ? seg_scale[1] * seg_inv[0] : seg_scale[2] * seg_inv[1]);
+            if (ratio != 1.0f) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= ratio;
+            }
+        }
         __syncthreads();
         if (!PF_DBG(2) || (si == 0 && ch == 0)) store_lds(si, ch);
         __syncthreads();
@@ -282,7 +273,7 @@ __global__ __launch_bounds__(256, ((MT == 4 && WM == 2 && KC == 16) ? 3 : 1)) vo
     constexpr int TP = 36;                             // scratch row pitch in floats (32 + 4 pad)
     float* s_tr = reinterpret_cast<float*>(s_patch) + wave * (32 * TP);
     float* s_red = reinterpret_cast<float*>(s_patch) + 4 * 32 * TP;   // [WM][BN][2] behind the 4 scratch tiles
-    const float oscale = p.out_scale * (1.0f / 256.0f);
+    const float oscale = p.out_scale * (1.0f / 256.0f) * (p.nseg == 1 ? seg_inv[0] : (p.nseg == 2 ? seg_inv[1] : seg_inv[2]));
     const int cq = lane & 7;                           // this lane's channel quad inside a 32-channel tile
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -425,7 +416,7 @@ static hipError_t launch_sel16(const ConvParams& p, hipStream_t stream) {
 // Only fragment-major packed weights (w_mode 0) with a 16-bit repack are supported; the caller keeps the
 // fp32 kernel (launch_conv) for the generic strided operands of attention.
 hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t stream) {
-    if (p.gn_C > 1024) return hipErrorInvalidValue;      // the kernel finalises at most 4 x 256 GroupNorm channels
+    if (p.gn_C > 1024 || (p.gn_C > 0 && p.coef == nullptr)) return hipErrorInvalidValue;      // the kernel parks at most 4 x 256 GroupNorm channels
     bool all_1tap = true;
     for (int i = 0; i < p.nseg; ++i) {
         if (p.seg[i].w_mode != 0 || p.seg[i].w16 == nullptr) return hipErrorInvalidValue;

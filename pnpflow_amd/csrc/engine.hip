@@ -35,7 +35,7 @@ struct LevelDesc { std::vector<ResDesc> blocks; std::string resample; int res_ch
 
 struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; double* stats = nullptr; };
 
-enum OpKind { OP_MEMSET, OP_TEMB, OP_BEGIN, OP_CONV, OP_SOFTMAX, OP_ATTN, OP_END,
+enum OpKind { OP_MEMSET, OP_TEMB, OP_BEGIN, OP_CONV, OP_SOFTMAX, OP_ATTN, OP_END, OP_GN_COEF,
               // backward-only
               OP_GN_FWD_COEF, OP_GN_BWD_PRE, OP_GN_BWD_COEF, OP_GN_BWD_POST, OP_TRANSPOSE, OP_SOFTMAX_BWD, OP_SUMPOOL };
 struct Op {
@@ -46,6 +46,7 @@ struct Op {
     void* ptr = nullptr; size_t bytes = 0;          // memset
     float* sm = nullptr; int64_t sm_rows = 0; int sm_cols = 0;
     AttnParams ap{};
+    GnCoefParams gp{};
     size_t flops = 0;
     // generic slots of the backward helper ops
     const void* P[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -73,6 +74,10 @@ struct Plan {
     std::vector<void*> allocs;
     std::vector<Tap> taps;
     size_t gemm_flops = 0;
+    // per-launch GroupNorm coefficients / operand scales (one buffer: the launches of a plan are stream-ordered) and the
+    // numeric-health flag word their finalisation kernel sets
+    float* coef = nullptr; float* scale = nullptr; unsigned int* flags = nullptr;
+    static constexpr int COEF_STRIDE = 1024;
     // retained-activation plans (VJP): forward tape + backward op list
     bool retain = false;
     std::vector<TapeRec> tape;
@@ -362,7 +367,36 @@ static void add_seg(ConvParams& p, const Tensor& t, int xform, int taps, int gn_
     s.src = t.p; s.C = t.C; s.cstride = t.C; s.coff = 0; s.xform = xform; s.taps = taps; s.gn_off = gn_off; s.stats = t.stats;
 }
 
-static void push_conv(Builder& bd, const ConvParams& p, int stride = 1, int up = 0) {
+// GroupNorm coefficients (and, in the split-fp16 mode, the power-of-two operand scale) of a conv launch are finalised by a
+// micro-launch right before it; returns the ConvParams with coef / scale filled in
+static ConvParams with_coef(Builder& bd, ConvParams p, std::vector<Op>& ops) {
+    Plan* plan = bd.plan;
+    if (!plan->coef) {
+        plan->coef = bd.acquire((size_t)bd.B * 2 * Plan::COEF_STRIDE);
+        plan->scale = bd.acquire((size_t)bd.B * 8);
+        plan->flags = reinterpret_cast<unsigned int*>(bd.acquire(64));
+        if (plan->flags) hipMemset(plan->flags, 0, 64);
+    }
+    bool raw_stats = false, packed16 = true;
+    for (int i = 0; i < p.nseg; ++i) {
+        raw_stats |= p.seg[i].xform == 0 && p.seg[i].stats != nullptr;
+        packed16 &= p.seg[i].w_mode == 0 && p.seg[i].w16 != nullptr;
+    }
+    const bool want_scale = bd.e->precision != 0 && packed16 && (raw_stats || p.gn_C > 0);
+    if (p.gn_C == 0 && !want_scale) return p;
+    Op op{}; op.kind = OP_GN_COEF;
+    GnCoefParams& g = op.gp;
+    g.nseg = p.nseg;
+    for (int i = 0; i < p.nseg; ++i) { g.st[i] = p.seg[i].stats; g.C[i] = p.seg[i].C; g.xform[i] = p.seg[i].xform; g.gn_off[i] = p.seg[i].gn_off; }
+    g.gn_C = p.gn_C; g.gn_cpg = p.gn_cpg; g.HW = p.Hs * p.Ws; g.eps = p.gn_eps; g.gamma = p.gamma; g.beta = p.beta;
+    g.coef = plan->coef; g.coef_stride = Plan::COEF_STRIDE; g.scale = want_scale ? plan->scale : nullptr; g.flags = plan->flags;
+    ops.push_back(op);
+    p.coef = plan->coef; p.coef_stride = Plan::COEF_STRIDE; p.scale = want_scale ? plan->scale : nullptr;
+    return p;
+}
+
+static void push_conv(Builder& bd, const ConvParams& p0, int stride = 1, int up = 0) {
+    const ConvParams p = with_coef(bd, p0, bd.plan->ops);
     Op op{}; op.kind = OP_CONV; op.cp = p; op.stride = stride; op.up = up; op.flops = conv_flops(p);
     bd.plan->gemm_flops += op.flops;
     bd.plan->ops.push_back(op);
@@ -525,6 +559,7 @@ static void fix_stats(Op& op, double* slab) {
     auto fx = [&](const double*& p) { if (p) p = (const double*)((char*)slab + ((uintptr_t)p - 1)); };
     auto fxm = [&](double*& p) { if (p) p = (double*)((char*)slab + ((uintptr_t)p - 1)); };
     if (op.kind == OP_CONV) { for (int i = 0; i < op.cp.nseg; ++i) fx(op.cp.seg[i].stats); fxm(op.cp.stats_out); }
+    if (op.kind == OP_GN_COEF) for (int i = 0; i < op.gp.nseg; ++i) fx(op.gp.st[i]);
     if (op.kind == OP_END) fx(op.ep.stats);
     if (op.kind == OP_BEGIN) fxm(op.ep.stats_out);
     if (op.kind == OP_GN_FWD_COEF) { const double* a = (const double*)op.P[0]; const double* b2 = (const double*)op.P[1]; fx(a); fx(b2); op.P[0] = a; op.P[1] = b2; }
@@ -1002,6 +1037,8 @@ static int run_plan(pf_engine* e, Plan* plan, const float* x, const float* t, fl
             case OP_SOFTMAX: r = launch_softmax_rows(op.sm, op.sm_rows, op.sm_cols, s); break;
             case OP_ATTN: r = launch_attn_fused(op.ap, s); break;
             case OP_END: { EdgeConvParams ep = op.ep; ep.out = v; r = launch_end_conv(ep, s); break; }
+            case OP_GN_COEF: r = launch_gn_coef(op.gp, plan->B, s); break;
+            default: break;
         }
         if (r != hipSuccess) { e->err = std::string("kernel launch failed: ") + hipGetErrorString(r); return PF_ERR_HIP; }
     }
@@ -1050,6 +1087,23 @@ int pf_engine_create(int device_id, const pf_unet_cfg* cfg, pf_engine** out) {
     int rc = build_arch(e);
     if (rc != PF_OK) { g_create_err = e->err; delete e; return rc; }
     *out = e;
+    return PF_OK;
+}
+
+// reads (and clears) the numeric-health flags of every plan; the caller has synchronised the stream(s) that ran them
+static int check_flags(pf_engine* e) {
+    bool bad = false;
+    for (auto& kv : e->plans) {
+        Plan* pl = kv.second.get();
+        if (!pl->flags) continue;
+        unsigned int f = 0;
+        HIPCHK(e, hipMemcpy(&f, pl->flags, sizeof f, hipMemcpyDeviceToHost));
+        if (f) { bad = true; HIPCHK(e, hipMemset(pl->flags, 0, sizeof f)); }
+    }
+    if (bad) {
+        e->err = "non-finite activation statistics: an activation overflowed or was NaN inside the U-Net (inputs / weights out of range)";
+        return PF_ERR_NUMERIC;
+    }
     return PF_OK;
 }
 
@@ -1411,10 +1465,17 @@ int pf_pnp_flow_restore(pf_engine* e, const pf_degradation* d, const pf_pnp_para
     }
     HIPCHK(e, hipMemcpyAsync(x_out, b.x, (size_t)B * n * 4, hipMemcpyDeviceToDevice, s));
     HIPCHK(e, hipStreamSynchronize(s));
-    return PF_OK;
+    return check_flags(e);
 }
 
 int64_t pf_engine_memory_bytes(const pf_engine* e) { return e ? e->bytes : 0; }
+
+int pf_engine_check_numerics(pf_engine* e, void* stream) {
+    if (!e) return PF_ERR_INVALID;
+    USE_DEVICE(e);
+    HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
+    return check_flags(e);
+}
 
 int pf_engine_profile(pf_engine* e, int enable) {
     if (!e) return PF_ERR_INVALID;

@@ -43,6 +43,16 @@ struct ConvParams {
     float gn_eps;
     const float* gamma;   // [gn_C]
     const float* beta;
+    // Per-image GroupNorm coefficients of this launch, finalised ONCE per launch by gn_coef_kernel (launch_gn_coef) instead of
+    // by every workgroup: coef[(b*2 + 0)*coef_stride + c] = gamma[c]*rstd, coef[(b*2 + 1)*coef_stride + c] = beta[c] - mean*gamma[c]*rstd
+    // over the gn_C normalised channels; nullptr only when gn_C == 0.
+    const float* coef;
+    int coef_stride;
+    // Power-of-two operand scales of image b (split-fp16 kernels only; nullptr = 1): the staged activations of K-segment si are
+    // multiplied by scale[8b + si] before they are split into fp16 hi/lo; the accumulator is kept in the units of the segment
+    // being walked (multiplied by scale[8b + si'] * scale[8b + 4 + si] at a switch si -> si', exact) and by scale[8b + 4 + last]
+    // in the epilogue - so raw (un-normalised) inputs of any magnitude keep fp32-grade relative accuracy and cannot overflow fp16.
+    const float* scale;
     unsigned long long* trace;   // profiling only: per-launch phase cycle sums [prologue, staging, k-loop, epilogue, stats, workgroups], or nullptr
     int dbg;              // ablation switches for profiling (0 in production): 1 skip MFMAs, 2 skip re-staging, 4 skip LDS A reads, 8 skip B loads, 16 skip epilogue global traffic
 };
@@ -76,8 +86,23 @@ struct TembParams {
     int B, ch, total_out;
 };
 
+// GroupNorm coefficient / operand-scale finalisation of one conv launch (unet_misc.hip): one block per image
+struct GnCoefParams {
+    const double* st[3];  // per K-segment of the consuming launch: per-channel (sum, sumsq) [B][C][2] of its source, or nullptr
+    int C[3], xform[3], gn_off[3];
+    int nseg, gn_C, gn_cpg, HW;      // HW = pixels of the SOURCE tensors (what the statistics were summed over)
+    float eps;
+    const float* gamma; const float* beta;
+    float* coef; int coef_stride;    // see ConvParams::coef (written only when gn_C > 0)
+    float* scale;                    // [B][8] (s of segment 0..2, pad, 1/s of segment 0..2, pad), or nullptr
+    unsigned int* flags;             // bit 0 is set when a statistic is not finite (an activation overflowed / NaN upstream)
+};
+hipError_t launch_gn_coef(const GnCoefParams& p, int B, hipStream_t s);
+
 hipError_t launch_conv(const ConvParams& p, int stride, int up, hipStream_t s);
 hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t s);   // split-fp16 MFMA variant
+bool conv_ws_supported(const ConvParams& p, int stride, int up);
+hipError_t launch_conv_ws(const ConvParams& p, hipStream_t s);                     // wave-specialised persistent split-fp16 variant (conv_ws.hip)
 size_t conv_flops(const ConvParams& p);
 hipError_t launch_begin_conv(const EdgeConvParams& p, hipStream_t s);
 hipError_t launch_end_conv(const EdgeConvParams& p, hipStream_t s);

@@ -255,4 +255,108 @@ hipError_t launch_softmax_rows(float* data, int64_t rows, int cols, hipStream_t 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------
+// GroupNorm coefficients + operand scale of ONE conv launch, finalised once per image (models.py:33-38: GroupNorm(32 groups,
+// eps 1e-6) over the - possibly concatenated - input of the conv).  Round 1 redid this fp64 finalisation in the prologue of
+// every workgroup of the consuming launch (10 240 workgroups per 128^2-level launch each re-deriving the same 160 images'
+// coefficients: the "15 % prologue" of profiles/r02_phase_trace_baseline.txt); now it is one micro-launch of B blocks and the
+// conv prologue is two coalesced loads.
+//   coef  sc[c] = gamma[c]*rstd_g, sh[c] = beta[c] - mean_g*sc[c]  (the statistics of a group may straddle two source tensors)
+//   scale one power of two per K-segment, s * rms(staged operands of the segment) in [1/4, 64]: rms of a raw segment from its
+//         (sum x^2) statistics, of the normalised ones from gamma/beta; s = 1 whenever the operands already are in that window
+//         (every BASELINE net with weights of ordinary magnitude), so the guard costs one exact multiply and changes no result
+//         there.  The conv kernel keeps its accumulator in the units of the segment it is walking (exact power-of-two rescale
+//         at a segment switch) and undoes the last segment's scale in the epilogue.  Layout: scale[8b + si] = s, [8b + 4 + si] = 1/s
+//   flags bit 0 when a statistic is not finite: an upstream activation overflowed (or was NaN) - reported by
+//         pf_engine_check_numerics / at the end of the solver loops instead of propagating silently
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_coef_kernel(const GnCoefParams p) {
+    __shared__ double s_st[2 * 1024];
+    __shared__ double s_red[16];
+    __shared__ int s_bad;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) s_bad = 0;
+    bool bad = false;
+    // (sum, sumsq) of every normalised channel, in GroupNorm channel order
+    for (int c = tid; c < p.gn_C; c += 256) {
+        double a = 0.0, q = 0.0;
+        for (int si = 0; si < p.nseg; ++si)
+            if (p.xform[si] != 0 && c >= p.gn_off[si] && c < p.gn_off[si] + p.C[si]) {
+                const double* st = p.st[si] + ((size_t)b * p.C[si] + (c - p.gn_off[si])) * 2;
+                a = st[0]; q = st[1];
+            }
+        bad |= !(isfinite(a) && isfinite(q));
+        s_st[2 * c] = a; s_st[2 * c + 1] = q;
+    }
+    // mean square of each raw segment that carries statistics
+    double raw_ss[3] = {0.0, 0.0, 0.0};
+    for (int si = 0; si < p.nseg; ++si)
+        if (p.xform[si] == 0 && p.st[si] != nullptr)
+            for (int c = tid; c < p.C[si]; c += 256) {
+                const double q = p.st[si][((size_t)b * p.C[si] + c) * 2 + 1];
+                bad |= !isfinite(q);
+                raw_ss[si] += q;
+            }
+    __syncthreads();
+    double gn_ms = 0.0;
+    const double inv_n = 1.0 / ((double)p.gn_cpg * (double)p.HW);
+    for (int c = tid; c < p.gn_C; c += 256) {
+        const int g0 = (c / p.gn_cpg) * p.gn_cpg;
+        double sm = 0.0, ss = 0.0;
+        for (int j = g0; j < g0 + p.gn_cpg; ++j) { sm += s_st[2 * j]; ss += s_st[2 * j + 1]; }
+        const double mean = sm * inv_n;
+        double var = ss * inv_n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+        const float ga = p.gamma[c], be = p.beta[c];
+        const float sc = ga * rstd;
+        p.coef[((size_t)b * 2 + 0) * p.coef_stride + c] = sc;
+        p.coef[((size_t)b * 2 + 1) * p.coef_stride + c] = be - (float)mean * sc;
+        gn_ms += (double)ga * ga + (double)be * be;          // E[(gamma*xhat + beta)^2] with E[xhat] = 0, E[xhat^2] = 1 per group
+    }
+    if (bad) atomicOr(&s_bad, 1);
+    if (p.scale != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            gn_ms += __shfl_xor(gn_ms, o);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) raw_ss[k] += __shfl_xor(raw_ss[k], o);
+        }
+        if ((tid & 63) == 0) { s_red[(tid >> 6) * 4] = gn_ms; for (int k = 0; k < 3; ++k) s_red[(tid >> 6) * 4 + 1 + k] = raw_ss[k]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (s_bad && p.flags != nullptr) atomicOr(p.flags, 1u);
+        if (p.scale != nullptr) {
+            auto pow2_for = [](double ms) {            // power of two s with s*rms in [0.5, 1) when rms is outside [1/4, 64]; else 1
+                float s = 1.0f;
+                const float rms = (float)sqrt(ms);
+                if (isfinite(rms) && rms > 0.f && (rms < 0.25f || rms > 64.f)) {
+                    int e; frexpf(rms, &e);
+                    e = e < -40 ? -40 : (e > 40 ? 40 : e);
+                    s = ldexpf(1.0f, -e);
+                }
+                return s;
+            };
+            const double gs = s_red[0] + s_red[4] + s_red[8] + s_red[12];
+            const float s_gn = p.gn_C > 0 ? pow2_for(gs / (double)p.gn_C) : 1.0f;
+            for (int si = 0; si < 3; ++si) {
+                float sv = 1.0f;
+                if (si < p.nseg) {
+                    if (p.xform[si] != 0) sv = s_gn;
+                    else if (p.st[si] != nullptr)
+                        sv = pow2_for((s_red[1 + si] + s_red[5 + si] + s_red[9 + si] + s_red[13 + si]) / ((double)p.C[si] * (double)p.HW));
+                }
+                p.scale[8 * b + si] = sv; p.scale[8 * b + 4 + si] = 1.0f / sv;
+            }
+        }
+    }
+}
+
+hipError_t launch_gn_coef(const GnCoefParams& p, int B, hipStream_t s) {
+    if (p.gn_C > 1024 || (p.gn_C > 0 && (p.coef == nullptr || p.gn_cpg <= 0))) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gn_coef_kernel, dim3(B), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 }  // namespace pf

@@ -85,6 +85,7 @@ class OT_ODE(object):
                                                  float(delta), B, n, st), None, "pf_ot_ode_update")
             if iter_cb is not None:
                 iter_cb(iteration, x)
+        self.model.check_numerics()
         return x
 
     def solve_ip(self, test_loader, degradation, sigma_noise, H_funcs=None):

@@ -148,6 +148,10 @@ class UNet:
         _lib.check(self._lib.pf_engine_set_precision(self._h, int(mode)), self._h, "pf_engine_set_precision")
         return self
 
+    def check_numerics(self):
+        """Synchronises the current stream and raises if any forward since the last check saw a non-finite activation."""
+        _lib.check(self._lib.pf_engine_check_numerics(self._h, _lib.current_stream_ptr()), self._h, "pf_engine_check_numerics")
+
     def memory_bytes(self) -> int:
         """Device bytes the engine currently holds (weights, activation plans, solver buffers)."""
         return int(self._lib.pf_engine_memory_bytes(self._h))

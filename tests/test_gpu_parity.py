@@ -792,3 +792,51 @@ def test_state_errors_are_loud(hip):
     solver = PNP_FLOW(m, torch.device("cuda"), CfgNode(dict(method="pnp_flow", model="ot")))
     a = solver.interpolation_step(x, torch.tensor(0.0).cuda()); b = solver.interpolation_step(x, torch.tensor(0.0).cuda())
     assert float((a - b).abs().max()) > 0.1
+
+
+def _scaled_model(name, scale_fn):
+    """tiny4-style model whose state_dict went through scale_fn(key, tensor); returns (hip model, cfg, sd)."""
+    from pnpflow_amd.models import UNet
+    c = CFGS[name]
+    cfg = O.unet_config(**c)
+    sd = {k: scale_fn(k, v.clone()) for k, v in O.synthetic_state_dict(cfg, 0).items()}
+    m = UNet(c["input_channels"], c["input_height"], c["ch"], ch_mult=c["ch_mult"], num_res_blocks=c["num_res_blocks"],
+             attn_resolutions=c["attn_resolutions"])
+    m.load_state_dict(sd)
+    return m, cfg, sd
+
+
+@pytest.mark.parametrize("case", ["large", "small"])
+def test_forward_range_guard(hip, case):
+    """The split-fp16 operands are range-guarded per image and per K-segment (power-of-two scale from the producer's
+    statistics): a residual stream of magnitude 1e6 (raw stride-2 / nearest-up / folded-shortcut inputs far above the fp16
+    maximum 65504) and one of magnitude 1e-7 (far below the fp16 normal range) both match the fp32 oracle, in the default
+    precision mode as in the exact-fp32 mode (reference: plain fp32, models.py:94-113)."""
+    if case == "large":
+        fn = lambda k, v: v * 1e6 if k.startswith("begin_conv.") else v
+    else:
+        tiny = ("begin_conv.", "conv2.", "proj_out.")
+        fn = lambda k, v: v * 1e-7 if any(t in k for t in tiny) else v
+    m, cfg, sd = _scaled_model("tiny4", fn)
+    x = det_normal((2, 3, 64, 64), 97); t = torch.tensor([0.15, 0.8])
+    with torch.no_grad():
+        ref = O.unet_forward(sd, cfg, x, t)
+    assert torch.isfinite(ref).all()
+    scale = float(ref.abs().max())
+    for prec in (0, 1):
+        m.set_precision(prec)
+        out = m(x.cuda(), t.cuda())
+        m.check_numerics()
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-4 * scale, err_msg=f"{case} precision {prec}")
+
+
+def test_overflow_is_loud(hip):
+    """Activations beyond fp32 range cannot be guarded: the GroupNorm finalisation sees non-finite statistics and the engine
+    reports PF_ERR_NUMERIC instead of returning garbage silently."""
+    m, cfg, sd = _scaled_model("tiny4", lambda k, v: v * 1e30 if k.startswith("begin_conv.") else v)
+    x = det_normal((1, 3, 64, 64), 98).cuda(); t = torch.tensor([0.5]).cuda()
+    m(x, t)
+    with pytest.raises(hip.PnpFlowHipError):
+        m.check_numerics()
+    m2, _, _ = model_for("tiny4")
+    m2(x, t); m2.check_numerics()                       # a healthy forward stays quiet

@@ -999,6 +999,7 @@ static hipError_t dispatch_conv(pf_engine* e, const Op& op, hipStream_t s) {
     if (e->precision != 0) {
         bool ok16 = true;
         for (int i = 0; i < op.cp.nseg; ++i) ok16 &= op.cp.seg[i].w_mode == 0 && op.cp.seg[i].w16 != nullptr;
+        if (ok16 && conv_ws_supported(op.cp, op.stride, op.up)) return launch_conv_ws(op.cp, s);
         if (ok16) return launch_conv16(op.cp, op.stride, op.up, s);
     }
     return launch_conv(op.cp, op.stride, op.up, s);

@@ -35,8 +35,16 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // v_exp_f32 / v_rcp_f32 (1 ulp each); __frcp_rn would be a correctly rounded division: 10 instructions per element
 __device__ __forceinline__ float silu_fast16(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// A/B switches of the profiling builds (tools/ab_variants.sh): PF_AB_GN_INKERNEL re-derives the GroupNorm coefficients in every
+// workgroup's prologue as round 1 did; PF_AB_NO_RESCALE drops the per-segment accumulator rescale and the register bound it needs
+#ifdef PF_AB_NO_RESCALE
+#define PF_LB3(MT, WM, KC) ((MT) == 4 && (WM) == 2 && (KC) == 16)
+#else
+#define PF_LB3(MT, WM, KC) (((MT) == 4 && (WM) == 2 && (KC) == 16) || ((KC) != 64 && (((MT) == 4 && (WM) == 1) || ((MT) == 2 && (WM) == 4))))
+#endif
+
 template <int MT, int NT, int WM, int WN, int S, int UP, int KC>
-__global__ __launch_bounds__(256, (((MT == 4 && WM == 2 && KC == 16) || (KC != 64 && ((MT == 4 && WM == 1) || (MT == 2 && WM == 4)))) ? 3 : 1)) void conv_mfma16_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16_kernel(const ConvParams p) {
     constexpr int ROW = KC + 4;                  // dwords per LDS row: KC/2 (hi) + KC/2 (lo) + 4 (pad)
     constexpr int KQ = KC / 4, KH = KC / 2, KS = KC / 16;
     constexpr int TH = 2 * MT * WM, TW = 16;
@@ -143,6 +151,47 @@ __global__ __launch_bounds__(256, (((MT == 4 && WM == 2 && KC == 16) || (KC != 6
     // GroupNorm coefficients of image b: finalised once per launch by gn_coef_kernel (unet_misc.hip); requested BEFORE the
     // first patch chunk (loads return in order) and parked in LDS behind the patch, where the staging reads them.
     constexpr int GNP = 4;                       // passes of 256 channels: gn_C <= 1024 (checked by the launcher)
+#ifdef PF_AB_GN_INKERNEL
+    double gsum[GNP], gsq[GNP]; float gga[GNP], gbe[GNP];
+#pragma unroll
+    for (int i = 0; i < GNP; ++i) {
+        const int c = tid + i * 256;
+        gsum[i] = 0.0; gsq[i] = 0.0; gga[i] = 0.f; gbe[i] = 0.f;
+        if (c < p.gn_C) {
+            for (int si = 0; si < p.nseg; ++si) {
+                const ConvSeg& sg = p.seg[si];
+                if (sg.xform != 0 && c >= sg.gn_off && c < sg.gn_off + sg.C) {
+                    const double* st = sg.stats + ((size_t)b * sg.C + (c - sg.gn_off)) * 2;
+                    gsum[i] = st[0]; gsq[i] = st[1];
+                }
+            }
+            gga[i] = p.gamma[c]; gbe[i] = p.beta[c];
+        }
+    }
+    prefetch(0, 0);
+    if (p.gn_C > 0) {
+        double* s_st = reinterpret_cast<double*>(s_patch);
+#pragma unroll
+        for (int i = 0; i < GNP; ++i) { const int c = tid + i * 256; if (c < p.gn_C) { s_st[2 * c] = gsum[i]; s_st[2 * c + 1] = gsq[i]; } }
+        __syncthreads();
+        const double inv_n = 1.0 / ((double)p.gn_cpg * (double)p.Hs * (double)p.Ws);
+#pragma unroll
+        for (int i = 0; i < GNP; ++i) {
+            const int c = tid + i * 256;
+            if (c < p.gn_C) {
+                const int g0 = (c / p.gn_cpg) * p.gn_cpg;
+                double sm = 0.0, ss = 0.0;
+                for (int j = g0; j < g0 + p.gn_cpg; ++j) { sm += s_st[2 * j]; ss += s_st[2 * j + 1]; }
+                const double mean = sm * inv_n;
+                double var = ss * inv_n - mean * mean;
+                var = var > 0.0 ? var : 0.0;
+                const float rstd = __builtin_amdgcn_rsqf((float)(var + (double)p.gn_eps));
+                const float sc = gga[i] * rstd;
+                s_sc[c] = sc; s_sh[c] = gbe[i] - (float)mean * sc;
+            }
+        }
+    }
+#else
     float csc[GNP], csh[GNP];
     {
         const float* cb = p.coef + (size_t)b * 2 * p.coef_stride;
@@ -161,6 +210,7 @@ __global__ __launch_bounds__(256, (((MT == 4 && WM == 2 && KC == 16) || (KC != 6
         const int c = tid + i * 256;
         if (c < p.gn_C) { s_sc[c] = csc[i]; s_sh[c] = csh[i]; }          // visible to store_lds after the chunk loop's first barrier
     }
+#endif
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -193,7 +243,12 @@ __global__ __launch_bounds__(256, (((MT == 4 && WM == 2 && KC == 16) || (KC != 6
         if (ch == 0 && si > 0) {
             // the accumulator changes units: from segment si-1's operand scale to segment si's (both powers of two: exact)
             const float ratio = (si == 1 ? seg_scale[1] * seg_inv[0] : seg_scale[2] * seg_inv[1]);
-            if (ratio != 1.0f) {
+#ifndef PF_AB_NO_RESCALE
+            if (ratio != 1.0f)
+#else
+            if (false)
+#endif
+            {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -416,7 +471,11 @@ static hipError_t launch_sel16(const ConvParams& p, hipStream_t stream) {
 // Only fragment-major packed weights (w_mode 0) with a 16-bit repack are supported; the caller keeps the
 // fp32 kernel (launch_conv) for the generic strided operands of attention.
 hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t stream) {
+#ifdef PF_AB_GN_INKERNEL
+    if (p.gn_C > 1024) return hipErrorInvalidValue;
+#else
     if (p.gn_C > 1024 || (p.gn_C > 0 && p.coef == nullptr)) return hipErrorInvalidValue;      // the kernel parks at most 4 x 256 GroupNorm channels
+#endif
     bool all_1tap = true;
     for (int i = 0; i < p.nseg; ++i) {
         if (p.seg[i].w_mode != 0 || p.seg[i].w16 == nullptr) return hipErrorInvalidValue;

@@ -384,6 +384,7 @@ static ConvParams with_coef(Builder& bd, ConvParams p, std::vector<Op>& ops) {
     }
     const bool want_scale = bd.e->precision != 0 && packed16 && (raw_stats || p.gn_C > 0);
     if (p.gn_C == 0 && !want_scale) return p;
+    if (getenv("PNPFLOW_HIP_AB_NO_COEF")) return p;      // A/B builds with -DPF_AB_GN_INKERNEL only (tools/ab_variants.sh)
     Op op{}; op.kind = OP_GN_COEF;
     GnCoefParams& g = op.gp;
     g.nseg = p.nseg;

@@ -17,6 +17,70 @@ __device__ __forceinline__ float mask_at(const DegView& d, int b, int y, int x, 
     return 1.f;
 }
 
+// float4 variants (W % 4 == 0): one thread = 4 consecutive pixels of a row; grid (x: float4 index inside the image, y: image), so
+// no per-element division survives - the row/column of the quad come from one division per thread, the byte mask is read as one
+// 32-bit word.  16 B per lane per access: the HBM-bound kernels of the iteration move 12 B (grad step), 8 B (interpolation) and
+// 12-16 B (average) per pixel at the streaming rate.
+__device__ __forceinline__ float4 mask4_at(const DegView& d, int b, int y, int x, int H, int W) {
+    if (d.kind == DEG_BOX) {
+        const int c = H / 2, lo = c - d.half, hi = c + d.half;
+        const bool row = y >= lo && y < hi;
+        return make_float4((row && x >= lo && x < hi) ? 0.f : 1.f, (row && x + 1 >= lo && x + 1 < hi) ? 0.f : 1.f,
+                           (row && x + 2 >= lo && x + 2 < hi) ? 0.f : 1.f, (row && x + 3 >= lo && x + 3 < hi) ? 0.f : 1.f);
+    }
+    if (d.kind == DEG_MASK) {
+        const uint32_t m = *reinterpret_cast<const uint32_t*>(d.mask + ((size_t)b * H + y) * W + x);
+        return make_float4((float)(m & 0xff), (float)((m >> 8) & 0xff), (float)((m >> 16) & 0xff), (float)(m >> 24));
+    }
+    return make_float4(1.f, 1.f, 1.f, 1.f);
+}
+
+__global__ __launch_bounds__(256) void mask_apply4_kernel(DegView d, const float4* __restrict__ x, float4* __restrict__ y, int n4, int H, int W4) {
+    const int b = blockIdx.y;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+        const int row = i / W4, px = (i - row * W4) * 4, py = row % H;
+        const float4 m = mask4_at(d, b, py, px, H, W4 * 4), v = x[(size_t)b * n4 + i];
+        y[(size_t)b * n4 + i] = make_float4(m.x * v.x, m.y * v.y, m.z * v.z, m.w * v.w);
+    }
+}
+
+__global__ __launch_bounds__(256) void grad_step_mask4_kernel(DegView d, const float4* __restrict__ x, const float4* __restrict__ y,
+                                                              const float* __restrict__ coef, float4* __restrict__ z, int n4, int H, int W4, int laplace) {
+    const int b = blockIdx.y;
+    const float cf = coef[b];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+        const int row = i / W4, px = (i - row * W4) * 4, py = row % H;
+        const float4 m = mask4_at(d, b, py, px, H, W4 * 4), xv = x[(size_t)b * n4 + i], yv = y[(size_t)b * n4 + i];
+        float4 r = make_float4(m.x * xv.x - yv.x, m.y * xv.y - yv.y, m.z * xv.z - yv.z, m.w * xv.w - yv.w);
+        if (laplace) r = make_float4(r.x > 0.f ? 1.f : -1.f, r.y > 0.f ? 1.f : -1.f, r.z > 0.f ? 1.f : -1.f, r.w > 0.f ? 1.f : -1.f);
+        z[(size_t)b * n4 + i] = make_float4(xv.x - cf * (m.x * r.x), xv.y - cf * (m.y * r.y), xv.z - cf * (m.z * r.z), xv.w - cf * (m.w * r.w));
+    }
+}
+
+// z = x - coef * zerofill(decimate(x) - y): a full-resolution quad holds at most 4/sf samples of the low-resolution image
+__global__ __launch_bounds__(256) void grad_step_sr4_kernel(const float4* __restrict__ x, const float* __restrict__ y, const float* __restrict__ coef,
+                                                            float4* __restrict__ z, int n4, int C, int H, int W4, int sf, int laplace) {
+    const int b = blockIdx.y;
+    const int W = W4 * 4, Hy = H / sf, Wy = W / sf;
+    const float cf = coef[b];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+        const int row = i / W4, px = (i - row * W4) * 4, py = row % H, pl = row / H;
+        const float4 xv = x[(size_t)b * n4 + i];
+        float v[4] = {xv.x, xv.y, xv.z, xv.w};
+        if (py % sf == 0) {
+            const float* yr = y + (((size_t)b * C + pl) * Hy + py / sf) * Wy;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if ((px + j) % sf == 0) {
+                    float g = v[j] - yr[(px + j) / sf];
+                    if (laplace) g = g > 0.f ? 1.f : -1.f;
+                    v[j] = v[j] - cf * g;
+                }
+        }
+        z[(size_t)b * n4 + i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 // y = M*x (H and H_adj of the mask family, identity for denoising)
 __global__ __launch_bounds__(256) void mask_apply_kernel(DegView d, const float* x, float* y, int C, int H, int W) {
     const int b = blockIdx.y;
@@ -56,39 +120,81 @@ __global__ __launch_bounds__(256) void zerofill_kernel(const float* y, float* x,
 //   dir 0: along x, dir 1: along y;  sign +1: convolution (H), -1: correlation (H_adj)
 //   mode 0: out = val;  1: out = val - aux[i];  2: out = aux[i] - coef[b]*val;  3: out = sgn(val - aux[i]) in {-1,+1}
 //   (sgn = 2*heaviside(.,0)-1, the Laplace data-fit gradient of pnp_flow.py:42-43)
-__global__ __launch_bounds__(256) void blur_pass_kernel(const float* in, float* out, const float* taps, int ntaps,
-                                                        int C, int H, int W, int dir, int sign, int mode,
-                                                        const float* aux, const float* coef) {
-    __shared__ float s_g[128];
-    if (threadIdx.x < ntaps) s_g[threadIdx.x] = taps[threadIdx.x];
+// LDS-tiled (round 1 re-read 61 taps per output from global memory with a modulo per tap): a workgroup stages the lines it
+// filters once - dir 0: BL_ROWS whole image rows, dir 1: a strip of BL_COLS columns over the full height - with the circular
+// wrap resolved at staging time (the line is stored with `r` wrapped samples on either side), so the tap loop is
+// ntaps fused multiply-adds on consecutive LDS words.  Algorithmic HBM traffic: one read + one write of the plane per pass
+// (+ aux in modes 1-3); the summation order over the taps is the one of round 1 (k ascending), results unchanged.
+constexpr int BL_MAXW = 2048 + 128;       // longest staged line (image side <= 2048, ntaps <= 127)
+
+__global__ __launch_bounds__(256) void blur_rows_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ taps,
+                                                       int ntaps, int rows, int W, int sign, int mode,
+                                                       const float* __restrict__ aux, const float* __restrict__ coef, int rows_per_image) {
+    extern __shared__ float s_line[];            // [rows_here][W + 2r] then the taps
+    const int r = ntaps / 2, LW = W + 2 * r;
+    const int rows_here = min((int)blockDim.y, rows - (int)blockIdx.x * (int)blockDim.y);
+    float* s_g = s_line + blockDim.y * LW;
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x, nthr = blockDim.x * blockDim.y;
+    for (int k = tid; k < ntaps; k += nthr) s_g[k] = taps[k];
+    const size_t row0 = (size_t)blockIdx.x * blockDim.y;
+    for (int i = tid; i < rows_here * LW; i += nthr) {
+        const int rr = i / LW, j = i % LW;
+        int xx = (j - r) % W; xx += xx < 0 ? W : 0;
+        s_line[rr * LW + j] = in[(row0 + rr) * W + xx];
+    }
     __syncthreads();
-    const int b = blockIdx.y;
-    const int n = C * H * W;
-    const int r = ntaps / 2;          // index of the tap that sits at offset 0 after the reference's roll by -(K-1)//2 (floor division)
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int px = i % W, py = (i / W) % H, pl = i / (W * H);
-        const float* src = in + ((size_t)b * C + pl) * H * W;
+    if ((int)threadIdx.y >= rows_here) return;
+    const size_t grow = row0 + threadIdx.y;
+    const int b = (int)(grow / rows_per_image);
+    const float* line = s_line + threadIdx.y * LW + r;       // line[x] = in[row][x], valid for x in [-r, W + r)
+    for (int px = threadIdx.x; px < W; px += blockDim.x) {
         float acc = 0.f;
-        if (dir == 0) {
-            const float* row = src + (size_t)py * W;
-            for (int k = 0; k < ntaps; ++k) {
-                int xx = (px - sign * (k - r)) % W;
-                xx += xx < 0 ? W : 0;
-                acc = fmaf(s_g[k], row[xx], acc);
-            }
-        } else {
-            for (int k = 0; k < ntaps; ++k) {
-                int yy = (py - sign * (k - r)) % H;
-                yy += yy < 0 ? H : 0;
-                acc = fmaf(s_g[k], src[(size_t)yy * W + px], acc);
-            }
-        }
-        const size_t o = (size_t)b * n + i;
+        // out[px] = sum_k g[k] * in[(px - sign*(k - r)) mod W]
+        if (sign > 0) { for (int k = 0; k < ntaps; ++k) acc = fmaf(s_g[k], line[px - (k - r)], acc); }
+        else          { for (int k = 0; k < ntaps; ++k) acc = fmaf(s_g[k], line[px + (k - r)], acc); }
+        const size_t o = grow * W + px;
         if (mode == 1) acc = acc - aux[o];
         else if (mode == 2) acc = aux[o] - coef[b] * acc;
         else if (mode == 3) acc = (acc - aux[o]) > 0.f ? 1.f : -1.f;
         out[o] = acc;
     }
+}
+
+constexpr int BL_COLS = 32;
+__global__ __launch_bounds__(256) void blur_cols_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ taps,
+                                                       int ntaps, int H, int W, int sign, int mode,
+                                                       const float* __restrict__ aux, const float* __restrict__ coef, int planes_per_image) {
+    extern __shared__ float s_col[];             // [H + 2r][BL_COLS] then the taps
+    const int r = ntaps / 2, LH = H + 2 * r;
+    float* s_g = s_col + LH * BL_COLS;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < ntaps; k += 256) s_g[k] = taps[k];
+    const int plane = blockIdx.y, x0 = blockIdx.x * BL_COLS;
+    const float* src = in + (size_t)plane * H * W;
+    for (int i = tid; i < LH * BL_COLS; i += 256) {
+        const int j = i / BL_COLS, cx = i % BL_COLS;
+        int yy = (j - r) % H; yy += yy < 0 ? H : 0;
+        s_col[i] = (x0 + cx < W) ? src[(size_t)yy * W + x0 + cx] : 0.f;
+    }
+    __syncthreads();
+    const int b = plane / planes_per_image;
+    const int cx = tid % BL_COLS;
+    if (x0 + cx >= W) return;
+    for (int py = tid / BL_COLS; py < H; py += 256 / BL_COLS) {
+        const float* col = s_col + (py + r) * BL_COLS + cx;       // col[d * BL_COLS] = in[py + d][x]
+        float acc = 0.f;
+        if (sign > 0) { for (int k = 0; k < ntaps; ++k) acc = fmaf(s_g[k], col[-(k - r) * BL_COLS], acc); }
+        else          { for (int k = 0; k < ntaps; ++k) acc = fmaf(s_g[k], col[(k - r) * BL_COLS], acc); }
+        const size_t o = ((size_t)plane * H + py) * W + x0 + cx;
+        if (mode == 1) acc = acc - aux[o];
+        else if (mode == 2) acc = aux[o] - coef[b] * acc;
+        else if (mode == 3) acc = (acc - aux[o]) > 0.f ? 1.f : -1.f;
+        out[o] = acc;
+    }
+}
+
+static inline bool aligned16(const void* a, const void* b, const void* c = nullptr, const void* d = nullptr) {
+    return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15) == 0;
 }
 
 static inline dim3 grid_for(int n_per_image, int B) {
@@ -99,16 +205,31 @@ static inline dim3 grid_for(int n_per_image, int B) {
 
 static hipError_t blur2(const DegView& d, const float* in, float* tmp, float* out, int B, int C, int H, int W, int sign,
                         int mode, const float* aux, const float* coef, hipStream_t s) {
-    dim3 g = grid_for(C * H * W, B);
-    hipLaunchKernelGGL(blur_pass_kernel, g, dim3(256), 0, s, in, tmp, d.taps, d.ntaps, C, H, W, 0, sign, 0, (const float*)nullptr, (const float*)nullptr);
-    hipLaunchKernelGGL(blur_pass_kernel, g, dim3(256), 0, s, (const float*)tmp, out, d.taps, d.ntaps, C, H, W, 1, sign, mode, aux, coef);
+    if (W + d.ntaps > BL_MAXW || H + d.ntaps > BL_MAXW) return hipErrorInvalidValue;
+    const int r = d.ntaps / 2;
+    // rows: 64-wide row groups, 256 threads per workgroup
+    const int tx = 64, ty = 4, rows = B * C * H;
+    const size_t lds_r = ((size_t)ty * (W + 2 * r) + 128) * sizeof(float);
+    hipLaunchKernelGGL(blur_rows_kernel, dim3((rows + ty - 1) / ty), dim3(tx, ty), lds_r, s, in, tmp, d.taps, d.ntaps, rows, W, sign, 0,
+                       (const float*)nullptr, (const float*)nullptr, C * H);
+    const size_t lds_c = ((size_t)(H + 2 * r) * BL_COLS + 128) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(blur_cols_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (lds_c > 160 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(blur_cols_kernel, dim3((W + BL_COLS - 1) / BL_COLS, B * C), dim3(256), lds_c, s, (const float*)tmp, out, d.taps, d.ntaps,
+                       H, W, sign, mode, aux, coef, C);
     return hipGetLastError();
 }
 
 hipError_t launch_deg_H(const DegView& d, const float* x, float* y, int B, int C, int H, int W, float* scratch, hipStream_t s) {
     switch (d.kind) {
         case DEG_DENOISE: case DEG_BOX: case DEG_MASK:
-            hipLaunchKernelGGL(mask_apply_kernel, grid_for(C * H * W, B), dim3(256), 0, s, d, x, y, C, H, W);
+            if (W % 4 == 0 && aligned16(x, y) && ((uintptr_t)d.mask & 3) == 0) hipLaunchKernelGGL(mask_apply4_kernel, grid_for(C * H * W / 4, B), dim3(256), 0, s, d, (const float4*)x, (float4*)y, C * H * W / 4, H, W / 4);
+            else hipLaunchKernelGGL(mask_apply_kernel, grid_for(C * H * W, B), dim3(256), 0, s, d, x, y, C, H, W);
             return hipGetLastError();
         case DEG_SR: {
             if (d.sf <= 0 || H % d.sf || W % d.sf) return hipErrorInvalidValue;
@@ -135,7 +256,8 @@ hipError_t launch_deg_H(const DegView& d, const float* x, float* y, int B, int C
 hipError_t launch_deg_Hadj(const DegView& d, const float* y, float* x, int B, int C, int H, int W, float* scratch, hipStream_t s) {
     switch (d.kind) {
         case DEG_DENOISE: case DEG_BOX: case DEG_MASK:
-            hipLaunchKernelGGL(mask_apply_kernel, grid_for(C * H * W, B), dim3(256), 0, s, d, y, x, C, H, W);
+            if (W % 4 == 0 && aligned16(x, y) && ((uintptr_t)d.mask & 3) == 0) hipLaunchKernelGGL(mask_apply4_kernel, grid_for(C * H * W / 4, B), dim3(256), 0, s, d, (const float4*)y, (float4*)x, C * H * W / 4, H, W / 4);
+            else hipLaunchKernelGGL(mask_apply_kernel, grid_for(C * H * W, B), dim3(256), 0, s, d, y, x, C, H, W);
             return hipGetLastError();
         case DEG_SR: {
             if (d.sf <= 0 || H % d.sf || W % d.sf) return hipErrorInvalidValue;
@@ -214,11 +336,17 @@ hipError_t launch_grad_step(const DegView& d, const float* x, const float* y, co
     dim3 g = grid_for(C * H * W, B);
     switch (d.kind) {
         case DEG_DENOISE: case DEG_BOX: case DEG_MASK:
-            hipLaunchKernelGGL(grad_step_mask_kernel, g, dim3(256), 0, s, d, x, y, coef, z, C, H, W, laplace);
+            if (W % 4 == 0 && aligned16(x, y, z) && (d.kind != DEG_MASK || ((uintptr_t)d.mask & 3) == 0))
+                hipLaunchKernelGGL(grad_step_mask4_kernel, grid_for(C * H * W / 4, B), dim3(256), 0, s, d, (const float4*)x, (const float4*)y, coef, (float4*)z,
+                                   C * H * W / 4, H, W / 4, laplace);
+            else hipLaunchKernelGGL(grad_step_mask_kernel, g, dim3(256), 0, s, d, x, y, coef, z, C, H, W, laplace);
             return hipGetLastError();
         case DEG_SR:
             if (d.sf <= 0 || H % d.sf || W % d.sf) return hipErrorInvalidValue;
-            hipLaunchKernelGGL(grad_step_sr_kernel, g, dim3(256), 0, s, x, y, coef, z, C, H, W, d.sf, laplace);
+            if (W % 4 == 0 && aligned16(x, z))
+                hipLaunchKernelGGL(grad_step_sr4_kernel, grid_for(C * H * W / 4, B), dim3(256), 0, s, (const float4*)x, y, coef, (float4*)z, C * H * W / 4, C, H, W / 4,
+                                   d.sf, laplace);
+            else hipLaunchKernelGGL(grad_step_sr_kernel, g, dim3(256), 0, s, x, y, coef, z, C, H, W, d.sf, laplace);
             return hipGetLastError();
         case DEG_BLUR: {
             if (!scratch || d.ntaps < 1 || d.ntaps > 127) return hipErrorInvalidValue;
@@ -336,6 +464,20 @@ __global__ __launch_bounds__(256) void interp_iter_kernel(const float* z, const 
     const int64_t slot = (int64_t)(*iter) * num_samples + sample;
     const uint64_t stream = stream_base + (uint64_t)slot;
     const float* nz = noise != nullptr ? noise + slot * total : nullptr;
+    if ((n & 3) == 0 && gridDim.y > 1) {
+        // one image per blockIdx.y, 4 consecutive elements per thread: t[b] is a scalar, loads and stores are 16 B per lane
+        const int b = blockIdx.y, n4 = n >> 2;
+        const float tb = t[b], ob = 1.0f - tb;
+        for (int q = blockIdx.x * 256 + threadIdx.x; q < n4; q += gridDim.x * 256) {
+            const int64_t i = (int64_t)b * n + (int64_t)q * 4;
+            float e[4];
+            if (nz != nullptr) { const float4 ev = *reinterpret_cast<const float4*>(nz + i); e[0] = ev.x; e[1] = ev.y; e[2] = ev.z; e[3] = ev.w; }
+            else normals_at(elem_offset + (uint64_t)i, seed, stream, e);
+            const float4 zv = *reinterpret_cast<const float4*>(z + i);
+            *reinterpret_cast<float4*>(zt + i) = make_float4(tb * zv.x + e[0] * ob, tb * zv.y + e[1] * ob, tb * zv.z + e[2] * ob, tb * zv.w + e[3] * ob);
+        }
+        return;
+    }
     const int64_t nq = (total + 3) / 4;
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
         float e[4];
@@ -357,14 +499,28 @@ __global__ __launch_bounds__(256) void interp_iter_kernel(const float* z, const 
 hipError_t launch_interp_iter(const float* z, const float* t, const float* noise, const unsigned long long* rng,
                               const int* iter, int num_samples, int sample, float* zt, int B, int n, hipStream_t s) {
     const int64_t total = (int64_t)B * n, nq = (total + 3) / 4;
-    hipLaunchKernelGGL(interp_iter_kernel, dim3((unsigned)std::min<int64_t>((nq + 255) / 256, 4096)), dim3(256), 0, s,
-                       z, t, noise, rng, iter, num_samples, sample, zt, n, total);
+    const bool vec = (n & 3) == 0 && B > 1 && B <= 65535 && aligned16(z, zt, noise);
+    const dim3 grid = vec ? grid_for(n / 4, B) : dim3((unsigned)std::min<int64_t>((nq + 255) / 256, 4096));
+    hipLaunchKernelGGL(interp_iter_kernel, grid, dim3(256), 0, s, z, t, noise, rng, iter, num_samples, sample, zt, n, total);
     return hipGetLastError();
 }
 
 // acc (=|+=) z_tilde + (1-t)*v ; last sample: acc /= num_samples  (pnp_flow.py:50-52,114-121)
 __global__ __launch_bounds__(256) void denoise_accum_kernel(float* acc, const float* zt, const float* v, const float* t,
                                                             int mode, float ns, int n, int64_t total) {
+    if ((n & 3) == 0 && gridDim.y > 1) {
+        const int b = blockIdx.y, n4 = n >> 2;
+        const float ob = 1.0f - t[b];
+        for (int q = blockIdx.x * 256 + threadIdx.x; q < n4; q += gridDim.x * 256) {
+            const int64_t i = (int64_t)b * n + (int64_t)q * 4;
+            const float4 a = *reinterpret_cast<const float4*>(zt + i), w = *reinterpret_cast<const float4*>(v + i);
+            float4 r = make_float4(a.x + ob * w.x, a.y + ob * w.y, a.z + ob * w.z, a.w + ob * w.w);
+            if (!(mode & 1)) { const float4 o = *reinterpret_cast<const float4*>(acc + i); r = make_float4(o.x + r.x, o.y + r.y, o.z + r.z, o.w + r.w); }
+            if (mode & 2) r = make_float4(r.x / ns, r.y / ns, r.z / ns, r.w / ns);
+            *reinterpret_cast<float4*>(acc + i) = r;
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const float tb = t[i / n];
         float val = zt[i] + (1.0f - tb) * v[i];
@@ -377,8 +533,9 @@ __global__ __launch_bounds__(256) void denoise_accum_kernel(float* acc, const fl
 hipError_t launch_denoise_accum(float* acc, const float* zt, const float* v, const float* t, int mode, float ns,
                                 int B, int n, hipStream_t s) {
     const int64_t total = (int64_t)B * n;
-    hipLaunchKernelGGL(denoise_accum_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s,
-                       acc, zt, v, t, mode, ns, n, total);
+    const bool vec = (n & 3) == 0 && B > 1 && B <= 65535 && aligned16(acc, zt, v);
+    const dim3 grid = vec ? grid_for(n / 4, B) : dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096));
+    hipLaunchKernelGGL(denoise_accum_kernel, grid, dim3(256), 0, s, acc, zt, v, t, mode, ns, n, total);
     return hipGetLastError();
 }
 

@@ -432,7 +432,7 @@ def test_unet_vjp_full_net_and_linearity(hip):
     g1 = m.backward(v1.cuda()); g2 = m.backward(v2.cuda()); g12 = m.backward((2.0 * v1 - 0.5 * v2).cuda())
     scale = float(g1.abs().max())
     # size-independent property: J^T is linear in vec
-    np.testing.assert_allclose(g12.cpu().numpy(), (2.0 * g1 - 0.5 * g2).cpu().numpy(), atol=2e-5 * scale)
+    np.testing.assert_allclose(g12.cpu().numpy(), (2.0 * g1 - 0.5 * g2).cpu().numpy(), atol=VJP_RTOL * scale)
     ref = O.unet_vjp(sd, cfg, x, t, v1)
     np.testing.assert_allclose(g1.cpu().numpy(), ref.numpy(), atol=VJP_RTOL * scale)
     # homogeneity far outside the f16 range: the backward normalises vec by a power of two, so

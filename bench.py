@@ -137,6 +137,195 @@ def cpu_baseline(wl, budget_s=20.0):
                        f"in {dt:.1f}s on {cores} threads, scaled linearly to {total_fw} evaluations")
 
 
+FWD_FLOPS = {128: 49.78e9, 256: 189.44e9}      # algorithmic FLOP per image per U-Net forward
+
+# HBM bytes per conv-GEMM launch measured with rocprofv3 --pmc (FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled as
+# MI355X_MICROARCH.md prescribes for gfx950): {workload: (bytes per launch, committed summary it comes from)}
+TRAFFIC = {
+    "c2": (478.7e6, "profiles/r01_pmc_hbm_traffic_forward_c2_fused.md"),
+}
+
+
+class Runner:
+    """One BASELINE workload on this rank: model, solver, resident synthetic batch, `step(i)` = one full restoration."""
+
+    def __init__(self, name, rank, world, dev, precision=1, use_graph=True, models=None):
+        import pnpflow_amd.degradations as D
+        from pnpflow_amd.methods.pnp_flow import PNP_FLOW
+        from pnpflow_amd.models import UNet
+        from pnpflow_amd.utils import CfgNode
+        from tools.synthetic_weights import synthetic_state_dict      # product-side recipe (no checkpoint is reachable offline)
+        self.name, self.wl, self.rank, self.world, self.dev = name, WORKLOADS[name], rank, world, dev
+        wl = self.wl
+        dim, B = wl["dim"], wl["B"]
+        key = (dim, wl["nres"])
+        if models is not None and key in models:
+            self.model = models[key]
+        else:
+            self.model = UNet(3, dim, 32, ch_mult=(1, 2, 4, 8), num_res_blocks=wl["nres"], attn_resolutions=(16, 8), device_index=dev.index or 0)
+            self.model.load_state_dict(synthetic_state_dict(self.model, 0))
+            if models is not None:
+                models[key] = self.model
+        self.model.set_precision(precision)
+        lo, hi, clean, meas_noise, init_noise = shard_inputs(wl, rank, world)
+        self.degradation, self.sigma = make_problem(D, wl["problem"], dim, global_batch=world * B, batch_offset=lo)
+        self.is_ode = wl.get("method") == "ot_ode"
+        self.args = CfgNode(dict(method=wl.get("method", "pnp_flow"), model="ot", problem=wl["problem"], noise_type="gaussian", num_samples=wl["ns"],
+                                 steps_pnp=wl["steps"], lr_pnp=1.0, gamma_style="alpha_1_minus_t", alpha=wl["alpha"], max_batch=1,
+                                 steps_ode=wl["steps"], start_time=wl.get("start_time", 0.1), gamma=wl.get("gamma", "constant"),
+                                 compute_time=False, compute_memory=False, save_results=False, batch=0, sigma_noise=self.sigma))
+        if self.is_ode:
+            from pnpflow_amd.methods.ot_ode import OT_ODE
+            self.solver = OT_ODE(self.model, dev, self.args)
+            self.solver.init_noise = init_noise.to(dev)
+        else:
+            self.solver = PNP_FLOW(self.model, dev, self.args)
+            self.solver.use_graph = use_graph
+            self.solver.noise_seed = 2024          # one Philox key for the job; the shard draws ITS slice of every global noise tensor:
+            self.solver.image_offset = lo          # pf_pnp_params.elem_offset = lo*C*H*W
+        # synthetic batch of this rank (global batch = world*B, rank r owns images [lo, hi)), resident in HBM
+        self.clean = clean.to(dev)
+        self.y = self.degradation.H(self.clean) + self.sigma * meas_noise.to(dev)
+        self.lr = self.sigma ** 2 * 1.0
+
+    def step(self, i, steps=None):
+        self.args.batch = i            # selects the Philox noise stream block
+        if steps is not None:          # short warm-up: same kernels / plans / graph, fewer outer iterations
+            self.args.steps_pnp = steps; self.args.steps_ode = steps
+        try:
+            if self.is_ode:
+                return self.solver.restore_batch(self.y, self.degradation, self.sigma)
+            return self.solver.restore_batch(self.y, self.degradation, self.sigma, self.lr)
+        finally:
+            self.args.steps_pnp = self.wl["steps"]; self.args.steps_ode = self.wl["steps"]
+
+    def flops_per_image(self):
+        f = FWD_FLOPS.get(self.wl["dim"])
+        if f is None:
+            return None
+        if self.is_ode:   # algorithmic: 1 forward + 1 input-gradient backward (= 2 forward-equivalents) per Euler step
+            return (self.wl["steps"] - int(self.wl["steps"] * self.wl["start_time"])) * 2 * f
+        return self.wl["steps"] * self.wl["ns"] * f
+
+    def unet_batch(self):
+        return self.wl["B"] * (self.wl["ns"] if getattr(self.solver, "batch_samples", False) else 1)
+
+
+def conv_roofline(r, precision, workload):
+    """Roofline of the dominant kernel family (split-fp16 implicit-GEMM conv on MFMA): HIP-event timing of every conv-GEMM
+    launch over a profiled slice of the SAME workload at the SAME U-Net batch (eager launches; graph replay hides the
+    per-kernel boundaries)."""
+    model = r.model
+    rep = r.unet_batch() // r.wl["B"]
+    n_fw = 2 if rep > 1 else 4
+    t_dev = torch.full((r.wl["B"] * rep,), 0.37, device=r.dev)
+    zt = (r.clean + 0.1).repeat(rep, 1, 1, 1)
+    model(zt, t_dev)                     # builds the plan outside the profiled slice
+    model.profile(True)
+    for _ in range(n_fw):
+        model(zt, t_dev)
+    launches, ms, flops = model.profile_read()
+    model.profile(False)
+    ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0      # ALGORITHMIC (fp32-equivalent) TFLOP/s of the conv-GEMM launches
+    traffic, src = TRAFFIC.get(workload, (None, None)) if (precision == 1 and rep == 5) else (None, None)
+    if precision == 0:
+        peak = 157.3   # TFLOP/s, fp32 MFMA dense peak (MI355X_MICROARCH.md)
+        roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=None,
+                    kernel="conv_mfma_kernel (fp32 32x32x2 MFMA implicit GEMM)")
+    else:
+        peak = 2500.0  # TFLOP/s, f16 MFMA dense peak; every algorithmic product is executed as 3 f16 MFMA products
+        roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=traffic,
+                    traffic_source=src,
+                    kernel="conv_mfma16_kernel (f16 32x32x16 MFMA x3 split, implicit GEMM; every 3x3/1x1 conv of the U-Net; the fused attention core is a separate launch and not in this family)",
+                    mfma_tflops_executed=round(3 * ach, 2), frac_executed=round(3 * ach / peak, 4))
+    roof.update(launches=int(launches // n_fw), avg_launch_us=round(ms * 1e3 / max(1, launches), 2),
+                algorithmic_gflop_per_launch=round(flops / max(1, launches) / 1e9, 4), unet_batch=r.wl["B"] * rep)
+    return roof
+
+
+def pointwise_block(dev, D):
+    """HBM-side evidence for the per-pixel prox / data-fidelity kernels (north_star): each kernel timed with HIP events on the
+    launch stream over `reps` back-to-back launches at the BASELINE configs' sizes; achieved = ALGORITHMIC bytes / time against
+    the 8 TB/s HBM3E peak (6.3 TB/s is what a float4 copy reaches, MI355X_MICROARCH.md).  The working sets (6-50 MB) fit the
+    256 MiB Infinity Cache, so 'achieved' is an on-die streaming rate, and at 5-15 us per launch these kernels are launch-latency-
+    sized: they sit inside the per-iteration hipGraph for that reason."""
+    import ctypes as C
+    from pnpflow_amd import _lib
+    lib = _lib.load()
+    st = _lib.current_stream_ptr
+
+    def timed(fn, reps=20):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    out = {}
+
+    def add(name, secs, nbytes, shape):
+        out[name] = dict(us=round(secs * 1e6, 2), algorithmic_mb=round(nbytes / 1e6, 2), achieved_gbs=round(nbytes / secs / 1e9, 1),
+                         frac_of_8tbs=round(nbytes / secs / 8e12, 4), frac_of_6p3tbs=round(nbytes / secs / 6.3e12, 4), shape=shape)
+
+    cases = [("c2 box mask 32x3x128^2", D.BoxInpainting(20), 32, 128, 1), ("c3 gaussian blur 64x3x128^2", D.GaussianDeblurring(1.0, 61, "fft", 3, 128), 64, 128, 1),
+             ("c4 decimation x4 16x3x256^2", D.Superresolution(4, 256), 16, 256, 4), ("c5 random mask 32x3x256^2", D.RandomInpainting(0.7), 32, 256, 1)]
+    for label, deg, B, dim, sf in cases:
+        x = torch.randn(B, 3, dim, dim, device=dev); y = torch.randn(B, 3, dim // sf, dim // sf, device=dev); z = torch.empty_like(x)
+        coef = torch.full((B,), 0.5, device=dev); scratch = torch.empty((2,) + tuple(x.shape), device=dev)
+        d = deg.descriptor(B, dim, dim, dev)
+        n = x.numel() * 4
+        blur = "blur" in label
+        # grad step: read x, read y, write z (+ 4 separable passes of read+write and the aux reads for the blur)
+        nb = n * (2 + 1.0 / (sf * sf)) if not blur else n * (2 * 4 + 2)
+        secs = timed(lambda: lib.pf_grad_step(C.byref(d), x.data_ptr(), y.data_ptr(), coef.data_ptr(), z.data_ptr(), B, 3, dim, dim, scratch.data_ptr(), st()))
+        add("grad_step " + label, secs, nb, [B, 3, dim, dim])
+    for label, B, dim in (("c2/c3 128^2", 32, 128), ("c4 256^2", 16, 256)):
+        x = torch.randn(B, 3, dim, dim, device=dev); zt = torch.empty_like(x); v = torch.randn_like(x); acc = torch.zeros_like(x)
+        t = torch.full((B,), 0.3, device=dev); n = x.numel() * 4; npi = 3 * dim * dim
+        secs = timed(lambda: lib.pf_interpolate(x.data_ptr(), t.data_ptr(), None, 2024, 5, zt.data_ptr(), B, npi, st()))
+        add(f"interpolate+philox {label} B={B}", secs, 2 * n, [B, 3, dim, dim])
+        secs = timed(lambda: lib.pf_denoise_accumulate(acc.data_ptr(), zt.data_ptr(), v.data_ptr(), t.data_ptr(), 0, 5.0, B, npi, st()))
+        add(f"denoise_accumulate {label} B={B}", secs, 4 * n, [B, 3, dim, dim])
+    return out
+
+
+def cpu_baseline_ot_ode(wl, budget_s=15.0):
+    """The oracle's OT-ODE loop (forward + autograd input-gradient per Euler step) on the usable host cores, B=1, as many of the
+    first steps as fit in ~budget_s; scaled linearly to all steps (cost is linear in steps x images)."""
+    from oracle import pnpflow_oracle as O
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    dim = wl["dim"]
+    cfg = O.unet_config(3, dim, 32, (1, 2, 4, 8), wl["nres"], (16, 8))
+    sd = O.synthetic_state_dict(cfg, 0)
+    deg, sigma = O.make_degradation(wl["problem"], dim)
+    clean = det_image((1, 3, dim, dim), 31)
+    y = O.make_measurement(clean, deg, sigma, 0)
+    total = wl["steps"] - int(wl["steps"] * wl["start_time"])
+    done = {"n": 0}
+    t0 = time.perf_counter()
+
+    class _Stop(Exception):
+        pass
+
+    def rec(it, xx):
+        done["n"] += 1
+        if time.perf_counter() - t0 > budget_s:
+            raise _Stop()
+    try:
+        O.ot_ode_restore(lambda a, t: O.unet_forward(sd, cfg, a, t), lambda a, t, v: O.unet_vjp(sd, cfg, a, t, v), deg, wl["problem"], y, sigma,
+                         steps=wl["steps"], start_time=wl["start_time"], gamma=wl.get("gamma", "constant"), record=rec)
+    except _Stop:
+        pass
+    dt = time.perf_counter() - t0
+    per_image = dt / max(1, done["n"]) * total
+    return dict(value=1.0 / per_image, unit="images/s", cores=cores, kind="port",
+                sample=f"oracle OT-ODE loop, B=1, first {done['n']} of {total} Euler steps (forward + input-gradient backward each) in {dt:.1f}s "
+                       f"on {cores} threads, scaled linearly to {total} steps")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +333,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary BASELINE configs and the pointwise block (N=1 default runs include them)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--precision", type=int, default=1, choices=[0, 1],
                     help="1 (default): fp32-equivalent split-fp16 MFMA (3 x f16 MFMA per product); 0: exact fp32 MFMA")
@@ -160,47 +350,13 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import pnpflow_amd.degradations as D
-    from pnpflow_amd.methods.pnp_flow import PNP_FLOW
-    from pnpflow_amd.models import UNet
-    from pnpflow_amd.parallel import shard_range
-    from pnpflow_amd.utils import CfgNode, psnr_per_image
+    from pnpflow_amd.utils import psnr_per_image
 
+    models = {}
+    r = Runner(a.workload, rank, world, dev, a.precision, not a.no_graph, models)
     dim, B = wl["dim"], wl["B"]
-    from tools.synthetic_weights import synthetic_state_dict      # product-side recipe (no checkpoint is reachable offline)
-    model = UNet(3, dim, 32, ch_mult=(1, 2, 4, 8), num_res_blocks=wl["nres"], attn_resolutions=(16, 8), device_index=local)
-    model.load_state_dict(synthetic_state_dict(model, 0))
-    model.set_precision(a.precision)
-    lo, hi, clean, meas_noise, init_noise = shard_inputs(wl, rank, world)
-    degradation, sigma = make_problem(D, wl["problem"], dim, global_batch=world * B, batch_offset=lo)
-    is_ode = wl.get("method") == "ot_ode"
-
-    args = CfgNode(dict(method=wl.get("method", "pnp_flow"), model="ot", problem=wl["problem"], noise_type="gaussian", num_samples=wl["ns"],
-                        steps_pnp=wl["steps"], lr_pnp=1.0, gamma_style="alpha_1_minus_t", alpha=wl["alpha"], max_batch=1,
-                        steps_ode=wl["steps"], start_time=wl.get("start_time", 0.1), gamma=wl.get("gamma", "constant"),
-                        compute_time=False, compute_memory=False, save_results=False, batch=0, sigma_noise=sigma))
-    if is_ode:
-        from pnpflow_amd.methods.ot_ode import OT_ODE
-        solver = OT_ODE(model, dev, args)
-        solver.init_noise = init_noise.to(dev)
-    else:
-        solver = PNP_FLOW(model, dev, args)
-        solver.use_graph = not a.no_graph
-        solver.noise_seed = 2024          # one Philox key for the job; the shard draws ITS slice of every global noise tensor:
-        solver.image_offset = lo          # pf_pnp_params.elem_offset = lo*C*H*W
-
-    # synthetic batch of this rank (global batch = world*B, rank r owns images [lo, hi)), resident in HBM
-    clean = clean.to(dev)
-    y = degradation.H(clean) + sigma * meas_noise.to(dev)
-    lr = sigma ** 2 * 1.0
-
-    def step(i):
-        args.batch = i            # selects the Philox noise stream block
-        if is_ode:
-            return solver.restore_batch(y, degradation, sigma)
-        return solver.restore_batch(y, degradation, sigma, lr)
-
     for i in range(a.warmup):
-        step(i)
+        r.step(i)
 
     def sync():
         torch.cuda.synchronize()
@@ -212,7 +368,7 @@ def main():
     t0 = time.perf_counter()
     x = None
     for i in range(a.steps):
-        x = step(a.warmup + i)
+        x = r.step(a.warmup + i)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -221,47 +377,15 @@ def main():
         dt = float(tt.item())
 
     # the ONE data-path collective: per-image PSNR gathered in global image order
-    psnr = psnr_per_image(x, clean)
+    psnr = psnr_per_image(x, r.clean)
     if world > 1:
         allp = [torch.empty_like(psnr) for _ in range(world)]
         dist.all_gather(allp, psnr)
         psnr = torch.cat(allp)
     psnr_mean = float(psnr.mean())
 
-    # roofline of the dominant kernel family (fp32 implicit-GEMM conv on MFMA): HIP-event timing of every
-    # conv-GEMM launch over a profiled slice of the SAME workload (eager launches; graph replay hides the
-    # per-kernel boundaries), rank 0 only
-    roof = None
-    if rank == 0:
-        # same U-Net batch as the timed region: num_samples*B images per pass when the samples are batched
-        rep = wl["ns"] if getattr(solver, "batch_samples", False) else 1
-        n_fw = 2 if rep > 1 else 4
-        t_dev = torch.full((B * rep,), 0.37, device=dev)
-        zt = (clean + 0.1).repeat(rep, 1, 1, 1)
-        model(zt, t_dev)                     # builds the plan outside the profiled slice
-        model.profile(True)
-        for _ in range(n_fw):
-            model(zt, t_dev)
-        launches, ms, flops = model.profile_read()
-        model.profile(False)
-        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0      # ALGORITHMIC (fp32-equivalent) TFLOP/s of the conv-GEMM launches
-        if a.precision == 0:
-            peak = 157.3   # TFLOP/s, fp32 MFMA dense peak (MI355X_MICROARCH.md)
-            roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-                        traffic=503.7e6 if (a.workload == "c2" and rep == 5) else None,
-                        kernel="conv_mfma_kernel (fp32 32x32x2 MFMA implicit GEMM)")
-        else:
-            peak = 2500.0  # TFLOP/s, f16 MFMA dense peak; every algorithmic product is executed as 3 f16 MFMA products
-            roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
-                        traffic=TRAFFIC_C2_F16X3 if (a.workload == "c2" and rep == 5) else None,
-                        kernel="conv_mfma16_kernel (f16 32x32x16 MFMA x3 split, implicit GEMM; every 3x3/1x1 conv of the U-Net; the fused attention core is a separate launch and not in this family)",
-                        mfma_tflops_executed=round(3 * ach, 2), frac_executed=round(3 * ach / peak, 4))
-        roof.update(launches=int(launches // n_fw), avg_launch_us=round(ms * 1e3 / max(1, launches), 2),
-                    algorithmic_gflop_per_launch=round(flops / max(1, launches) / 1e9, 4))
-
     if rank == 0:
         total_images = world * B * a.steps
-        fwd_flops = {128: 49.78e9, 256: 189.44e9}.get(dim)
         out = {
             "metric": "restored images/sec", "value": round(total_images / dt, 4), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
@@ -270,19 +394,41 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["label"], "image": f"{dim}x{dim}x3", "batch_per_gpu": B, "global_batch": world * B,
                        "steps_pnp": wl["steps"], "num_samples": wl["ns"], "weights": "synthetic seed 0 (no checkpoint offline)",
-                       "noise": "on-device Philox4x32-10", "hipgraph": bool(getattr(solver, "use_graph", False)),
-                       "unet_batch": B * (wl["ns"] if getattr(solver, "batch_samples", False) else 1),
-                       "parallelism": f"dp{world} (independent batches)"},
+                       "noise": "on-device Philox4x32-10 (one global stream per (iteration, sample), sliced per shard)",
+                       "hipgraph": bool(getattr(r.solver, "use_graph", False)), "unet_batch": r.unet_batch(),
+                       "parallelism": f"dp{world} (contiguous shards of the global batch, no data-path collective)"},
             "psnr_db": round(psnr_mean, 4),
-            "roofline": roof,
+            "roofline": conv_roofline(r, a.precision, a.workload),
         }
-        if fwd_flops and not is_ode:
-            out["unet_tflops_end_to_end"] = round(total_images * wl["steps"] * wl["ns"] * fwd_flops / dt / 1e12, 2)
-        if fwd_flops and is_ode:   # algorithmic: 1 forward + 1 input-gradient backward (= 2 forward-equivalents) per Euler step
-            n_it = wl["steps"] - int(wl["steps"] * wl["start_time"])
-            out["unet_tflops_end_to_end"] = round(total_images * n_it * 2 * fwd_flops / dt / 1e12, 2)
-        if not a.no_cpu_baseline and world == 1 and not is_ode:
-            out["cpu_baseline"] = cpu_baseline(wl)
+        fpi = r.flops_per_image()
+        if fpi:
+            out["unet_tflops_end_to_end"] = round(total_images * fpi / dt / 1e12, 2)
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline_ot_ode(wl) if r.is_ode else cpu_baseline(wl)
+        if world == 1 and not a.no_extra and a.workload == "c2":
+            # the other BASELINE configs under the same clock (one full restoration each after a short warm-up that builds the
+            # plans / graph), and the HBM-side numbers of the pointwise prox kernels
+            extra = {}
+            for name in ("c3", "c4", "c5"):
+                rr = Runner(name, 0, 1, dev, a.precision, not a.no_graph, models)
+                rr.step(0, steps=12 if rr.is_ode else 2)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                xx = rr.step(1)
+                torch.cuda.synchronize()
+                d1 = time.perf_counter() - t1
+                w2 = rr.wl
+                rec = {"workload": w2["label"], "images_per_s": round(w2["B"] / d1, 4), "ms_per_step": round(d1 * 1e3, 1), "steps": 1,
+                       "unet_batch": rr.unet_batch(), "psnr_db": round(float(psnr_per_image(xx, rr.clean).mean()), 4),
+                       "unet_tflops_end_to_end": round(w2["B"] * rr.flops_per_image() / d1 / 1e12, 2)}
+                if not rr.is_ode:
+                    rec["roofline"] = conv_roofline(rr, a.precision, name)
+                elif not a.no_cpu_baseline:
+                    rec["cpu_baseline"] = cpu_baseline_ot_ode(w2, budget_s=12.0)
+                extra[name] = rec
+                del rr
+            out["configs"] = extra
+            out["pointwise"] = pointwise_block(dev, D)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -157,6 +157,19 @@ int pf_psnr(const float* rec, const float* clean, float* out, int B, int n_per_i
  * fp64 -> out[B] (device, double).  H, W > 5.  PARITY UNPINNED: ignite is absent from the build container. */
 int pf_ssim(const float* rec, const float* clean, double* out, int B, int C, int H, int W, void* stream);
 
+/* ---- the reference's native ops (NCSN++ "rectified" velocity net) ------------------------------------------- */
+/* upfirdn2d (pnpflow/image_generation/op/upfirdn2d_kernel.cu:49-369; definition: op/upfirdn2d.py:142-187): per plane of
+ * in[planes][in_h][in_w]: zero-insert upsample by (up_x, up_y), pad (negative = crop) by (pad_x0, pad_x1, pad_y0, pad_y1), true 2-D
+ * convolution with kernel[kh][kw] (device), decimate by (down_x, down_y) -> out[planes][out_h][out_w],
+ * out_h = (in_h*up_y + pad_y0 + pad_y1 - kh) / down_y + 1 (same for w). */
+int pf_upfirdn2d(const float* in, const float* kernel, float* out, int planes, int in_h, int in_w, int kh, int kw, int up_x, int up_y,
+                 int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+/* fused_bias_act (op/fused_bias_act_kernel.cu:19-99): out[i] = act(x[i] + bias[(i / step_b) % size_b]) * scale;
+ * act 1 = linear, 3 = leaky ReLU(alpha); grad 0 = value, 1 = first derivative (sign taken from ref[i], the saved output),
+ * 2 = zero; bias / ref may be NULL. */
+int pf_fused_bias_act(const float* x, const float* bias, const float* ref, float* out, int64_t n, int step_b, int size_b, int act, int grad,
+                      float alpha, float scale, void* stream);
+
 /* ---- attention core -------------------------------------------------------------------- */
 /* out[B,T,C] = softmax(q k^T * C^-1/2, dim=-1) v for q|k|v stacked as qkv[B,T,3C] (fp32, token-major): the bmm /
  * softmax / bmm of SelfAttention.forward (pnpflow/models.py:152-158) in one launch, split-f16 MFMA (fp32-equivalent).
@@ -183,6 +196,29 @@ int pf_ot_ode_vec(const pf_degradation* d, const float* x, const float* vt, cons
                   const float* rt2, float sigma2, float* vec, int B, int C, int H, int W, float* scratch, void* stream);
 int pf_ot_ode_update(float* x, const float* vt, const float* vec, const float* g, const float* one_minus_t,
                      const float* coef, float delta, int B, int n_per_image, void* stream);
+
+/* Whole OT-ODE loop of one batch on the device (pnpflow/methods/ot_ode.py:63-147): iterations first..steps-1 of
+ *   v_t = v_theta(x, t);  vec = H_adj((r_t^2 H H^T + sigma^2)^-1 (y - H(x + (1-t) v_t)));  g = J^T vec;
+ *   x += delta * (v_t + coef * (vec + (1-t) g))
+ * with the per-iteration scalars (host tables, fp32 values computed with the reference's own expressions - including its
+ * `delta * iteration**2` quirk for superresolution, ot_ode.py:96) read on the device through an iteration counter, the buffers
+ * pre-allocated, and one hipGraph per Euler step (retained forward -> solve -> hand-written backward -> update) captured once
+ * and replayed.  x_inout: the initialisation t0*H_adj(y) + (1-t0)*noise on entry (ot_ode.py:27-28, 50-52), the result on exit. */
+typedef struct pf_ot_ode_params {
+    int32_t steps;                  /* steps_ode */
+    int32_t first;                  /* int(steps_ode * start_time) */
+    const float* host_t;            /* host [steps] */
+    const float* host_one_minus_t;  /* host [steps] */
+    const float* host_rt2;          /* host [steps] */
+    const float* host_coef;         /* host [steps]: ((1-t)/t) * gamma_t */
+    float sigma2;                   /* sigma_noise^2 */
+    float delta;                    /* 1 / steps_ode */
+    int32_t use_graph;
+    int32_t reserved0;
+    const uint8_t* host_cb_mask;    /* optional host [steps]: iterations after which iter_cb is called; NULL = every iteration */
+} pf_ot_ode_params;
+int pf_ot_ode_restore(pf_engine* e, const pf_degradation* d, const pf_ot_ode_params* prm, const float* y, float* x_inout, int B,
+                      void* stream, void (*iter_cb)(int iteration, void* user), void* user);
 
 /* ---- whole restoration loop --------------------------------------------------------- */
 typedef struct pf_pnp_params {

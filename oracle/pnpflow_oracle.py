@@ -612,3 +612,72 @@ def ot_ode_restore(model: Callable, vjp: Callable, degradation: Degradation, pro
         if record is not None:
             record(iteration, x)
     return x
+
+
+# --------------------------------------------------------------------------------------
+# the reference's native ops (NCSN++ "rectified" net)         pnpflow/image_generation/op/
+# --------------------------------------------------------------------------------------
+
+def upfirdn2d(inp: torch.Tensor, kernel: torch.Tensor, up_x: int = 1, up_y: int = 1, down_x: int = 1, down_y: int = 1,
+              pad_x0: int = 0, pad_x1: int = 0, pad_y0: int = 0, pad_y1: int = 0) -> torch.Tensor:
+    """op/upfirdn2d.py:142-187 (`upfirdn2d_native`, the pure-torch definition of the CUDA kernel): zero-insert upsampling,
+    padding (negative = crop), correlation with the FLIPPED kernel (= true convolution), decimation; (N,C,H,W) -> (N,C,Ho,Wo)."""
+    N, C, in_h, in_w = inp.shape
+    kh, kw = kernel.shape
+    x = inp.reshape(N * C, in_h, 1, in_w, 1)
+    x = torch.nn.functional.pad(x, [0, up_x - 1, 0, 0, 0, up_y - 1])                   # zero insertion            (:152-154)
+    x = x.reshape(N * C, in_h * up_y, in_w * up_x)
+    x = torch.nn.functional.pad(x, [max(pad_x0, 0), max(pad_x1, 0), max(pad_y0, 0), max(pad_y1, 0)])     # (:156-158)
+    x = x[:, max(-pad_y0, 0): x.shape[1] - max(-pad_y1, 0), max(-pad_x0, 0): x.shape[2] - max(-pad_x1, 0)]   # (:159-164)
+    w = torch.flip(kernel, [0, 1]).view(1, 1, kh, kw)                                   # (:170)
+    out = torch.nn.functional.conv2d(x.unsqueeze(1), w)[:, 0]                           # (:171)
+    out = out[:, ::down_y, ::down_x]                                                    # (:179)
+    out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) // down_y + 1
+    out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) // down_x + 1
+    return out.reshape(N, C, out_h, out_w)
+
+
+def fir_kernel_2d(k, gain: float = 1.0) -> torch.Tensor:
+    """models/up_or_down_sampling.py:191-198 `_setup_kernel`: outer product of a separable filter, normalised to sum 1."""
+    k = np.asarray(k, dtype=np.float32)
+    if k.ndim == 1:
+        k = np.outer(k, k)
+    k = k / np.sum(k)
+    return torch.from_numpy(k * gain)
+
+
+def upsample_2d(x: torch.Tensor, k=None, factor: int = 2, gain: float = 1.0) -> torch.Tensor:
+    """models/up_or_down_sampling.py:205-230"""
+    k = [1] * factor if k is None else k
+    kk = fir_kernel_2d(k, gain * factor ** 2)
+    p = kk.shape[0] - factor
+    return upfirdn2d(x, kk, up_x=factor, up_y=factor, pad_x0=(p + 1) // 2 + factor - 1, pad_x1=p // 2, pad_y0=(p + 1) // 2 + factor - 1, pad_y1=p // 2)
+
+
+def downsample_2d(x: torch.Tensor, k=None, factor: int = 2, gain: float = 1.0) -> torch.Tensor:
+    """models/up_or_down_sampling.py:233-259"""
+    k = [1] * factor if k is None else k
+    kk = fir_kernel_2d(k, gain)
+    p = kk.shape[0] - factor
+    return upfirdn2d(x, kk, down_x=factor, down_y=factor, pad_x0=(p + 1) // 2, pad_x1=p // 2, pad_y0=(p + 1) // 2, pad_y1=p // 2)
+
+
+def fused_bias_act(x: torch.Tensor, bias: Optional[torch.Tensor], ref: Optional[torch.Tensor], act: int, grad: int, alpha: float,
+                   scale: float) -> torch.Tensor:
+    """op/fused_bias_act_kernel.cu:19-49: y = act(x + b[channel]) * scale (channel = dim 1); act 1 linear, 3 leaky ReLU;
+    grad 1 takes the sign from `ref`, grad 2 is identically zero."""
+    if bias is not None:
+        x = x + bias.view(1, -1, *([1] * (x.ndim - 2)))
+    if grad == 2:
+        y = torch.zeros_like(x)
+    elif act == 3:
+        sel = x if grad == 0 else ref
+        y = torch.where(sel > 0, x, x * alpha)
+    else:
+        y = x
+    return y * scale
+
+
+def fused_leaky_relu(x: torch.Tensor, bias: torch.Tensor, negative_slope: float = 0.2, scale: float = 2 ** 0.5) -> torch.Tensor:
+    """op/fused_act.py:84-96 (the GPU branch: the reference's CPU branch hard-codes the slope 0.2)."""
+    return fused_bias_act(x, bias, None, 3, 0, negative_slope, scale)

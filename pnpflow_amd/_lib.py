@@ -36,6 +36,12 @@ class PfPnpParams(C.Structure):
                 ("reserved0", C.c_int32), ("elem_offset", C.c_uint64), ("host_cb_mask", C.c_void_p)]
 
 
+class PfOtOdeParams(C.Structure):
+    _fields_ = [("steps", C.c_int32), ("first", C.c_int32), ("host_t", C.POINTER(C.c_float)), ("host_one_minus_t", C.POINTER(C.c_float)),
+                ("host_rt2", C.POINTER(C.c_float)), ("host_coef", C.POINTER(C.c_float)), ("sigma2", C.c_float), ("delta", C.c_float),
+                ("use_graph", C.c_int32), ("reserved0", C.c_int32), ("host_cb_mask", C.c_void_p)]
+
+
 ITER_CB = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
 
 # name -> (restype, argtypes); this table is also what tests use to check that every symbol
@@ -70,7 +76,10 @@ SIGNATURES = {
     "pf_fill_normal_at": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]),
     "pf_attention_core": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pf_psnr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "pf_upfirdn2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 13 + [C.c_void_p]),
+    "pf_fused_bias_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "pf_ssim": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pf_ot_ode_restore": (C.c_int, [C.c_void_p, C.POINTER(PfDegradation), C.POINTER(PfOtOdeParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, ITER_CB, C.c_void_p]),
     "pf_pnp_flow_restore": (C.c_int, [C.c_void_p, C.POINTER(PfDegradation), C.POINTER(PfPnpParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, ITER_CB, C.c_void_p]),
     "pf_engine_memory_bytes": (C.c_int64, [C.c_void_p]),
     "pf_engine_check_numerics": (C.c_int, [C.c_void_p, C.c_void_p]),

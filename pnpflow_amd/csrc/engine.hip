@@ -128,6 +128,12 @@ struct pf_engine {
     GraphKey gkey{}; hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
     int precision = 1;   // 1 (default): split-fp16 (3 x f16 MFMA, fp32-equivalent) for the packed-weight convs; 0: exact fp32 MFMA
     SolverBufs sb;
+    // OT-ODE loop (pf_ot_ode_restore): iterate, velocity, solve output, J^T vec, per-iteration schedule tables, cached graph
+    struct OdeBufs { int B = 0; size_t n = 0, ny = 0; int steps = 0; bool blur = false;
+                     float *x = nullptr, *vt = nullptr, *vec = nullptr, *g = nullptr, *y = nullptr, *scratch = nullptr;
+                     float *tab = nullptr /* [4][steps]: t, 1-t, r_t^2, coef */, *cur = nullptr /* [4][B] */; int* iter = nullptr; int64_t bytes = 0; } ob;
+    struct OdeKey { const void* plan; int kind, half, sf, ntaps; const void* mask; const void* taps; int B; float sigma2, delta; };
+    OdeKey okey{}; hipGraph_t ograph = nullptr; hipGraphExec_t ogexec = nullptr;
     hipStream_t work_stream = nullptr;   // used when the caller passes the NULL stream and asks for graph replay
     // profiling
     bool profile = false;
@@ -578,7 +584,7 @@ static int build_plan(pf_engine* e, int B, bool retain, Plan** out_plan) {
     while (e->plans.size() >= 8) {
         auto victim = e->plans.end();
         for (auto jt = e->plans.begin(); jt != e->plans.end(); ++jt) {
-            if (jt->second.get() == e->retained_plan || jt->second.get() == e->gkey.plan) continue;
+            if (jt->second.get() == e->retained_plan || jt->second.get() == e->gkey.plan || jt->second.get() == e->okey.plan) continue;
             if (victim == e->plans.end() || jt->second->last_used < victim->second->last_used) victim = jt;
         }
         if (victim == e->plans.end()) break;
@@ -1109,6 +1115,8 @@ static int check_flags(pf_engine* e) {
     return PF_OK;
 }
 
+static void free_ode(pf_engine* e);
+
 static void drop_graph(pf_engine* e) {
     if (e->gexec) hipGraphExecDestroy(e->gexec);
     if (e->graph) hipGraphDestroy(e->graph);
@@ -1129,6 +1137,7 @@ void pf_engine_destroy(pf_engine* e) {
     if (!e) return;
     hipSetDevice(e->device);
     drop_graph(e);
+    free_ode(e);
     for (auto& kv : e->plans) for (void* p : kv.second->allocs) hipFree(p);
     for (void* p : e->weight_allocs) hipFree(p);
     for (auto& ev : e->ev_pool) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
@@ -1332,6 +1341,19 @@ int pf_psnr(const float* rec, const float* clean, float* out, int B, int n_per_i
     return PF_OK;
 }
 
+int pf_upfirdn2d(const float* in, const float* kernel, float* out, int planes, int in_h, int in_w, int kh, int kw, int up_x, int up_y,
+                 int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream) {
+    if (!in || !kernel || !out) return PF_ERR_INVALID;
+    LAUNCHCHK(launch_upfirdn2d(in, kernel, out, planes, in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, (hipStream_t)stream));
+    return PF_OK;
+}
+int pf_fused_bias_act(const float* x, const float* bias, const float* ref, float* out, int64_t n, int step_b, int size_b, int act, int grad,
+                      float alpha, float scale, void* stream) {
+    if (!x || !out) return PF_ERR_INVALID;
+    LAUNCHCHK(launch_fused_bias_act(x, bias, ref, out, n, step_b, size_b, act, grad, alpha, scale, (hipStream_t)stream));
+    return PF_OK;
+}
+
 int pf_ssim(const float* rec, const float* clean, double* out, int B, int C, int H, int W, void* stream) {
     if (!rec || !clean || !out) return PF_ERR_INVALID;
     LAUNCHCHK(launch_ssim(rec, clean, out, B, C, H, W, (hipStream_t)stream));
@@ -1476,6 +1498,136 @@ int pf_engine_check_numerics(pf_engine* e, void* stream) {
     if (!e) return PF_ERR_INVALID;
     USE_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
+    return check_flags(e);
+}
+
+
+// ---- OT-ODE restoration loop on the device (pnpflow/methods/ot_ode.py:49-52, 63-147) ---------------------------------------
+__global__ void ode_prep_kernel(const int* iter, const float* tab, int steps, float* cur, int B) {
+    const int it = *iter;
+    for (int i = threadIdx.x; i < 4 * B; i += blockDim.x) cur[i] = tab[(i / B) * steps + it];
+}
+
+static void drop_ode_graph(pf_engine* e) {
+    if (e->ogexec) hipGraphExecDestroy(e->ogexec);
+    if (e->ograph) hipGraphDestroy(e->ograph);
+    e->ogexec = nullptr; e->ograph = nullptr; e->okey = pf_engine::OdeKey{};
+}
+
+static void free_ode(pf_engine* e) {
+    drop_ode_graph(e);
+    auto& b = e->ob;
+    for (void* p : {(void*)b.x, (void*)b.vt, (void*)b.vec, (void*)b.g, (void*)b.y, (void*)b.scratch, (void*)b.tab, (void*)b.cur, (void*)b.iter})
+        if (p) hipFree(p);
+    e->bytes -= b.bytes;
+    b = pf_engine::OdeBufs{};
+}
+
+static int ensure_ode(pf_engine* e, int B, size_t n, size_t ny, int steps, bool blur, int H) {
+    auto& b = e->ob;
+    if (b.B == B && b.n == n && b.ny == ny && b.steps >= steps && b.blur == blur) return PF_OK;
+    free_ode(e);
+    const size_t tot = (size_t)B * n;
+    HIPCHK(e, hipMalloc(&b.x, tot * 4)); HIPCHK(e, hipMalloc(&b.vt, tot * 4)); HIPCHK(e, hipMalloc(&b.vec, tot * 4)); HIPCHK(e, hipMalloc(&b.g, tot * 4));
+    HIPCHK(e, hipMalloc(&b.y, (size_t)B * ny * 4));
+    const size_t scr = blur ? 4 * tot + 2 * (size_t)H : 0;
+    if (scr) HIPCHK(e, hipMalloc(&b.scratch, scr * 4));
+    HIPCHK(e, hipMalloc(&b.tab, (size_t)4 * steps * 4)); HIPCHK(e, hipMalloc(&b.cur, (size_t)4 * B * 4)); HIPCHK(e, hipMalloc(&b.iter, 64));
+    b.B = B; b.n = n; b.ny = ny; b.steps = steps; b.blur = blur;
+    b.bytes = (int64_t)(4 * tot * 4 + (size_t)B * ny * 4 + scr * 4 + (size_t)4 * steps * 4 + (size_t)4 * B * 4 + 64);
+    e->bytes += b.bytes;
+    return PF_OK;
+}
+
+// one Euler step (ot_ode.py:67-147): every per-iteration scalar is read on the device from the schedule tables through the
+// iteration counter, so one captured graph serves every iteration
+static int enqueue_ode_step(pf_engine* e, Plan* plan, const DegView& dv, const pf_ot_ode_params* prm, int B, int C, int H, hipStream_t s) {
+    auto& b = e->ob;
+    const int n = C * H * H;
+    hipLaunchKernelGGL(ode_prep_kernel, dim3(1), dim3(256), 0, s, (const int*)b.iter, (const float*)b.tab, b.steps, b.cur, B);
+    const float* t_cur = b.cur; const float* omt = b.cur + B; const float* rt2 = b.cur + 2 * B; const float* coef = b.cur + 3 * B;
+    int rc = run_plan(e, plan, b.x, t_cur, b.vt, s);                                        // v_t = v_theta(x, t), activations retained
+    if (rc != PF_OK) return rc;
+    hipError_t r = dv.kind == DEG_BLUR
+        ? launch_ot_ode_vec_blur(dv, b.x, b.vt, b.y, omt, rt2, prm->sigma2, b.vec, B, C, H, H, b.scratch, s)
+        : launch_ot_ode_vec(dv, b.x, b.vt, b.y, omt, rt2, prm->sigma2, b.vec, B, C, H, H, s);
+    if (r != hipSuccess) { e->err = std::string("ot_ode vec: ") + hipGetErrorString(r); return PF_ERR_HIP; }
+    if ((rc = run_backward(e, plan, b.vec, b.g, s)) != PF_OK) return rc;                     // g = J^T vec
+    r = launch_ot_ode_update(b.x, b.vt, b.vec, b.g, omt, coef, prm->delta, B, n, s);
+    if (r != hipSuccess) { e->err = std::string("ot_ode update: ") + hipGetErrorString(r); return PF_ERR_HIP; }
+    hipLaunchKernelGGL(bump_iter_kernel, dim3(1), dim3(64), 0, s, b.iter);
+    r = hipGetLastError();
+    if (r != hipSuccess) { e->err = std::string("ot_ode step: ") + hipGetErrorString(r); return PF_ERR_HIP; }
+    return PF_OK;
+}
+
+int pf_ot_ode_restore(pf_engine* e, const pf_degradation* d, const pf_ot_ode_params* prm, const float* y, float* x_inout, int B,
+                      void* stream, pf_iter_callback iter_cb, void* user) {
+    if (!e || !d || !prm || !y || !x_inout || B <= 0 || prm->steps <= 0 || prm->first < 0 || prm->first > prm->steps || !prm->host_t ||
+        !prm->host_one_minus_t || !prm->host_rt2 || !prm->host_coef)
+        return PF_ERR_INVALID;
+    if (!e->finalized) { e->err = "weights not finalized"; return PF_ERR_STATE; }
+    USE_DEVICE(e);
+    hipStream_t s = (hipStream_t)stream;
+    if (prm->use_graph && s == nullptr) {
+        if (!e->work_stream) HIPCHK(e, hipStreamCreateWithFlags(&e->work_stream, hipStreamNonBlocking));
+        HIPCHK(e, hipStreamSynchronize(nullptr));
+        s = e->work_stream;
+    }
+    const int C = e->cfg.input_channels, H = e->cfg.input_height;
+    if (e->cfg.output_channels != C) { e->err = "restoration needs output_channels == input_channels"; return PF_ERR_INVALID; }
+    if (d->kind == PF_DEG_SR_FILTERED) { e->err = "ot_ode: no closed-form solve for the filtered superresolution operator"; return PF_ERR_INVALID; }
+    const size_t n = (size_t)C * H * H;
+    const int Hy = d->kind == PF_DEG_SUPERRESOLUTION ? H / std::max(1, d->sf) : H;
+    const size_t ny = (size_t)C * Hy * Hy;
+    int rc = ensure_ode(e, B, n, ny, prm->steps, d->kind == PF_DEG_GAUSSIAN_BLUR, H);
+    if (rc != PF_OK) return rc;
+    auto& b = e->ob;
+    Plan* plan = nullptr;
+    if ((rc = build_plan(e, B, true, &plan)) != PF_OK) return rc;
+    e->retained_B = B; e->retained_plan = plan;
+    const DegView dv = to_view(d);
+    std::vector<float> tab((size_t)4 * b.steps, 0.f);
+    for (int i = 0; i < prm->steps; ++i) {
+        tab[i] = prm->host_t[i]; tab[(size_t)b.steps + i] = prm->host_one_minus_t[i];
+        tab[(size_t)2 * b.steps + i] = prm->host_rt2[i]; tab[(size_t)3 * b.steps + i] = prm->host_coef[i];
+    }
+    const int first = prm->first;
+    HIPCHK(e, hipMemcpyAsync(b.tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(b.iter, &first, sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(b.y, y, (size_t)B * ny * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(b.x, x_inout, (size_t)B * n * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(e, hipStreamSynchronize(s));      // the host tables may go away after return
+
+    const pf_engine::OdeKey key{plan, dv.kind, dv.half, dv.sf, dv.ntaps, dv.mask, dv.taps, B, prm->sigma2, prm->delta};
+    if (e->ogexec && memcmp(&key, &e->okey, sizeof key) != 0) drop_ode_graph(e);
+    const bool can_graph = prm->use_graph && !e->profile;
+    for (int it = first; it < prm->steps; ++it) {
+        if (can_graph && (it > first || e->ogexec)) {
+            if (!e->ogexec) {
+                HIPCHK(e, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                rc = enqueue_ode_step(e, plan, dv, prm, B, C, H, s);
+                hipGraph_t g = nullptr;
+                hipError_t ce = hipStreamEndCapture(s, &g);
+                if (rc != PF_OK) { if (g) hipGraphDestroy(g); return rc; }
+                if (ce != hipSuccess) { e->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(ce); return PF_ERR_HIP; }
+                e->ograph = g;
+                hipError_t ie = hipGraphInstantiate(&e->ogexec, e->ograph, nullptr, nullptr, 0);
+                if (ie != hipSuccess) { drop_ode_graph(e); e->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(ie); return PF_ERR_HIP; }
+                memset(&e->okey, 0, sizeof e->okey); e->okey = key;
+            }
+            HIPCHK(e, hipGraphLaunch(e->ogexec, s));
+        } else {
+            if ((rc = enqueue_ode_step(e, plan, dv, prm, B, C, H, s)) != PF_OK) return rc;
+        }
+        if (iter_cb && (!prm->host_cb_mask || prm->host_cb_mask[it])) {
+            HIPCHK(e, hipMemcpyAsync(x_inout, b.x, (size_t)B * n * 4, hipMemcpyDeviceToDevice, s));
+            HIPCHK(e, hipStreamSynchronize(s));
+            iter_cb(it, user);
+        }
+    }
+    HIPCHK(e, hipMemcpyAsync(x_inout, b.x, (size_t)B * n * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(e, hipStreamSynchronize(s));
     return check_flags(e);
 }
 

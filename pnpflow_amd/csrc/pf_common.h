@@ -141,6 +141,11 @@ hipError_t launch_denoise_accum(float* acc, const float* zt, const float* v, con
 hipError_t launch_fill_normal(float* out, int64_t n, uint64_t seed, uint64_t stream_id, uint64_t elem_offset, hipStream_t s);
 hipError_t launch_psnr(const float* rec, const float* clean, float* out, int B, int n, hipStream_t s);
 hipError_t launch_fill(float* out, int64_t n, float v, hipStream_t s);
+// FIR resampling / fused bias+activation of the NCSN++ velocity net (fir_ops.hip)
+hipError_t launch_upfirdn2d(const float* in, const float* kernel, float* out, int planes, int in_h, int in_w, int kh, int kw,
+                            int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, hipStream_t s);
+hipError_t launch_fused_bias_act(const float* x, const float* bias, const float* ref, float* out, int64_t n, int step_b, int size_b,
+                                 int act, int grad, float alpha, float scale, hipStream_t s);
 hipError_t launch_ssim(const float* rec, const float* clean, double* out, int B, int C, int H, int W, hipStream_t s);   // metrics.hip
 hipError_t launch_vjp_normalise(const float* vec, float* vec_scaled, int64_t n, unsigned int* amax_bits, float* scale, hipStream_t s);
 hipError_t launch_scale_inplace(float* x, int64_t n, const float* scale, hipStream_t s);

@@ -28,6 +28,8 @@ class OT_ODE(object):
         self.model = model.to(device)
         self.method = args.method
         self.lib = _lib.load()
+        self.use_graph = True           # one hipGraph per Euler step
+        self.last_callback_seconds = 0.0
         self.init_noise = None          # optional override of the randn_like in `initialization` (parity runs)
         self.measurement_noise = None   # optional override of the torch.manual_seed(batch) draw
         self.last_restored = None
@@ -55,37 +57,59 @@ class OT_ODE(object):
         f = lambda a: a.to(torch.float32).contiguous().to(dev)
         return f(t1), f(omt), f(rt2), f(coef)
 
-    def restore_batch(self, noisy_img, degradation, sigma_noise, iter_cb=None):
+    def restore_batch(self, noisy_img, degradation, sigma_noise, iter_cb=None, cb_iterations=None):
+        """The loop of solve_ip for one batch (ot_ode.py:49-52, 63-147) on the engine: pf_ot_ode_restore runs every Euler step on
+        the device - schedule scalars from device tables, pre-allocated buffers, one hipGraph per step (retained forward ->
+        closed-form / Fourier solve -> hand-written backward -> update).  iter_cb(iteration, x) is called on the host after the
+        iterations in `cb_iterations` (None = every iteration)."""
         args = self.args
         problem = args.problem
         if problem not in ("denoising", "inpainting", "random_inpainting", "superresolution", "gaussian_deblurring_FFT"):
             # the reference's remaining branch is a per-image GMRES on H H^T (ot_ode.py:118-128); none of its operators reach it
             raise NotImplementedError(f"ot_ode linear solve for '{problem}' is not implemented by this engine")
-        steps, delta = args.steps_ode, 1 / args.steps_ode
+        steps, delta = int(args.steps_ode), 1 / args.steps_ode
+        first = int(steps * args.start_time)
         B = noisy_img.shape[0]
-        Cc, Hh = self.model.input_channels, self.model.input_height
+        Hh = self.model.input_height
         dev = noisy_img.device
         d = degradation.descriptor(B, Hh, Hh, dev)
         y = noisy_img.contiguous().float()
-        x = self.initialization(degradation.H_adj(y.clone()), args.start_time).contiguous()     # ot_ode.py:50-52
-        vec = torch.empty_like(x)
-        n = x[0].numel()
-        # Fourier-domain solve (ot_ode.py:108-117): workspace for x1_hat, H(x1_hat), the complex spectrum and |fft filter|^2
-        scratch = torch.empty(4 * x.numel() + 2 * Hh, dtype=torch.float32, device=dev) if problem == "gaussian_deblurring_FFT" else None
-        st = _lib.current_stream_ptr()
-        for iteration in range(int(steps * args.start_time), int(steps)):
-            t1, omt, rt2, coef = self._scalars(iteration, delta, problem, B, dev)
-            vt = self.model.forward_retain(x, t1)
-            _lib.check(self.lib.pf_ot_ode_vec(C.byref(d), x.data_ptr(), vt.data_ptr(), y.data_ptr(), omt.data_ptr(), rt2.data_ptr(),
-                                              float(np.float32(sigma_noise) ** 2) if problem == "superresolution" else float(sigma_noise ** 2),
-                                              vec.data_ptr(), B, Cc, Hh, Hh, scratch.data_ptr() if scratch is not None else None, st),
-                       None, "pf_ot_ode_vec")
-            g = self.model.backward(vec)
-            _lib.check(self.lib.pf_ot_ode_update(x.data_ptr(), vt.data_ptr(), vec.data_ptr(), g.data_ptr(), omt.data_ptr(), coef.data_ptr(),
-                                                 float(delta), B, n, st), None, "pf_ot_ode_update")
-            if iter_cb is not None:
-                iter_cb(iteration, x)
-        self.model.check_numerics()
+        x = self.initialization(degradation.H_adj(y.clone()), args.start_time).contiguous().float()     # ot_ode.py:50-52
+        # per-iteration scalars with the reference's own fp32 expressions (one value per iteration: they are batch-constant)
+        tab = np.zeros((4, steps), dtype=np.float32)
+        for it in range(first, steps):
+            t1, omt, rt2, coef = self._scalars(it, delta, problem, 1, "cpu")
+            tab[0, it], tab[1, it], tab[2, it], tab[3, it] = float(t1[0]), float(omt[0]), float(rt2[0]), float(coef[0])
+        prm = _lib.PfOtOdeParams()
+        prm.steps, prm.first = steps, first
+        fp = lambda r: tab[r].ctypes.data_as(C.POINTER(C.c_float))
+        prm.host_t, prm.host_one_minus_t, prm.host_rt2, prm.host_coef = fp(0), fp(1), fp(2), fp(3)
+        prm.sigma2 = float(np.float32(sigma_noise) ** 2) if problem == "superresolution" else float(sigma_noise ** 2)
+        prm.delta = float(delta)
+        prm.use_graph = 1 if self.use_graph else 0
+        holder = {"err": None}
+        self.last_callback_seconds = 0.0
+        if iter_cb is not None:
+            def _cb(it, user):
+                t_cb = perf_counter()
+                try:
+                    if holder["err"] is None:
+                        iter_cb(it, x)
+                except BaseException as exc:      # must not unwind through the C frames: re-raised below
+                    holder["err"] = exc
+                self.last_callback_seconds += perf_counter() - t_cb
+            cb = _lib.ITER_CB(_cb)
+            if cb_iterations is not None:
+                mask = np.zeros(steps, dtype=np.uint8)
+                mask[[i for i in cb_iterations if 0 <= i < steps]] = 1
+                holder["mask"] = mask
+                prm.host_cb_mask = mask.ctypes.data
+        else:
+            cb = C.cast(None, _lib.ITER_CB)
+        _lib.check(self.lib.pf_ot_ode_restore(self.model.handle, C.byref(d), C.byref(prm), y.data_ptr(), x.data_ptr(), B,
+                                              _lib.current_stream_ptr(), cb, None), self.model.handle, "pf_ot_ode_restore")
+        if holder["err"] is not None:
+            raise holder["err"]
         return x
 
     def solve_ip(self, test_loader, degradation, sigma_noise, H_funcs=None):
@@ -123,20 +147,21 @@ class OT_ODE(object):
                 torch.cuda.synchronize(); t0 = perf_counter()
             if self.args.compute_memory:
                 torch.cuda.reset_peak_memory_stats(self.device)
-            self._cb_seconds = 0.0
 
             def on_iter(iteration, x):
-                if self.args.save_results and (iteration % 10 == 0 or self.should_save_image(iteration, steps)):
-                    t_cb = perf_counter()
-                    utils.compute_psnr(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=iteration)
-                    utils.compute_ssim(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=iteration)
-                    self._cb_seconds += perf_counter() - t_cb
+                utils.compute_psnr(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=iteration)
+                utils.compute_ssim(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=iteration)
+
+            # the reference's logging iterations (ot_ode.py:149-150): the host is not involved on any other iteration
+            log_its = [it for it in range(int(steps * self.args.start_time), int(steps))
+                       if it % 10 == 0 or self.should_save_image(it, steps)] if self.args.save_results else []
 
             saved_init = self.init_noise
             if init is not None:
                 self.init_noise = init
             try:
-                x = self.restore_batch(noisy_img, degradation, sigma_noise, iter_cb=on_iter if self.args.save_results else None)
+                x = self.restore_batch(noisy_img, degradation, sigma_noise, iter_cb=on_iter if self.args.save_results else None,
+                                       cb_iterations=log_its)
             finally:
                 self.init_noise = saved_init
             self.last_restored = x
@@ -145,7 +170,7 @@ class OT_ODE(object):
                                       self.args)
             if self.args.compute_time:
                 torch.cuda.synchronize()
-                utils.save_time_use({"batch": batch, "time_per_batch": perf_counter() - t0 - self._cb_seconds}, self.args)
+                utils.save_time_use({"batch": batch, "time_per_batch": perf_counter() - t0 - self.last_callback_seconds}, self.args)
             if self.args.save_results:
                 utils.compute_psnr(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=int(steps) - 1)
                 utils.compute_ssim(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=int(steps) - 1)

@@ -268,3 +268,29 @@ def test_ot_ode_c5_step_matches_reference(golden):
     except _Stop:
         pass
     _check_crops(its[10], g, "x_it10", 2e-5 * float(np.abs(g["x_it10_crop"]).max()))
+
+
+# ---- the reference's native ops (NCSN++ net): op/upfirdn2d.py, op/fused_act.py ------------------------------------------------
+UPFIRDN_CASES = ["fir4_up2", "fir4_down2", "asym3x2_up3_down2_crop", "k1_identity", "k5_pad"]
+
+
+@pytest.mark.parametrize("name", UPFIRDN_CASES)
+def test_upfirdn2d_matches_reference(golden, name):
+    g = golden("native_ops")
+    x = det_normal((2, 3, 20, 24), 71)
+    ux, uy, dx, dy, px0, px1, py0, py1 = [int(v) for v in g[name + "_p"]]
+    out = O.upfirdn2d(x, torch.from_numpy(g[name + "_k"]), ux, uy, dx, dy, px0, px1, py0, py1)
+    assert tuple(out.shape) == g[name + "_out"].shape
+    np.testing.assert_allclose(out.numpy(), g[name + "_out"], atol=1e-6)
+
+
+def test_fir_resampling_and_fused_act_match_reference(golden):
+    g = golden("native_ops")
+    x2 = det_normal((2, 4, 16, 16), 72)
+    np.testing.assert_allclose(O.upsample_2d(x2, (1, 3, 3, 1), 2).numpy(), g["upsample_2d_1331"], atol=1e-6)
+    np.testing.assert_allclose(O.downsample_2d(x2, (1, 3, 3, 1), 2).numpy(), g["downsample_2d_1331"], atol=1e-6)
+    np.testing.assert_allclose(O.upsample_2d(x2, None, 2).numpy(), g["upsample_2d_default"], atol=1e-6)
+    np.testing.assert_allclose(O.downsample_2d(x2, None, 2).numpy(), g["downsample_2d_default"], atol=1e-6)
+    xb = det_normal((2, 5, 6, 7), 73); bias = det_normal((5,), 74)
+    np.testing.assert_allclose(O.fused_leaky_relu(xb, bias).numpy(), g["fused_leaky_relu"], atol=1e-6)
+    np.testing.assert_allclose(O.fused_leaky_relu(det_normal((3, 5), 75), bias).numpy(), g["fused_leaky_relu_2d"], atol=1e-6)

@@ -3,7 +3,7 @@
 #   run (on the GPU box):   bash tools/ab_variants.sh run [dim] [B] [reps]
 set -e
 cd "$(dirname "$0")/.."
-SRC="engine.hip conv_mfma.hip conv_mfma16.hip conv_ws.hip unet_misc.hip attention.hip unet_bwd.hip pointwise.hip fft2.hip metrics.hip"
+SRC="engine.hip conv_mfma.hip conv_mfma16.hip conv_ws.hip unet_misc.hip attention.hip unet_bwd.hip pointwise.hip fft2.hip metrics.hip fir_ops.hip"
 if [ "$1" = "build" ]; then
   mkdir -p gpurun_out/ab
   build() { /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-result -Wno-unused-value $2 -o pnpflow_amd/libpnpflow_hip_ab_$1.so $(for f in $SRC; do echo pnpflow_amd/csrc/$f; done) & }

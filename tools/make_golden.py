@@ -340,10 +340,53 @@ def gen_big(models, degr, utils):
     print("ot_ode step afhq256", iterates[10].abs().mean().item())
 
 
+def gen_ops():
+    """The reference's native ops through their own pure-torch definitions: op/upfirdn2d.py `upfirdn2d_native` (:142-187) and the
+    CPU branch of op/fused_act.py `fused_leaky_relu` (:84-96), imported with torch.utils.cpp_extension.load stubbed out (the
+    modules JIT-compile their CUDA sources at import, which cannot happen here), plus upsample_2d / downsample_2d of
+    models/up_or_down_sampling.py, which call them."""
+    import importlib
+    import types
+    import torch.utils.cpp_extension as ce
+    saved = ce.load
+    ce.load = lambda *a, **k: types.SimpleNamespace()
+    try:
+        from ref_import import install_stubs, REF
+        install_stubs()
+        if REF not in sys.path:
+            sys.path.insert(0, REF)
+        up = importlib.import_module("pnpflow.image_generation.op.upfirdn2d")
+        fa = importlib.import_module("pnpflow.image_generation.op.fused_act")
+        uds = importlib.import_module("pnpflow.image_generation.models.up_or_down_sampling")
+    finally:
+        ce.load = saved
+    rec = {}
+    x = det_normal((2, 3, 20, 24), 71)
+    cases = [("fir4_up2", np.outer([1, 3, 3, 1], [1, 3, 3, 1]) / 16.0, 2, 2, 1, 1, 2, 1, 2, 1),
+             ("fir4_down2", np.outer([1, 3, 3, 1], [1, 3, 3, 1]) / 64.0, 1, 1, 2, 2, 1, 1, 1, 1),
+             ("asym3x2_up3_down2_crop", np.array([[1.0, -2.0], [0.5, 3.0], [4.0, -1.5]]), 3, 2, 2, 3, -1, 2, 3, -2),
+             ("k1_identity", np.array([[1.0]]), 1, 1, 1, 1, 0, 0, 0, 0),
+             ("k5_pad", np.arange(25, dtype=np.float64).reshape(5, 5) / 25.0, 1, 1, 1, 1, 2, 2, 2, 2)]
+    for name, k, ux, uy, dx, dy, px0, px1, py0, py1 in cases:
+        kt = torch.from_numpy(np.asarray(k, dtype=np.float32))
+        rec[name + "_k"] = kt.numpy(); rec[name + "_p"] = np.array([ux, uy, dx, dy, px0, px1, py0, py1])
+        rec[name + "_out"] = up.upfirdn2d_native(x, kt, ux, uy, dx, dy, px0, px1, py0, py1).numpy()
+    x2 = det_normal((2, 4, 16, 16), 72)
+    rec["upsample_2d_1331"] = uds.upsample_2d(x2, (1, 3, 3, 1), factor=2).numpy()
+    rec["downsample_2d_1331"] = uds.downsample_2d(x2, (1, 3, 3, 1), factor=2).numpy()
+    rec["upsample_2d_default"] = uds.upsample_2d(x2, factor=2).numpy()
+    rec["downsample_2d_default"] = uds.downsample_2d(x2, factor=2).numpy()
+    xb = det_normal((2, 5, 6, 7), 73); bias = det_normal((5,), 74)
+    rec["fused_leaky_relu"] = fa.fused_leaky_relu(xb, bias, 0.2, 2 ** 0.5).numpy()
+    rec["fused_leaky_relu_2d"] = fa.fused_leaky_relu(det_normal((3, 5), 75), bias, 0.2, 2 ** 0.5).numpy()
+    np.savez_compressed(os.path.join(OUT, "native_ops.npz"), **rec)
+    print("native ops ok")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     models, degr, utils, pnp = import_reference()
-    which = sys.argv[1:] or ["unet", "degr", "traj", "ot_ode", "big"]
+    which = sys.argv[1:] or ["unet", "degr", "traj", "ot_ode", "big", "ops"]
     if "unet" in which:
         gen_unet(models)
     if "degr" in which:
@@ -354,3 +397,5 @@ if __name__ == "__main__":
         gen_ot_ode(models, degr, utils)
     if "big" in which:
         gen_big(models, degr, utils)
+    if "ops" in which:
+        gen_ops()

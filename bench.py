@@ -177,6 +177,7 @@ class Runner:
         if self.is_ode:
             from pnpflow_amd.methods.ot_ode import OT_ODE
             self.solver = OT_ODE(self.model, dev, self.args)
+            self.solver.use_graph = use_graph
             self.solver.init_noise = init_noise.to(dev)
         else:
             self.solver = PNP_FLOW(self.model, dev, self.args)

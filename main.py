@@ -48,6 +48,8 @@ def make_degradation(problem, dim_image, num_channels, noise_type, device):
         return D.Denoising(), (0.3 if lap else 0.2)
     if problem == "inpainting":
         return D.BoxInpainting({128: 20, 256: 40}[dim_image]), (0.3 if lap else 0.05)
+    if problem == "paintbrush_inpainting":
+        return D.PaintbrushInpainting(), (0.3 if lap else 0.05)
     if problem == "random_inpainting":
         return D.RandomInpainting(0.7), (0.3 if lap else 0.01)
     if problem == "superresolution":

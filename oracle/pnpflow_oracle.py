@@ -311,6 +311,41 @@ class RandomInpainting(Degradation):
     H_adj = H
 
 
+def paintbrush_mask_array(B: int, H: int, W: int) -> np.ndarray:
+    """pnpflow/utils.py:339-350 with MaskGenerator._generate_mask (:904-924): random.seed(42); per image 10 strokes
+    (endpoints randint(W//2 +- 30), randint(H//2 +- 30), thickness randint(8, int((W+H)*0.08))).  PARITY UNPINNED: the
+    reference rasterises strokes with cv2.line, which is not installed here; a stroke is restated as the capsule cv2's
+    rectangle + round caps approximates (pixels within thickness/2 of the segment); edge pixels may differ by one."""
+    import random
+    rng = random.Random(42)
+    size = int((W + H) * 0.08)
+    ys, xs = np.arange(H, dtype=np.float64)[:, None], np.arange(W, dtype=np.float64)[None, :]
+    out = np.ones((B, H, W), dtype=np.uint8)
+    for b in range(B):
+        for _ in range(10):
+            x1 = rng.randint(W // 2 - 30, W // 2 + 30); x2 = rng.randint(W // 2 - 30, W // 2 + 30)
+            y1 = rng.randint(H // 2 - 30, H // 2 + 30); y2 = rng.randint(H // 2 - 30, H // 2 + 30)
+            t = rng.randint(8, size)
+            ex, ey = float(x2 - x1), float(y2 - y1)
+            den = ex * ex + ey * ey
+            for yy in range(H):
+                for_x = xs[0]
+                u = np.clip(((for_x - x1) * ex + (yy - y1) * ey) / den, 0.0, 1.0) if den > 0 else np.zeros(W)
+                d2 = (for_x - (x1 + u * ex)) ** 2 + (yy - (y1 + u * ey)) ** 2
+                out[b, yy, d2 <= (t / 2.0) ** 2] = 0
+    return out
+
+
+class PaintbrushInpainting(Degradation):
+    """pnpflow/degradations.py:47-52"""
+
+    def H(self, x):
+        m = torch.from_numpy(paintbrush_mask_array(x.shape[0], x.shape[2], x.shape[3]).astype(np.float32))
+        return m[:, None] * x
+
+    H_adj = H
+
+
 class GaussianDeblurring(Degradation):
     """pnpflow/degradations.py:55-89, mode 'fft' : circular convolution via FFT."""
     def __init__(self, sigma_blur, kernel_size, mode="fft", num_channels=3, dim_image=128, device="cpu"):

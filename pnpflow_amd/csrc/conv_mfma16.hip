@@ -43,7 +43,7 @@ __device__ __forceinline__ float silu_fast16(float x) { return x * __builtin_amd
 #define PF_LB3(MT, WM, KC) (((MT) == 4 && (WM) == 2 && (KC) == 16) || ((KC) != 64 && (((MT) == 4 && (WM) == 1) || ((MT) == 2 && (WM) == 4))))
 #endif
 
-template <int MT, int NT, int WM, int WN, int S, int UP, int KC>
+template <int MT, int NT, int WM, int WN, int S, int UP, int KC, bool GNB = false>
 __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16_kernel(const ConvParams p) {
     constexpr int ROW = KC + 4;                  // dwords per LDS row: KC/2 (hi) + KC/2 (lo) + 4 (pad)
     constexpr int KQ = KC / 4, KH = KC / 2, KS = KC / 16;
@@ -338,13 +338,36 @@ __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16
         const int n4 = ncol + cq * 4;
         const bool nok4 = n4 < p.Cout;
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        // fused GroupNorm-backward first stage (GNB): per-channel forward coefficients of this lane's 4 channels
+        float4 g_mu, g_rs, g_ga, g_be;
+        if constexpr (GNB) {
+            const int gc = p.gnb_coff + min(n4, p.Cout - 4);
+            g_mu = *reinterpret_cast<const float4*>(p.gnb_mu + (size_t)b * p.gnb_Ct + gc);
+            g_rs = *reinterpret_cast<const float4*>(p.gnb_rs + (size_t)b * p.gnb_Ct + gc);
+            g_ga = *reinterpret_cast<const float4*>(p.gnb_gamma + gc);
+            g_be = *reinterpret_cast<const float4*>(p.gnb_beta + gc);
+        }
         // Residual values are requested for two M-tiles at a time, before any of their stores: a load issued while
         // stores are outstanding makes the wave wait for every store acknowledgement (one counter for loads and stores),
         // which the former load-add-store sequence per float4 paid 4 x MT times per workgroup.
         constexpr int RG = (MT >= 2 && WN != 4) ? 2 : 1;      // (one at a time where a second set of 16 registers would cost a wave per SIMD)
         float4 rv[RG][4];
+        float4 xv[GNB ? RG : 1][4];                            // GNB: the GroupNorm's forward input at the same pixels, requested like the residual
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+            if constexpr (GNB) {
+                if (mt % RG == 0) {
+#pragma unroll
+                    for (int g = 0; g < RG; ++g)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int px = (lane >> 3) + 8 * i;
+                            const int oy = min(oy0 + (wm * MT + mt + g) * 2 + (px >> 4), p.H - 1), ox = min(ox0 + (px & 15), p.W - 1);
+                            const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
+                            xv[g][i] = *reinterpret_cast<const float4*>(p.gnb_x + pix * p.gnb_xstride + min(n4, p.Cout - 4));
+                        }
+                }
+            }
             if (mt % RG == 0 && p.residual != nullptr && !PF_DBG(32)) {
 #pragma unroll
                 for (int g = 0; g < RG; ++g)
@@ -374,16 +397,36 @@ __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16
                     if (p.residual != nullptr && !PF_DBG(32)) {
                         v.x += rv[mt % RG][i].x; v.y += rv[mt % RG][i].y; v.z += rv[mt % RG][i].z; v.w += rv[mt % RG][i].w;
                     }
+                    if constexpr (GNB) {
+                        // dyhat = da * act'(u) * gamma,  u = gamma*yhat + beta,  yhat = (x - mu)*rstd   (same expressions as gn_bwd_pre_kernel)
+                        const float4 xx = xv[mt % RG][i];
+                        float d[4] = {v.x, v.y, v.z, v.w};
+                        const float xs[4] = {xx.x, xx.y, xx.z, xx.w}, mm[4] = {g_mu.x, g_mu.y, g_mu.z, g_mu.w}, rr[4] = {g_rs.x, g_rs.y, g_rs.z, g_rs.w};
+                        const float gg[4] = {g_ga.x, g_ga.y, g_ga.z, g_ga.w}, bb[4] = {g_be.x, g_be.y, g_be.z, g_be.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float yh = (xs[j] - mm[j]) * rr[j];
+                            if (p.gnb_silu) {
+                                const float u = yh * gg[j] + bb[j];
+                                const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+                                d[j] *= sg * (1.0f + u * (1.0f - sg));
+                            }
+                            d[j] *= gg[j];
+                            s1[j] += d[j]; s2[j] += d[j] * yh;
+                        }
+                        *reinterpret_cast<float4*>(p.out + pix * p.out_cstride + n4) = make_float4(d[0], d[1], d[2], d[3]);
+                    } else {
                     *reinterpret_cast<float4*>(p.out + pix * p.out_cstride + n4) = v;
                     s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;
                     s2[0] += v.x * v.x; s2[1] += v.y * v.y; s2[2] += v.z * v.z; s2[3] += v.w * v.w;
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();            // scratch is rewritten by the next tile
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        if (p.stats_out != nullptr && !PF_DBG(128)) {
+        if ((GNB || p.stats_out != nullptr) && !PF_DBG(128)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -399,7 +442,7 @@ __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16
         }
     }
     mark(3);
-    if (p.stats_out != nullptr && !PF_DBG(128)) {
+    if ((GNB || p.stats_out != nullptr) && !PF_DBG(128)) {
         __syncthreads();
         for (int t = tid; t < BN * 2; t += 256) {
             const int col = t >> 1, which = t & 1;
@@ -407,7 +450,10 @@ __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16
 #pragma unroll
             for (int w = 0; w < WM; ++w) tot += s_red[(w * BN + col) * 2 + which];
             const int n = n0 + col;
-            if (n < p.Cout) unsafeAtomicAdd(p.stats_out + ((size_t)b * p.Cout + n) * 2 + which, (double)tot);
+            if (n < p.Cout) {
+                if constexpr (GNB) unsafeAtomicAdd(p.gnb_sum + ((size_t)b * p.gnb_Ct + p.gnb_coff + n) * 2 + which, (double)tot);
+                else unsafeAtomicAdd(p.stats_out + ((size_t)b * p.Cout + n) * 2 + which, (double)tot);
+            }
         }
     }
     mark(4);
@@ -429,6 +475,22 @@ static hipError_t launch_cfg16(const ConvParams& p, hipStream_t stream) {
     constexpr int BN = WN * NT * 32;
     constexpr int EPI = 4 * 32 * 36 + WM * BN * 2;           // epilogue: 4 per-wave transpose tiles + statistics scratch (floats)
     const size_t lds = (size_t)((PP * ROW > EPI ? PP * ROW : EPI) + 2 * ((p.gn_C + 3) & ~3)) * 4;
+    const int tiles = p.B * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
+    dim3 grid(tiles, (p.Cout + BN - 1) / BN);
+    if constexpr (S == 1 && UP == 0) {
+        if (p.gnb_x != nullptr) {        // adjoint conv with the fused GroupNorm-backward first stage
+            static bool attr_set_g = false;
+            auto kg = conv_mfma16_kernel<MT, NT, WM, WN, S, UP, KC, true>;
+            if (!attr_set_g) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+                attr_set_g = true;
+            }
+            hipLaunchKernelGGL(kg, grid, dim3(256), lds, stream, p);
+            return hipGetLastError();
+        }
+    }
+    if (p.gnb_x != nullptr) return hipErrorInvalidValue;
     static bool attr_set = false;
     auto kern = conv_mfma16_kernel<MT, NT, WM, WN, S, UP, KC>;
     if (!attr_set) {
@@ -436,8 +498,6 @@ static hipError_t launch_cfg16(const ConvParams& p, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int tiles = p.B * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
-    dim3 grid(tiles, (p.Cout + BN - 1) / BN);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     return hipGetLastError();
 }

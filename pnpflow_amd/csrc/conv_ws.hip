@@ -432,7 +432,7 @@ bool conv_ws_supported(const ConvParams& p, int stride, int up) {
     // opt-in (PNPFLOW_HIP_WS=1): measured slower than conv_mfma16_kernel on every layer class of the BASELINE nets in round 2
     // (profiles/r02_ws_vs_lockstep_layers.md) - one consumer wave per SIMD has nothing to cover its epilogue / L2 round trips
     static const bool enabled = getenv("PNPFLOW_HIP_WS") && atoi(getenv("PNPFLOW_HIP_WS")) != 0;
-    if (!enabled || stride != 1 || up != 0 || p.nseg < 1 || p.seg[0].taps != 9) return false;
+    if (!enabled || stride != 1 || up != 0 || p.nseg < 1 || p.seg[0].taps != 9 || p.gnb_x != nullptr) return false;
     if (p.gn_C > 0 && (p.coef == nullptr || p.gn_C % 4 != 0)) return false;
     for (int i = 0; i < p.nseg; ++i) {
         const ConvSeg& s = p.seg[i];

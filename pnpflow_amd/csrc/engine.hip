@@ -565,7 +565,7 @@ static Tensor resample_conv(Builder& bd, const std::string& pfx, const Tensor& x
 static void fix_stats(Op& op, double* slab) {
     auto fx = [&](const double*& p) { if (p) p = (const double*)((char*)slab + ((uintptr_t)p - 1)); };
     auto fxm = [&](double*& p) { if (p) p = (double*)((char*)slab + ((uintptr_t)p - 1)); };
-    if (op.kind == OP_CONV) { for (int i = 0; i < op.cp.nseg; ++i) fx(op.cp.seg[i].stats); fxm(op.cp.stats_out); }
+    if (op.kind == OP_CONV) { for (int i = 0; i < op.cp.nseg; ++i) fx(op.cp.seg[i].stats); fxm(op.cp.stats_out); fxm(op.cp.gnb_sum); }
     if (op.kind == OP_GN_COEF) for (int i = 0; i < op.gp.nseg; ++i) fx(op.gp.st[i]);
     if (op.kind == OP_END) fx(op.ep.stats);
     if (op.kind == OP_BEGIN) fxm(op.ep.stats_out);
@@ -796,37 +796,72 @@ static void gen_seg(ConvParams& p, const float* src, int C, int cstride, const f
     s.w = w; s.w_mode = 1; s.w_bs = w_bs; s.w_cs = 0; s.w_ts = 0; s.w_ns = w_ns; s.w_ks = w_ks;
 }
 
-// GroupNorm(+SiLU) backward over a (possibly concatenated) input.  srcs[j] = forward input tensor j,
-// gtmp[j] = gradient w.r.t. the activated/normalised tensor (overwritten), dst[j] = where dx goes,
-// add[j] = optional extra addend (identity-shortcut gradient).
+// GroupNorm(+SiLU) backward over a (possibly concatenated) input, in three steps so that the FIRST stage (dyhat = da*act'(u)*gamma
+// and its two per-channel sums) can be fused into the epilogue of the adjoint conv that produces da (ConvParams::gnb_*):
+//   gn_bwd_begin   forward coefficients mu / rstd of the GroupNorm, the sum slab
+//   gn_bwd_fuse    fills the gnb_* fields of the conv that writes source j's da (split-fp16 kernel, stride 1): no PRE pass for j
+//   gn_bwd_finish  PRE pass for the sources that were not fused, group means, second stage
+// srcs[j] = forward input tensor j, gtmp[j] = gradient w.r.t. the activated/normalised tensor (overwritten),
+// dst[j] = where dx goes, add[j] = optional extra addend (identity-shortcut gradient).
+struct GnBwd {
+    std::vector<Tensor> srcs; int Ct = 0, cpg = 0, HW = 0; bool silu = false;
+    float *mu = nullptr, *rs = nullptr, *m1 = nullptr, *m2 = nullptr; double* bsum = nullptr;
+    const float *gamma = nullptr, *beta = nullptr;
+    std::vector<bool> fused;
+};
+
+static GnBwd gn_bwd_begin(BwdCtx& c, const std::vector<Tensor>& srcs, const std::string& norm_prefix, bool silu) {
+    pf_engine* e = c.e; const int B = c.B;
+    GnBwd g; g.srcs = srcs; g.silu = silu; g.HW = srcs[0].H * srcs[0].W;
+    for (auto& t : srcs) g.Ct += t.C;
+    g.cpg = g.Ct / 32; g.fused.assign(srcs.size(), false);
+    g.mu = c.fvec((size_t)B * g.Ct); g.rs = c.fvec((size_t)B * g.Ct); g.m1 = c.fvec((size_t)B * g.Ct); g.m2 = c.fvec((size_t)B * g.Ct);
+    g.bsum = c.dsum((size_t)B * g.Ct * 2);
+    g.gamma = upload(e, norm_prefix + "weight", W(e, norm_prefix + "weight").data);
+    g.beta = upload(e, norm_prefix + "bias", W(e, norm_prefix + "bias").data);
+    Op op{}; op.kind = OP_GN_FWD_COEF; op.P[0] = srcs[0].stats; op.P[1] = srcs.size() > 1 ? srcs[1].stats : nullptr; op.P[2] = g.mu; op.P[3] = g.rs;
+    op.I[0] = srcs[0].C; op.I[1] = srcs.size() > 1 ? srcs[1].C : 0; op.I[2] = g.cpg; op.I[3] = g.HW; c.push(op);
+    return g;
+}
+
+// returns true (and marks source j fused) when the conv described by p can carry the first stage in its epilogue
+static bool gn_bwd_fuse(BwdCtx& c, GnBwd& g, size_t j, ConvParams& p, int stride = 1, int up = 0) {
+    static const bool enabled = !(getenv("PNPFLOW_HIP_GNB_FUSE") && atoi(getenv("PNPFLOW_HIP_GNB_FUSE")) == 0);
+    bool ok16 = c.e->precision != 0 && enabled && stride == 1 && up == 0 && p.residual == nullptr && p.stats_out == nullptr && p.Cout % 4 == 0;
+    for (int i = 0; i < p.nseg; ++i) ok16 &= p.seg[i].w_mode == 0 && p.seg[i].w16 != nullptr;
+    if (!ok16) return false;
+    int coff = 0; for (size_t k = 0; k < j; ++k) coff += g.srcs[k].C;
+    p.gnb_x = g.srcs[j].p; p.gnb_xstride = g.srcs[j].C; p.gnb_mu = g.mu; p.gnb_rs = g.rs; p.gnb_gamma = g.gamma; p.gnb_beta = g.beta;
+    p.gnb_Ct = g.Ct; p.gnb_coff = coff; p.gnb_silu = g.silu ? 1 : 0; p.gnb_sum = g.bsum;
+    g.fused[j] = true;
+    return true;
+}
+
+static void gn_bwd_finish(BwdCtx& c, GnBwd& g, const std::vector<Tensor>& gtmp, const std::vector<GradEntry*>& dst,
+                          const std::vector<const float*>& add) {
+    int coff = 0;
+    for (size_t j = 0; j < g.srcs.size(); ++j) {
+        if (!g.fused[j]) {
+            Op op{}; op.kind = OP_GN_BWD_PRE; op.O = gtmp[j].p; op.P[0] = g.srcs[j].p; op.P[1] = g.mu; op.P[2] = g.rs; op.P[3] = g.gamma; op.P[4] = g.beta;
+            op.P[6] = g.bsum; op.I[0] = g.HW; op.I[1] = g.srcs[j].C; op.I[2] = coff; op.I[3] = g.Ct; op.I[4] = g.silu ? 1 : 0; c.push(op);
+        }
+        coff += g.srcs[j].C;
+    }
+    { Op op{}; op.kind = OP_GN_BWD_COEF; op.P[6] = g.bsum; op.P[1] = g.m1; op.P[2] = g.m2; op.I[0] = g.Ct; op.I[1] = g.cpg; op.I[2] = g.HW; c.push(op); }
+    coff = 0;
+    for (size_t j = 0; j < g.srcs.size(); ++j) {
+        Op op{}; op.kind = OP_GN_BWD_POST; op.P[0] = gtmp[j].p; op.P[1] = g.srcs[j].p; op.P[2] = g.mu; op.P[3] = g.rs; op.P[4] = g.m1; op.P[5] = g.m2;
+        op.P[7] = add[j]; op.O = dst[j]->t.p; op.I[0] = g.HW; op.I[1] = g.srcs[j].C; op.I[2] = coff; op.I[3] = g.Ct; op.I[4] = dst[j]->has ? 1 : 0;
+        dst[j]->has = true; c.push(op);
+        coff += g.srcs[j].C;
+    }
+    c.bd->recycle(g.mu); c.bd->recycle(g.rs); c.bd->recycle(g.m1); c.bd->recycle(g.m2);
+}
+
 static void gn_backward(BwdCtx& c, const std::vector<Tensor>& srcs, const std::vector<Tensor>& gtmp, const std::vector<GradEntry*>& dst,
                         const std::vector<const float*>& add, const std::string& norm_prefix, bool silu) {
-    pf_engine* e = c.e; const int B = c.B;
-    const int HW = srcs[0].H * srcs[0].W;
-    int Ct = 0; for (auto& t : srcs) Ct += t.C;
-    const int cpg = Ct / 32;
-    float* mu = c.fvec((size_t)B * Ct); float* rs = c.fvec((size_t)B * Ct);
-    float* m1 = c.fvec((size_t)B * Ct); float* m2 = c.fvec((size_t)B * Ct);
-    double* bsum = c.dsum((size_t)B * Ct * 2);
-    const float* gamma = upload(e, norm_prefix + "weight", W(e, norm_prefix + "weight").data);
-    const float* beta = upload(e, norm_prefix + "bias", W(e, norm_prefix + "bias").data);
-    { Op op{}; op.kind = OP_GN_FWD_COEF; op.P[0] = srcs[0].stats; op.P[1] = srcs.size() > 1 ? srcs[1].stats : nullptr; op.P[2] = mu; op.P[3] = rs;
-      op.I[0] = srcs[0].C; op.I[1] = srcs.size() > 1 ? srcs[1].C : 0; op.I[2] = cpg; op.I[3] = HW; c.push(op); }
-    int coff = 0;
-    for (size_t j = 0; j < srcs.size(); ++j) {
-        Op op{}; op.kind = OP_GN_BWD_PRE; op.O = gtmp[j].p; op.P[0] = srcs[j].p; op.P[1] = mu; op.P[2] = rs; op.P[3] = gamma; op.P[4] = beta;
-        op.P[6] = bsum; op.I[0] = HW; op.I[1] = srcs[j].C; op.I[2] = coff; op.I[3] = Ct; op.I[4] = silu ? 1 : 0; c.push(op);
-        coff += srcs[j].C;
-    }
-    { Op op{}; op.kind = OP_GN_BWD_COEF; op.P[6] = bsum; op.P[1] = m1; op.P[2] = m2; op.I[0] = Ct; op.I[1] = cpg; op.I[2] = HW; c.push(op); }
-    coff = 0;
-    for (size_t j = 0; j < srcs.size(); ++j) {
-        Op op{}; op.kind = OP_GN_BWD_POST; op.P[0] = gtmp[j].p; op.P[1] = srcs[j].p; op.P[2] = mu; op.P[3] = rs; op.P[4] = m1; op.P[5] = m2;
-        op.P[7] = add[j]; op.O = dst[j]->t.p; op.I[0] = HW; op.I[1] = srcs[j].C; op.I[2] = coff; op.I[3] = Ct; op.I[4] = dst[j]->has ? 1 : 0;
-        dst[j]->has = true; c.push(op);
-        coff += srcs[j].C;
-    }
-    c.bd->recycle(mu); c.bd->recycle(rs); c.bd->recycle(m1); c.bd->recycle(m2);
+    GnBwd g = gn_bwd_begin(c, srcs, norm_prefix, silu);
+    gn_bwd_finish(c, g, gtmp, dst, add);
 }
 
 static int build_backward(pf_engine* e, Plan* plan, Builder& bd) {
@@ -878,23 +913,30 @@ static int build_backward(pf_engine* e, Plan* plan, Builder& bd) {
             const int cin = tr.in0.C + (tr.has_in1 ? tr.in1.C : 0);
             // conv2 adjoint -> d(act2), GN2+SiLU backward -> d(h1)
             Tensor t1 = c.tmp(r.cout, H, Wd);
+            GnBwd gn2 = gn_bwd_begin(c, {tr.h1}, r.prefix + "norm2.", true);
             {
                 ConvParams p = bwd_params(B, H, Wd, H, Wd, r.cout);
                 raw_seg(p, gout.t.p, r.cout, r.cout, 9, packed_conv_T(e, r.prefix + "conv2.weight", 0, r.cout), packed_conv16_T(e, r.prefix + "conv2.weight", 0, r.cout));
-                p.out = t1.p; p.out_cstride = r.cout; c.conv_plain(p);
+                p.out = t1.p; p.out_cstride = r.cout;
+                gn_bwd_fuse(c, gn2, 0, p);
+                c.conv_plain(p);
             }
             GradEntry gh1; gh1.t = c.tmp(r.cout, H, Wd);
-            gn_backward(c, {tr.h1}, {t1}, {&gh1}, {nullptr}, r.prefix + "norm2.", true);
+            gn_bwd_finish(c, gn2, {t1}, {&gh1}, {nullptr});
             bd.recycle(t1.p);
             // conv1 adjoint per source -> d(act1), GN1+SiLU backward over the concatenation
             std::vector<Tensor> srcs{tr.in0}; if (tr.has_in1) srcs.push_back(tr.in1);
             std::vector<Tensor> us; std::vector<GradEntry*> dsts; std::vector<const float*> adds;
+            GnBwd gn1 = gn_bwd_begin(c, srcs, r.prefix + "norm1.", true);
             int lo = 0;
-            for (auto& sT : srcs) {
+            for (size_t sj = 0; sj < srcs.size(); ++sj) {
+                const Tensor& sT = srcs[sj];
                 Tensor u = c.tmp(sT.C, H, Wd);
                 ConvParams p = bwd_params(B, H, Wd, H, Wd, sT.C);
                 raw_seg(p, gh1.t.p, r.cout, r.cout, 9, packed_conv_T(e, r.prefix + "conv1.weight", lo, lo + sT.C), packed_conv16_T(e, r.prefix + "conv1.weight", lo, lo + sT.C));
-                p.out = u.p; p.out_cstride = sT.C; c.conv_plain(p);
+                p.out = u.p; p.out_cstride = sT.C;
+                gn_bwd_fuse(c, gn1, sj, p);
+                c.conv_plain(p);
                 us.push_back(u);
                 GradEntry& gd = c.G(sT);
                 if (cin != r.cout) {   // 1x1 shortcut adjoint goes straight into the gradient buffer
@@ -908,7 +950,7 @@ static int build_backward(pf_engine* e, Plan* plan, Builder& bd) {
                 dsts.push_back(&gd);
                 lo += sT.C;
             }
-            gn_backward(c, srcs, us, dsts, adds, r.prefix + "norm1.", true);
+            gn_bwd_finish(c, gn1, us, dsts, adds);
             for (auto& u : us) bd.recycle(u.p);
             bd.recycle(gh1.t.p);
         } else {   // TP_ATTN  (models.py:145-162)
@@ -939,9 +981,12 @@ static int build_backward(pf_engine* e, Plan* plan, Builder& bd) {
               gen_seg(p, AT.p, HW, HW, tr.qkv.p, (int64_t)HW * 3 * C, 1, 3 * C); p.out = dqkv.p + C; p.out_cstride = 3 * C; c.conv_plain(p); }
             // d(hn) = dqkv . Wqkv ; GroupNorm backward (no activation) ; + identity path
             Tensor dhn = c.tmp(C, H, Wd);
+            GnBwd gna = gn_bwd_begin(c, {x}, tr.pfx + "norm.", false);
             { ConvParams p = bwd_params(B, H, Wd, H, Wd, C);
-              raw_seg(p, dqkv.p, 3 * C, 3 * C, 1, packed_conv_T(e, tr.pfx + "qkv.w", 0, C), packed_conv16_T(e, tr.pfx + "qkv.w", 0, C)); p.out = dhn.p; p.out_cstride = C; c.conv_plain(p); }
-            gn_backward(c, {x}, {dhn}, {&c.G(x)}, {gout.t.p}, tr.pfx + "norm.", false);
+              raw_seg(p, dqkv.p, 3 * C, 3 * C, 1, packed_conv_T(e, tr.pfx + "qkv.w", 0, C), packed_conv16_T(e, tr.pfx + "qkv.w", 0, C)); p.out = dhn.p; p.out_cstride = C;
+              gn_bwd_fuse(c, gna, 0, p);
+              c.conv_plain(p); }
+            gn_bwd_finish(c, gna, {dhn}, {&c.G(x)}, {gout.t.p});
             for (float* q : {d_o.p, dA.p, dqkv.p, AT.p, dhn.p}) bd.recycle(q);
         }
     }

@@ -53,6 +53,16 @@ struct ConvParams {
     // being walked (multiplied by scale[8b + si'] * scale[8b + 4 + si] at a switch si -> si', exact) and by scale[8b + 4 + last]
     // in the epilogue - so raw (un-normalised) inputs of any magnitude keep fp32-grade relative accuracy and cannot overflow fp16.
     const float* scale;
+    // GroupNorm(+SiLU) backward, first stage, fused into the epilogue (adjoint convs of the VJP on the split-fp16 kernel): the conv
+    // result da (gradient w.r.t. the normalised/activated tensor) becomes dyhat = da * act'(u) * gamma in registers, and the
+    // per-channel sums (sum dyhat, sum dyhat*yhat) are reduced in the same kernel - what unet_bwd.hip's gn_bwd_pre pass does with a
+    // read and a write of the whole tensor.  gnb_x == nullptr: off.  Output channel n <-> GroupNorm channel gnb_coff + n.
+    const float* gnb_x;          // forward input of the GroupNorm: NHWC, channels [0, Cout) of a tensor with gnb_xstride floats per pixel
+    int gnb_xstride;
+    const float* gnb_mu; const float* gnb_rs;         // [B][gnb_Ct]
+    const float* gnb_gamma; const float* gnb_beta;    // [gnb_Ct]
+    int gnb_Ct, gnb_coff, gnb_silu;
+    double* gnb_sum;             // [B][gnb_Ct][2] += (sum dyhat, sum dyhat*yhat)
     unsigned long long* trace;   // profiling only: per-launch phase cycle sums [prologue, staging, k-loop, epilogue, stats, workgroups], or nullptr
     int dbg;              // ablation switches for profiling (0 in production): 1 skip MFMAs, 2 skip re-staging, 4 skip LDS A reads, 8 skip B loads, 16 skip epilogue global traffic
 };

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void blur_rows_kernel(const float* __restrict_
                                                        int ntaps, int rows, int W, int sign, int mode,
                                                        const float* __restrict__ aux, const float* __restrict__ coef, int rows_per_image) {
     extern __shared__ float s_line[];            // [rows_here][W + 2r] then the taps
-    const int r = ntaps / 2, LW = W + 2 * r;
+    const int r = ntaps / 2, LW = W + 2 * r + 4;           // 4 extra samples: the 4-output sliding window reads up to line[W + r + 2]
     const int rows_here = min((int)blockDim.y, rows - (int)blockIdx.x * (int)blockDim.y);
     float* s_g = s_line + blockDim.y * LW;
     const int tid = threadIdx.y * blockDim.x + threadIdx.x, nthr = blockDim.x * blockDim.y;
@@ -147,16 +147,37 @@ __global__ __launch_bounds__(256) void blur_rows_kernel(const float* __restrict_
     const size_t grow = row0 + threadIdx.y;
     const int b = (int)(grow / rows_per_image);
     const float* line = s_line + threadIdx.y * LW + r;       // line[x] = in[row][x], valid for x in [-r, W + r)
-    for (int px = threadIdx.x; px < W; px += blockDim.x) {
-        float acc = 0.f;
-        // out[px] = sum_k g[k] * in[(px - sign*(k - r)) mod W]
-        if (sign > 0) { for (int k = 0; k < ntaps; ++k) acc = fmaf(s_g[k], line[px - (k - r)], acc); }
-        else          { for (int k = 0; k < ntaps; ++k) acc = fmaf(s_g[k], line[px + (k - r)], acc); }
-        const size_t o = grow * W + px;
-        if (mode == 1) acc = acc - aux[o];
-        else if (mode == 2) acc = aux[o] - coef[b] * acc;
-        else if (mode == 3) acc = (acc - aux[o]) > 0.f ? 1.f : -1.f;
-        out[o] = acc;
+    // each thread filters 4 consecutive outputs with a sliding window: one LDS read feeds 4 multiply-adds (the tap order per
+    // output is unchanged: k ascending)
+    for (int px = threadIdx.x * 4; px < W; px += blockDim.x * 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (sign > 0) {
+            // out[px + j] = sum_k g[k] * line[px + j - (k - r)]: window w[j] = line[px + j + r - k]
+            float w1 = line[px + 1 + r], w2 = line[px + 2 + r], w3 = line[px + 3 + r];
+            for (int k = 0; k < ntaps; ++k) {
+                const float w0 = line[px + r - k], gk = s_g[k];
+                acc[0] = fmaf(gk, w0, acc[0]); acc[1] = fmaf(gk, w1, acc[1]); acc[2] = fmaf(gk, w2, acc[2]); acc[3] = fmaf(gk, w3, acc[3]);
+                w3 = w2; w2 = w1; w1 = w0;
+            }
+        } else {
+            // out[px + j] = sum_k g[k] * line[px + j + (k - r)]: window w[j] = line[px + j - r + k]
+            float w0 = line[px - r], w1 = line[px + 1 - r], w2 = line[px + 2 - r];
+            for (int k = 0; k < ntaps; ++k) {
+                const float w3 = line[px + 3 - r + k], gk = s_g[k];
+                acc[0] = fmaf(gk, w0, acc[0]); acc[1] = fmaf(gk, w1, acc[1]); acc[2] = fmaf(gk, w2, acc[2]); acc[3] = fmaf(gk, w3, acc[3]);
+                w0 = w1; w1 = w2; w2 = w3;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (px + j >= W) break;
+            float a = acc[j];
+            const size_t o = grow * W + px + j;
+            if (mode == 1) a = a - aux[o];
+            else if (mode == 2) a = aux[o] - coef[b] * a;
+            else if (mode == 3) a = (a - aux[o]) > 0.f ? 1.f : -1.f;
+            out[o] = a;
+        }
     }
 }
 
@@ -165,7 +186,7 @@ __global__ __launch_bounds__(256) void blur_cols_kernel(const float* __restrict_
                                                        int ntaps, int H, int W, int sign, int mode,
                                                        const float* __restrict__ aux, const float* __restrict__ coef, int planes_per_image) {
     extern __shared__ float s_col[];             // [H + 2r][BL_COLS] then the taps
-    const int r = ntaps / 2, LH = H + 2 * r;
+    const int r = ntaps / 2, LH = H + 2 * r + 4;          // 4 extra rows for the 4-output sliding window
     float* s_g = s_col + LH * BL_COLS;
     const int tid = threadIdx.x;
     for (int k = tid; k < ntaps; k += 256) s_g[k] = taps[k];
@@ -180,16 +201,35 @@ __global__ __launch_bounds__(256) void blur_cols_kernel(const float* __restrict_
     const int b = plane / planes_per_image;
     const int cx = tid % BL_COLS;
     if (x0 + cx >= W) return;
-    for (int py = tid / BL_COLS; py < H; py += 256 / BL_COLS) {
+    // 4 consecutive rows per thread, sliding window down the staged column (one LDS read per tap feeds 4 multiply-adds)
+    for (int py = (tid / BL_COLS) * 4; py < H; py += (256 / BL_COLS) * 4) {
         const float* col = s_col + (py + r) * BL_COLS + cx;       // col[d * BL_COLS] = in[py + d][x]
-        float acc = 0.f;
-        if (sign > 0) { for (int k = 0; k < ntaps; ++k) acc = fmaf(s_g[k], col[-(k - r) * BL_COLS], acc); }
-        else          { for (int k = 0; k < ntaps; ++k) acc = fmaf(s_g[k], col[(k - r) * BL_COLS], acc); }
-        const size_t o = ((size_t)plane * H + py) * W + x0 + cx;
-        if (mode == 1) acc = acc - aux[o];
-        else if (mode == 2) acc = aux[o] - coef[b] * acc;
-        else if (mode == 3) acc = (acc - aux[o]) > 0.f ? 1.f : -1.f;
-        out[o] = acc;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (sign > 0) {
+            float w1 = col[(1 + r) * BL_COLS], w2 = col[(2 + r) * BL_COLS], w3 = col[(3 + r) * BL_COLS];
+            for (int k = 0; k < ntaps; ++k) {
+                const float w0 = col[(r - k) * BL_COLS], gk = s_g[k];
+                acc[0] = fmaf(gk, w0, acc[0]); acc[1] = fmaf(gk, w1, acc[1]); acc[2] = fmaf(gk, w2, acc[2]); acc[3] = fmaf(gk, w3, acc[3]);
+                w3 = w2; w2 = w1; w1 = w0;
+            }
+        } else {
+            float w0 = col[(-r) * BL_COLS], w1 = col[(1 - r) * BL_COLS], w2 = col[(2 - r) * BL_COLS];
+            for (int k = 0; k < ntaps; ++k) {
+                const float w3 = col[(3 - r + k) * BL_COLS], gk = s_g[k];
+                acc[0] = fmaf(gk, w0, acc[0]); acc[1] = fmaf(gk, w1, acc[1]); acc[2] = fmaf(gk, w2, acc[2]); acc[3] = fmaf(gk, w3, acc[3]);
+                w0 = w1; w1 = w2; w2 = w3;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (py + j >= H) break;
+            float a = acc[j];
+            const size_t o = ((size_t)plane * H + py + j) * W + x0 + cx;
+            if (mode == 1) a = a - aux[o];
+            else if (mode == 2) a = aux[o] - coef[b] * a;
+            else if (mode == 3) a = (a - aux[o]) > 0.f ? 1.f : -1.f;
+            out[o] = a;
+        }
     }
 }
 
@@ -209,10 +249,10 @@ static hipError_t blur2(const DegView& d, const float* in, float* tmp, float* ou
     const int r = d.ntaps / 2;
     // rows: 64-wide row groups, 256 threads per workgroup
     const int tx = 64, ty = 4, rows = B * C * H;
-    const size_t lds_r = ((size_t)ty * (W + 2 * r) + 128) * sizeof(float);
+    const size_t lds_r = ((size_t)ty * (W + 2 * r + 4) + 128) * sizeof(float);
     hipLaunchKernelGGL(blur_rows_kernel, dim3((rows + ty - 1) / ty), dim3(tx, ty), lds_r, s, in, tmp, d.taps, d.ntaps, rows, W, sign, 0,
                        (const float*)nullptr, (const float*)nullptr, C * H);
-    const size_t lds_c = ((size_t)(H + 2 * r) * BL_COLS + 128) * sizeof(float);
+    const size_t lds_c = ((size_t)(H + 2 * r + 4) * BL_COLS + 128) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(blur_cols_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -126,6 +126,68 @@ class RandomInpainting(Degradation):
         return self._apply(x, True)
 
 
+def paintbrush_masks(B, H, W):
+    """Keep-masks (1 = observed) of pnpflow/utils.py:339-350 + MaskGenerator._generate_mask (:904-924) for a batch of B images:
+    `random.seed(42)`, then per image 10 strokes with endpoints randint(W//2-30, W//2+30) x randint(H//2-30, H//2+30) and
+    thickness randint(8, int((W+H)*0.08)) - Python's own Mersenne-Twister sequence, so endpoints and thicknesses ARE the
+    reference's.  The reference rasterises each stroke with cv2.line (thick line = filled rectangle + round caps, OpenCV's
+    fixed-point polygon fill); cv2 is not available here, so a stroke is rasterised as the capsule it approximates: pixel
+    centres within thickness/2 of the segment.  Edge pixels of a stroke may differ from OpenCV's by one pixel: PARITY UNPINNED."""
+    import random
+    if W < 64 or H < 64:
+        raise Exception("Width and Height of mask must be at least 64!")
+    rng = random.Random(42)
+    size = int((W + H) * 0.08)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    out = np.ones((B, H, W), dtype=np.uint8)
+    for b in range(B):
+        for _ in range(10):
+            x1, x2 = rng.randint(W // 2 - 30, W // 2 + 30), rng.randint(W // 2 - 30, W // 2 + 30)
+            y1, y2 = rng.randint(H // 2 - 30, H // 2 + 30), rng.randint(H // 2 - 30, H // 2 + 30)
+            t = rng.randint(8, size)
+            dx, dy = x2 - x1, y2 - y1
+            L2 = dx * dx + dy * dy
+            u = np.clip(((xx - x1) * dx + (yy - y1) * dy) / L2, 0.0, 1.0) if L2 > 0 else np.zeros_like(xx)
+            d2 = (xx - (x1 + u * dx)) ** 2 + (yy - (y1 + u * dy)) ** 2
+            out[b][d2 <= (t / 2.0) ** 2] = 0
+    return out
+
+
+class PaintbrushInpainting(Degradation):
+    """reference pnpflow/degradations.py:47-52 (mask: utils.py:339-350, 904-924).  H = H_adj = mask * x with the seeded
+    brush-stroke masks, generated once per (global batch, H, W) and sliced for multi-GPU shards (the stroke sequence is
+    prefix-consistent in the batch index).  Stroke rasterisation: see `paintbrush_masks` (parity unpinned without cv2)."""
+    kind = _lib.PF_DEG_MASK_INPAINTING
+
+    def __init__(self, global_batch=None, batch_offset=0):
+        super().__init__()
+        self.global_batch, self.batch_offset = global_batch, batch_offset
+        self._cache = {}
+
+    def set_shard(self, global_batch, batch_offset):
+        if (global_batch, batch_offset) != (self.global_batch, self.batch_offset):
+            self.global_batch, self.batch_offset = global_batch, batch_offset
+            self._cache = {}
+
+    def mask(self, B, H, W, device):
+        key = (B, H, W, str(device))
+        if key not in self._cache:
+            m = paintbrush_masks(self.batch_offset + B, H, W)[self.batch_offset:self.batch_offset + B]
+            self._cache[key] = torch.from_numpy(np.ascontiguousarray(m)).to(device)
+        return self._cache[key]
+
+    def descriptor(self, B, H, W, device):
+        d = _lib.PfDegradation(); d.kind = self.kind
+        d.mask = self.mask(B, H, W, device).data_ptr()
+        return d
+
+    def H(self, x):
+        return self._apply(x, False)
+
+    def H_adj(self, x):
+        return self._apply(x, True)
+
+
 class GaussianDeblurring(Degradation):
     """reference pnpflow/degradations.py:55-89, mode 'fft': circular convolution with the
     61x61 normalised Gaussian (utils.py:273-280).  The kernel is exactly separable, so the

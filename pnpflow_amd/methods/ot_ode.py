@@ -64,7 +64,7 @@ class OT_ODE(object):
         iterations in `cb_iterations` (None = every iteration)."""
         args = self.args
         problem = args.problem
-        if problem not in ("denoising", "inpainting", "random_inpainting", "superresolution", "gaussian_deblurring_FFT"):
+        if problem not in ("denoising", "inpainting", "random_inpainting", "paintbrush_inpainting", "superresolution", "gaussian_deblurring_FFT"):
             # the reference's remaining branch is a per-image GMRES on H H^T (ot_ode.py:118-128); none of its operators reach it
             raise NotImplementedError(f"ot_ode linear solve for '{problem}' is not implemented by this engine")
         steps, delta = int(args.steps_ode), 1 / args.steps_ode

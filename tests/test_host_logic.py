@@ -248,3 +248,23 @@ def test_operator_attributes_of_the_reference_api(golden=None):
     m = D.Superresolution(2, 8).downsampling_matrix
     x = torch.arange(64.0)
     assert torch.equal(m @ x, x.view(8, 8)[::2, ::2].reshape(-1)) and torch.equal(torch.diag(m @ m.T), torch.ones(16))
+
+
+def test_paintbrush_masks_are_seeded_prefix_consistent_and_match_the_oracle():
+    """PaintbrushInpainting (degradations.py:47-52): the stroke parameters come from Python's random.seed(42) sequence exactly as
+    in the reference (utils.py:904-924); image i's mask does not depend on the batch size (shards slice the global batch).
+    Rasterisation is a restatement of cv2.line's capsule (parity unpinned: cv2 absent) - product and oracle implement it
+    independently (vectorised vs per row)."""
+    import random
+    from oracle import pnpflow_oracle as O
+    from pnpflow_amd.degradations import paintbrush_masks
+    m4 = paintbrush_masks(4, 64, 96)
+    assert m4.shape == (4, 64, 96) and set(np.unique(m4)) <= {0, 1} and 0.02 < (m4 == 0).mean() < 0.6
+    np.testing.assert_array_equal(paintbrush_masks(2, 64, 96), m4[:2])
+    np.testing.assert_array_equal(O.paintbrush_mask_array(3, 64, 96), m4[:3])
+    # the first stroke of the reference's sequence: endpoints / thickness from random.seed(42)
+    rng = random.Random(42)
+    x1, x2 = rng.randint(48 - 30, 48 + 30), rng.randint(48 - 30, 48 + 30); y1, y2 = rng.randint(32 - 30, 32 + 30), rng.randint(32 - 30, 32 + 30)
+    assert m4[0, min(max(y1, 0), 63), min(max(x1, 0), 95)] == 0 and m4[0, min(max(y2, 0), 63), min(max(x2, 0), 95)] == 0
+    with pytest.raises(Exception):
+        paintbrush_masks(1, 32, 32)

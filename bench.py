@@ -336,19 +336,29 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary BASELINE configs and the pointwise block (N=1 default runs include them)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--batch", type=int, default=0, help="override the workload's batch per GPU (tests)")
     ap.add_argument("--precision", type=int, default=1, choices=[0, 1],
                     help="1 (default): fp32-equivalent split-fp16 MFMA (3 x f16 MFMA per product); 0: exact fp32 MFMA")
     a = ap.parse_args()
+    if a.batch > 0:
+        WORKLOADS[a.workload] = dict(WORKLOADS[a.workload], B=a.batch)
     wl = WORKLOADS[a.workload]
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # one process per GPU over RCCL ("nccl" on ROCm).  Functional tests on a 1-GPU box run the SAME rank logic with every rank
+    # on device PNPFLOW_FORCE_DEVICE and the collectives on gloo (PNPFLOW_DIST_BACKEND=gloo; tensors staged through the host)
+    backend = os.environ.get("PNPFLOW_DIST_BACKEND", "nccl")
+    local = int(os.environ.get("PNPFLOW_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    comm = (lambda t: t) if backend == "nccl" else (lambda t: t.cpu())
 
     import pnpflow_amd.degradations as D
     from pnpflow_amd.utils import psnr_per_image
@@ -373,13 +383,14 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = comm(torch.tensor([dt], device=dev, dtype=torch.float64))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     # the ONE data-path collective: per-image PSNR gathered in global image order
     psnr = psnr_per_image(x, r.clean)
     if world > 1:
+        psnr = comm(psnr)
         allp = [torch.empty_like(psnr) for _ in range(world)]
         dist.all_gather(allp, psnr)
         psnr = torch.cat(allp)

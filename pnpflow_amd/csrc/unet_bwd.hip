@@ -111,9 +111,13 @@ __global__ __launch_bounds__(256) void gn_bwd_coeffs_kernel(const double* bsum, 
 }
 
 // ---- stage B: out (=|+=) rs * (dyhat - m1 - yhat*m2) (+ add) -----------------------------------
-__global__ __launch_bounds__(256) void gn_bwd_post_kernel(const float* dy, const float* x, const float* mu, const float* rs, const float* m1,
-                                                          const float* m2, const float* add, float* out, int HW, int C, int coff, int Ct,
-                                                          int accumulate, int pix_per_block) {
+// (HAS_ADD / ACC are compile-time: a load inside a run-time branch makes hipcc wait for it on the spot - vmcnt(0) - which
+// serialised the 8-16 loads a thread keeps in flight; profiles/r02_kernel_trace_bench_c5.md: 3.2 TB/s before)
+template <bool HAS_ADD, bool ACC>
+__global__ __launch_bounds__(256) void gn_bwd_post_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mu,
+                                                          const float* __restrict__ rs, const float* __restrict__ m1, const float* __restrict__ m2,
+                                                          const float* __restrict__ add, float* out, int HW, int C, int coff, int Ct,
+                                                          int pix_per_block) {
     const int b = blockIdx.y, tid = threadIdx.x;
     const int cq = C / 4, lanes_p = 256 / cq;
     const int q = tid % cq, pr = tid / cq;
@@ -133,8 +137,8 @@ __global__ __launch_bounds__(256) void gn_bwd_post_kernel(const float* dy, const
             const size_t o = ((size_t)b * HW + pk) * C + q * 4;
             xv[k] = *reinterpret_cast<const float4*>(x + o);
             dv[k] = *reinterpret_cast<const float4*>(dy + o);
-            if (add != nullptr) av[k] = *reinterpret_cast<const float4*>(add + o);
-            if (accumulate) ov[k] = *reinterpret_cast<const float4*>(out + o);
+            if constexpr (HAS_ADD) av[k] = *reinterpret_cast<const float4*>(add + o);
+            if constexpr (ACC) ov[k] = *reinterpret_cast<const float4*>(out + o);
         }
 #pragma unroll
         for (int k = 0; k < UNR; ++k) {
@@ -144,8 +148,8 @@ __global__ __launch_bounds__(256) void gn_bwd_post_kernel(const float* dy, const
                 r.y = r4.y * (dv[k].y - a4.y - (xv[k].y - m4.y) * r4.y * b4.y);
                 r.z = r4.z * (dv[k].z - a4.z - (xv[k].z - m4.z) * r4.z * b4.z);
                 r.w = r4.w * (dv[k].w - a4.w - (xv[k].w - m4.w) * r4.w * b4.w);
-                if (add != nullptr) { r.x += av[k].x; r.y += av[k].y; r.z += av[k].z; r.w += av[k].w; }
-                if (accumulate) { r.x += ov[k].x; r.y += ov[k].y; r.z += ov[k].z; r.w += ov[k].w; }
+                if constexpr (HAS_ADD) { r.x += av[k].x; r.y += av[k].y; r.z += av[k].z; r.w += av[k].w; }
+                if constexpr (ACC) { r.x += ov[k].x; r.y += ov[k].y; r.z += ov[k].z; r.w += ov[k].w; }
                 *reinterpret_cast<float4*>(out + ((size_t)b * HW + pix + k * lanes_p) * C + q * 4) = r;
             }
         }
@@ -173,8 +177,11 @@ hipError_t launch_gn_bwd_post(const float* dy, const float* x, const float* mu, 
                               const float* add, float* out, int B, int HW, int C, int coff, int Ct, int accumulate, hipStream_t s) {
     if (C % 4 || C / 4 > 256) return hipErrorInvalidValue;
     const int ppb = 1024;
-    hipLaunchKernelGGL(gn_bwd_post_kernel, dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, s, dy, x, mu, rs, m1, m2,
-                       add, out, HW, C, coff, Ct, accumulate, ppb);
+    const dim3 grid((HW + ppb - 1) / ppb, B);
+    if (add != nullptr && accumulate) hipLaunchKernelGGL((gn_bwd_post_kernel<true, true>), grid, dim3(256), 0, s, dy, x, mu, rs, m1, m2, add, out, HW, C, coff, Ct, ppb);
+    else if (add != nullptr) hipLaunchKernelGGL((gn_bwd_post_kernel<true, false>), grid, dim3(256), 0, s, dy, x, mu, rs, m1, m2, add, out, HW, C, coff, Ct, ppb);
+    else if (accumulate) hipLaunchKernelGGL((gn_bwd_post_kernel<false, true>), grid, dim3(256), 0, s, dy, x, mu, rs, m1, m2, add, out, HW, C, coff, Ct, ppb);
+    else hipLaunchKernelGGL((gn_bwd_post_kernel<false, false>), grid, dim3(256), 0, s, dy, x, mu, rs, m1, m2, add, out, HW, C, coff, Ct, ppb);
     return hipGetLastError();
 }
 

@@ -33,14 +33,19 @@ def init_from_env(device_index=None):
     import os
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0")) if device_index is None else device_index
+    rank = int(os.environ.get("RANK", "0"))
+    # PNPFLOW_FORCE_DEVICE / PNPFLOW_DIST_BACKEND=gloo: functional runs of the N > 1 path on a 1-GPU box (every rank on one device,
+    # collectives staged through the host)
+    local = int(os.environ.get("PNPFLOW_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0"))) if device_index is None else device_index
+    backend = os.environ.get("PNPFLOW_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if torch.cuda.is_available():
-            torch.cuda.set_device(local)
+        if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
 
 
@@ -72,6 +77,8 @@ def gather_in_image_order(local: torch.Tensor, group=None) -> torch.Tensor:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo" and local.is_cuda:      # gloo collectives run on host tensors
+        return gather_in_image_order(local.cpu(), group).to(local.device)
     n = torch.tensor([local.numel()], device=local.device, dtype=torch.int64)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)

@@ -896,3 +896,55 @@ def test_fused_bias_act_matches_reference_and_oracle(hip, golden):
     np.testing.assert_allclose(fused_bias_act(x.cuda(), None, None, 3, 0, 0.2, 1.0).cpu().numpy(), O.fused_bias_act(x, None, None, 3, 0, 0.2, 1.0).numpy(), atol=1e-6)
     m = FusedLeakyReLU(8)
     np.testing.assert_allclose(m(x.cuda()).cpu().numpy(), O.fused_leaky_relu(x, torch.zeros(8)).numpy(), atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# the N > 1 path, executed: two ranks (torchrun) sharing this box's one GPU, collectives on gloo
+# ---------------------------------------------------------------------------------------------
+def _torchrun(script_args, nproc, extra_env=None):
+    import json, os, socket, subprocess, sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PNPFLOW_DIST_BACKEND="gloo", PNPFLOW_FORCE_DEVICE="0", MASTER_ADDR="127.0.0.1", **(extra_env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + script_args
+    if nproc == 1:
+        cmd = [sys.executable] + script_args
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return out.stdout
+
+
+def test_bench_two_ranks_reproduce_the_single_process_run(hip):
+    """bench.py launched exactly as the driver launches it for N = 2 (python -m torch.distributed.run ... bench.py --gpus 2): the
+    two ranks restore contiguous halves of a 4-image global batch (global-draw slices, Philox element offset, one gather of
+    per-image PSNR); the global PSNR equals the single-process run at batch 4."""
+    import json
+    args = ["bench.py", "--workload", "tiny", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extra"]
+    two = json.loads(_torchrun(args + ["--gpus", "2", "--batch", "2"], 2).strip().splitlines()[-1])
+    one = json.loads(_torchrun(args + ["--gpus", "1", "--batch", "4"], 1).strip().splitlines()[-1])
+    assert two["n_gpus"] == 2 and two["config"]["global_batch"] == 4 and one["config"]["global_batch"] == 4
+    assert two["scaling"] == "weak" and two["value"] > 0
+    assert abs(two["psnr_db"] - one["psnr_db"]) < 2e-3, (two["psnr_db"], one["psnr_db"])
+
+
+def test_main_two_ranks_write_the_single_process_result_files(hip, tmp_path):
+    """main.py under torchrun (synthetic opt-in: no checkpoint / dataset offline): rank 0 writes the reference's result files
+    for the GLOBAL batches, equal (PSNR to 1e-3 dB) to the single-process run's."""
+    import os
+    outs = {}
+    for n in (1, 2):
+        root = str(tmp_path / f"n{n}") + "/"
+        os.makedirs(root)
+        opts = ["main.py", "--opts", "dataset", "celeba", "problem", "random_inpainting", "method", "pnp_flow", "synthetic", "True", "max_batch", "2",
+                "batch_size_ip", "4", "steps_pnp", "10", "num_samples", "2", "output_root", root, "compute_time", "True"]
+        _torchrun(opts, n)
+        base = os.path.join(root, "results_synthetic", "celeba", "ot", "random_inpainting", "pnp_flow", "test")
+        sub = [d for d, _, f in os.walk(base) if "psnr_rec_batch1.txt" in f]
+        assert len(sub) == 1, list(os.walk(base))
+        outs[n] = {f: open(os.path.join(sub[0], f)).read() for f in ("psnr_rec_batch0.txt", "psnr_rec_batch1.txt", "psnr_noisy_batch1.txt", "psnr_rec_average.txt")}
+        assert os.path.isfile(os.path.join(base, "final_psnr.txt")) and os.path.isfile(os.path.join(sub[0], "time_average.txt"))
+    for f in outs[1]:
+        a = [l.split() for l in outs[1][f].strip().splitlines()]; b = [l.split() for l in outs[2][f].strip().splitlines()]
+        assert [x[0] for x in a] == [x[0] for x in b], f
+        assert max(abs(float(x[1]) - float(y[1])) for x, y in zip(a, b)) < 1e-3, (f, a, b)

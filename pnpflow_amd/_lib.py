@@ -127,3 +127,33 @@ def check(rc: int, engine=None, what: str = ""):
 def current_stream_ptr():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class solver_stream:
+    """Context for the solver loops: the engine captures one hipGraph per iteration, which the legacy NULL stream cannot do, and
+    the host callbacks of a loop (metrics: torch ops + pf_psnr / pf_ssim) must be ORDERED with the engine's own launches.  When
+    torch's current stream is the NULL stream, this switches torch to a side stream for the duration of the call - the engine
+    and every callback then enqueue on that one stream - and joins it with the caller's stream on both sides.
+    (Round 2: with the engine on a private non-blocking stream and the metric callbacks on the NULL stream, a second batch replaying
+    the cached graph produced NaNs after a few logged iterations; single-stream ordering removes the hazard class.)"""
+    _side = {}
+
+    def __enter__(self):
+        import torch
+        self.cur = torch.cuda.current_stream()
+        self.ctx = None
+        if self.cur.cuda_stream == 0:
+            dev = torch.cuda.current_device()
+            if dev not in solver_stream._side:
+                solver_stream._side[dev] = torch.cuda.Stream(device=dev)
+            self.side = solver_stream._side[dev]
+            self.side.wait_stream(self.cur)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            self.cur.wait_stream(self.side)
+        return False

@@ -396,7 +396,7 @@ static ConvParams with_coef(Builder& bd, ConvParams p, std::vector<Op>& ops) {
     g.nseg = p.nseg;
     for (int i = 0; i < p.nseg; ++i) { g.st[i] = p.seg[i].stats; g.C[i] = p.seg[i].C; g.xform[i] = p.seg[i].xform; g.gn_off[i] = p.seg[i].gn_off; }
     g.gn_C = p.gn_C; g.gn_cpg = p.gn_cpg; g.HW = p.Hs * p.Ws; g.eps = p.gn_eps; g.gamma = p.gamma; g.beta = p.beta;
-    g.coef = plan->coef; g.coef_stride = Plan::COEF_STRIDE; g.scale = want_scale ? plan->scale : nullptr; g.flags = plan->flags;
+    g.coef = plan->coef; g.coef_stride = Plan::COEF_STRIDE; g.scale = want_scale ? plan->scale : nullptr; g.flags = plan->flags; g.id = (int)ops.size();
     ops.push_back(op);
     p.coef = plan->coef; p.coef_stride = Plan::COEF_STRIDE; p.scale = want_scale ? plan->scale : nullptr;
     return p;
@@ -1145,16 +1145,24 @@ int pf_engine_create(int device_id, const pf_unet_cfg* cfg, pf_engine** out) {
 
 // reads (and clears) the numeric-health flags of every plan; the caller has synchronised the stream(s) that ran them
 static int check_flags(pf_engine* e) {
-    bool bad = false;
+    bool bad = false; std::string where;
     for (auto& kv : e->plans) {
         Plan* pl = kv.second.get();
         if (!pl->flags) continue;
-        unsigned int f = 0;
-        HIPCHK(e, hipMemcpy(&f, pl->flags, sizeof f, hipMemcpyDeviceToHost));
-        if (f) { bad = true; HIPCHK(e, hipMemset(pl->flags, 0, sizeof f)); }
+        unsigned int f[2] = {0, 0};
+        HIPCHK(e, hipMemcpy(f, pl->flags, sizeof f, hipMemcpyDeviceToHost));
+        if (f[0]) {
+            bad = true; HIPCHK(e, hipMemset(pl->flags, 0, sizeof f));
+            char buf[160] = "";
+            const int id = (int)f[1];                 // the op that follows the flagging finalisation is the consuming conv
+            if (id >= 1 && id < (int)pl->ops.size() && pl->ops[id].kind == OP_CONV)
+                snprintf(buf, sizeof buf, " (first seen by launch #%d of the B=%d plan: %dx%d, K segments %d, Cout %d)", id, pl->B, pl->ops[id].cp.H,
+                         pl->ops[id].cp.W, pl->ops[id].cp.nseg, pl->ops[id].cp.Cout);
+            where = buf;
+        }
     }
     if (bad) {
-        e->err = "non-finite activation statistics: an activation overflowed or was NaN inside the U-Net (inputs / weights out of range)";
+        e->err = "non-finite activation statistics: an activation overflowed or was NaN inside the U-Net (inputs / weights out of range)" + where;
         return PF_ERR_NUMERIC;
     }
     return PF_OK;
@@ -1471,9 +1479,12 @@ int pf_pnp_flow_restore(pf_engine* e, const pf_degradation* d, const pf_pnp_para
     USE_DEVICE(e);
     hipStream_t s = (hipStream_t)stream;
     if (prm->use_graph && s == nullptr) {
-        // the legacy NULL stream cannot be captured: run on an engine-owned stream, ordered after
-        // everything already enqueued on the NULL stream (the function synchronises before returning)
-        if (!e->work_stream) HIPCHK(e, hipStreamCreateWithFlags(&e->work_stream, hipStreamNonBlocking));
+        // the legacy NULL stream cannot be captured: run on an engine-owned stream, ordered after everything already
+        // enqueued on the NULL stream (the function synchronises before returning).  The stream is a BLOCKING one
+        // (hipStreamDefault): work a callback puts on the NULL stream and the engine's next launches stay ordered by the
+        // legacy-stream rule (round 2: on a non-blocking stream, metric kernels launched from the callbacks on the NULL
+        // stream and cached-graph replays produced NaNs on the second batch; the Python solvers also hand over a real stream)
+        if (!e->work_stream) HIPCHK(e, hipStreamCreateWithFlags(&e->work_stream, hipStreamDefault));
         HIPCHK(e, hipStreamSynchronize(nullptr));
         s = e->work_stream;
     }
@@ -1615,7 +1626,7 @@ int pf_ot_ode_restore(pf_engine* e, const pf_degradation* d, const pf_ot_ode_par
     USE_DEVICE(e);
     hipStream_t s = (hipStream_t)stream;
     if (prm->use_graph && s == nullptr) {
-        if (!e->work_stream) HIPCHK(e, hipStreamCreateWithFlags(&e->work_stream, hipStreamNonBlocking));
+        if (!e->work_stream) HIPCHK(e, hipStreamCreateWithFlags(&e->work_stream, hipStreamDefault));
         HIPCHK(e, hipStreamSynchronize(nullptr));
         s = e->work_stream;
     }

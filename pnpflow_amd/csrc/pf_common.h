@@ -105,7 +105,8 @@ struct GnCoefParams {
     const float* gamma; const float* beta;
     float* coef; int coef_stride;    // see ConvParams::coef (written only when gn_C > 0)
     float* scale;                    // [B][8] (s of segment 0..2, pad, 1/s of segment 0..2, pad), or nullptr
-    unsigned int* flags;             // bit 0 is set when a statistic is not finite (an activation overflowed / NaN upstream)
+    unsigned int* flags;             // [0] bit 0 is set when a statistic is not finite (an activation overflowed / NaN upstream); [1] = id + 1 of the first launch that saw it
+    int id;                          // index of the consuming conv in the plan (diagnostics)
 };
 hipError_t launch_gn_coef(const GnCoefParams& p, int B, hipStream_t s);
 

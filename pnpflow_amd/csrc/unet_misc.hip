@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void gn_coef_kernel(const GnCoefParams p) {
     }
     __syncthreads();
     if (tid == 0) {
-        if (s_bad && p.flags != nullptr) atomicOr(p.flags, 1u);
+        if (s_bad && p.flags != nullptr) { atomicOr(p.flags, 1u); atomicCAS(p.flags + 1, 0u, (unsigned)(p.id + 1)); }
         if (p.scale != nullptr) {
             auto pow2_for = [](double ms) {            // power of two s with s*rms in [0.5, 1) when rms is outside [1/4, 64]; else 1
                 float s = 1.0f;

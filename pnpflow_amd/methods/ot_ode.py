@@ -106,8 +106,9 @@ class OT_ODE(object):
                 prm.host_cb_mask = mask.ctypes.data
         else:
             cb = C.cast(None, _lib.ITER_CB)
-        _lib.check(self.lib.pf_ot_ode_restore(self.model.handle, C.byref(d), C.byref(prm), y.data_ptr(), x.data_ptr(), B,
-                                              _lib.current_stream_ptr(), cb, None), self.model.handle, "pf_ot_ode_restore")
+        with _lib.solver_stream():       # engine launches and metric callbacks on ONE stream (a real one: graph capture)
+            _lib.check(self.lib.pf_ot_ode_restore(self.model.handle, C.byref(d), C.byref(prm), y.data_ptr(), x.data_ptr(), B,
+                                                  _lib.current_stream_ptr(), cb, None), self.model.handle, "pf_ot_ode_restore")
         if holder["err"] is not None:
             raise holder["err"]
         return x

@@ -140,8 +140,9 @@ class PNP_FLOW(object):
         else:
             cb = C.cast(None, _lib.ITER_CB)
         holder["cb"] = cb
-        _lib.check(self.lib.pf_pnp_flow_restore(self.model.handle, C.byref(d), C.byref(prm), y.data_ptr(), x.data_ptr(), B,
-                                                _lib.current_stream_ptr(), cb, None), self.model.handle, "pf_pnp_flow_restore")
+        with _lib.solver_stream():       # engine launches and metric callbacks on ONE stream (a real one: graph capture)
+            _lib.check(self.lib.pf_pnp_flow_restore(self.model.handle, C.byref(d), C.byref(prm), y.data_ptr(), x.data_ptr(), B,
+                                                    _lib.current_stream_ptr(), cb, None), self.model.handle, "pf_pnp_flow_restore")
         if holder["err"] is not None:
             raise holder["err"]
         return x

@@ -142,7 +142,8 @@ FWD_FLOPS = {128: 49.78e9, 256: 189.44e9}      # algorithmic FLOP per image per 
 # HBM bytes per conv-GEMM launch measured with rocprofv3 --pmc (FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled as
 # MI355X_MICROARCH.md prescribes for gfx950): {workload: (bytes per launch, committed summary it comes from)}
 TRAFFIC = {
-    "c2": (478.7e6, "profiles/r01_pmc_hbm_traffic_forward_c2_fused.md"),
+    "c2": (473.5e6, "profiles/r02_pmc_fwd_c2_{FETCH,WRITE}_SIZE.md (142 conv launches per forward of 160 images)"),
+    "c4": (1082.9e6, "profiles/r02_pmc_fwd_c4_{FETCH,WRITE}_SIZE.md (116 conv launches per forward of 80 images at 256^2)"),
 }
 
 

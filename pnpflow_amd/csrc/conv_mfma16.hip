@@ -283,6 +283,12 @@ __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16
                 ah[mt] = *reinterpret_cast<const f16x8*>(s_patch + ppix * ROW + j * 8 + hi * 4);
                 al[mt] = *reinterpret_cast<const f16x8*>(s_patch + ppix * ROW + KH + j * 8 + hi * 4);
             }
+#ifndef PF_AB_NO_A_FIRST
+            // every A fragment of the k-step is requested before its first MFMA (the MFMAs then wait with counted lgkmcnt):
+            // left alone hipcc recycles ONE register quad for the four low-half fragments and emits ds_read -> lgkmcnt(0) -> MFMA
+            // four times per k-step.  Not on the 8x16x128 tile, where the extra live fragments spill at its 168-register bound.
+            if constexpr (!(MT == 4 && WM == 1)) __builtin_amdgcn_sched_barrier(0);
+#endif
             if (PF_DBG(1)) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(ah[mt]), "v"(al[mt]));

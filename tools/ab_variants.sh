@@ -8,9 +8,7 @@ if [ "$1" = "build" ]; then
   mkdir -p gpurun_out/ab
   build() { /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-result -Wno-unused-value $2 -o pnpflow_amd/libpnpflow_hip_ab_$1.so $(for f in $SRC; do echo pnpflow_amd/csrc/$f; done) & }
   build cur ""
-  build gnk "-DPF_AB_GN_INKERNEL"
-  build nors "-DPF_AB_NO_RESCALE"
-  build r1 "-DPF_AB_GN_INKERNEL -DPF_AB_NO_RESCALE"
+  build noaf "-DPF_AB_NO_A_FIRST"
   wait
   ls -la pnpflow_amd/libpnpflow_hip_ab_*.so
   exit 0
@@ -18,11 +16,6 @@ fi
 DIM=${2:-128}; NB=${3:-160}; R=${4:-3}
 run() { echo -n "$1 "; env PNPFLOW_HIP_LIB=$PWD/pnpflow_amd/libpnpflow_hip_ab_$2.so $3 timeout 180 python tools/gpu_forward_only.py $DIM $NB 8 | tail -1; }
 for i in $(seq $R); do
-  run "cur            " cur ""
-  run "r1-equivalent  " r1 "PNPFLOW_HIP_AB_NO_COEF=1"
-  run "gn-in-kernel   " gnk "PNPFLOW_HIP_AB_NO_COEF=1"
-  run "no-rescale     " nors ""
-  run "cur MIN_WGS1024" cur "PNPFLOW_HIP_MIN_WGS=1024"
-  run "cur KC_L1=16   " cur "PNPFLOW_HIP_KC_L1=16"
-  run "nors MINWGS1024" nors "PNPFLOW_HIP_MIN_WGS=1024"
+  run "cur (A first)  " cur ""
+  run "no A first     " noaf ""
 done

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 2
+#define PF_ABI_VERSION 3
 
 typedef enum pf_status {
     PF_OK = 0,
@@ -53,6 +53,37 @@ typedef struct pf_unet_cfg {
     int32_t num_attn_resolutions;
     int32_t attn_resolutions[8];
 } pf_unet_cfg;
+
+
+/* ---- NCSN++ ("rectified") velocity net ----------------------------------------------------
+ * Hyper-parameters of pnpflow.image_generation.models.ncsnpp.NCSNpp.__init__ (ncsnpp.py:38-206) as the reference's two
+ * rectified-flow configs set them (configs/rectified_flow/{celeba_hq,afhq_cat}_pytorch_rf_gaussian.py:46-64): BigGAN residual
+ * blocks with FIR [1,3,3,1] resampling, input_skip / output_skip pyramids combined by `sum`, Gaussian Fourier time
+ * conditioning, skip_rescale.  Only that block list is built (resblock_type 'biggan', progressive 'output_skip',
+ * progressive_input 'input_skip', embedding 'fourier', conditional); nf must be a multiple of 32. */
+typedef struct pf_ncsnpp_cfg {
+    int32_t image_size;        /* config.data.image_size (256) */
+    int32_t num_channels;      /* config.data.num_channels (3) */
+    int32_t nf;                /* 128 */
+    int32_t num_levels;        /* len(ch_mult) (7) */
+    int32_t ch_mult[8];        /* (1,1,2,2,2,2,2) */
+    int32_t num_res_blocks;    /* 2 */
+    int32_t num_attn_resolutions;
+    int32_t attn_resolutions[8];   /* (16,) */
+    int32_t fir_taps;          /* len(fir_kernel) (4) */
+    float fir_kernel[8];       /* [1,3,3,1] */
+    int32_t skip_rescale;      /* 1 */
+    int32_t scale_by_sigma;    /* 1: the output is divided by the time label (ncsnpp.py:378-381) */
+    int32_t centered;          /* config.data.centered; 0: x -> 2x - 1 first (ncsnpp.py:248-250; not built: must be 1) */
+} pf_ncsnpp_cfg;
+
+/* replaces mutils.create_model(config) (models/utils.py:91-103).  The handle is a pf_engine: weights are loaded with
+ * pf_engine_load_weight under NCSNpp's own state_dict keys ("all_modules.<i>.<...>", without DataParallel's "module."),
+ * pf_unet_forward(e, x, labels, out, B, stream) is model(x, labels) with labels = the reference's time_cond (t * 999,
+ * methods/pnp_flow.py:23-27).  The VJP entry points return PF_ERR_INVALID for this net. */
+int pf_ncsnpp_create(int device_id, const pf_ncsnpp_cfg* cfg, pf_engine** out);
+/* label = t * scale inside pf_pnp_flow_restore / pf_ot_ode_restore (PNP_FLOW.model_forward: `t * 999`); 1 for the OT net */
+int pf_engine_set_solver_time_scale(pf_engine* e, float scale);
 
 int pf_abi_version(void);
 

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PNPFLOW_HIP_LIB") or os.path.join(_HERE, "libpnpflow_hip.so")   # override: A/B builds of the kernels
 
-PF_ABI_VERSION = 2
+PF_ABI_VERSION = 3
 
 PF_DEG_DENOISING, PF_DEG_BOX_INPAINTING, PF_DEG_MASK_INPAINTING, PF_DEG_SUPERRESOLUTION, PF_DEG_GAUSSIAN_BLUR, PF_DEG_SR_FILTERED = range(6)
 
@@ -22,6 +22,13 @@ class PfUnetCfg(C.Structure):
                 ("ch", C.c_int32), ("num_levels", C.c_int32), ("ch_mult", C.c_int32 * 8),
                 ("num_res_blocks", C.c_int32), ("num_attn_resolutions", C.c_int32),
                 ("attn_resolutions", C.c_int32 * 8)]
+
+
+class PfNcsnppCfg(C.Structure):
+    _fields_ = [("image_size", C.c_int32), ("num_channels", C.c_int32), ("nf", C.c_int32), ("num_levels", C.c_int32),
+                ("ch_mult", C.c_int32 * 8), ("num_res_blocks", C.c_int32), ("num_attn_resolutions", C.c_int32),
+                ("attn_resolutions", C.c_int32 * 8), ("fir_taps", C.c_int32), ("fir_kernel", C.c_float * 8),
+                ("skip_rescale", C.c_int32), ("scale_by_sigma", C.c_int32), ("centered", C.c_int32)]
 
 
 class PfDegradation(C.Structure):
@@ -49,6 +56,8 @@ ITER_CB = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
 SIGNATURES = {
     "pf_abi_version": (C.c_int, []),
     "pf_engine_create": (C.c_int, [C.c_int, C.POINTER(PfUnetCfg), C.POINTER(C.c_void_p)]),
+    "pf_ncsnpp_create": (C.c_int, [C.c_int, C.POINTER(PfNcsnppCfg), C.POINTER(C.c_void_p)]),
+    "pf_engine_set_solver_time_scale": (C.c_int, [C.c_void_p, C.c_float]),
     "pf_engine_destroy": (None, [C.c_void_p]),
     "pf_last_error": (C.c_char_p, [C.c_void_p]),
     "pf_engine_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),

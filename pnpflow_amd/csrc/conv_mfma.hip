@@ -267,7 +267,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
                     const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
                     if (p.residual != nullptr) {
                         const float4 rv = *reinterpret_cast<const float4*>(p.residual + pix * p.res_cstride + n4);
-                        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+                        const float rsc = p.res_scale;
+                        v.x = fmaf(rv.x, rsc, v.x); v.y = fmaf(rv.y, rsc, v.y); v.z = fmaf(rv.z, rsc, v.z); v.w = fmaf(rv.w, rsc, v.w);
                     }
                     *reinterpret_cast<float4*>(p.out + pix * p.out_cstride + n4) = v;
                     s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;

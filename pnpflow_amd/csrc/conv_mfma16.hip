@@ -401,7 +401,8 @@ __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16
                 if (nok4 && oy < p.H && ox < p.W && !(PF_DBG(16) && v.x != 1.2345f)) {
                     const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
                     if (p.residual != nullptr && !PF_DBG(32)) {
-                        v.x += rv[mt % RG][i].x; v.y += rv[mt % RG][i].y; v.z += rv[mt % RG][i].z; v.w += rv[mt % RG][i].w;
+                        const float rsc = p.res_scale;
+                        v.x = fmaf(rv[mt % RG][i].x, rsc, v.x); v.y = fmaf(rv[mt % RG][i].y, rsc, v.y); v.z = fmaf(rv[mt % RG][i].z, rsc, v.z); v.w = fmaf(rv[mt % RG][i].w, rsc, v.w);
                     }
                     if constexpr (GNB) {
                         // dyhat = da * act'(u) * gamma,  u = gamma*yhat + beta,  yhat = (x - mu)*rstd   (same expressions as gn_bwd_pre_kernel)

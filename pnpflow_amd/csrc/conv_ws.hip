@@ -274,7 +274,8 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvParams p, con
                     if (nok4 && oy < p.H && ox < p.W) {
                         const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
                         if (p.residual != nullptr) {
-                            v.x += rv[mt % RG][i].x; v.y += rv[mt % RG][i].y; v.z += rv[mt % RG][i].z; v.w += rv[mt % RG][i].w;
+                            const float rsc = p.res_scale;
+                            v.x = fmaf(rv[mt % RG][i].x, rsc, v.x); v.y = fmaf(rv[mt % RG][i].y, rsc, v.y); v.z = fmaf(rv[mt % RG][i].z, rsc, v.z); v.w = fmaf(rv[mt % RG][i].w, rsc, v.w);
                         }
                         *reinterpret_cast<float4*>(p.out + pix * p.out_cstride + n4) = v;
                         s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;

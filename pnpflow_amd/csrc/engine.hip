@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -36,6 +37,8 @@ struct LevelDesc { std::vector<ResDesc> blocks; std::string resample; int res_ch
 struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; double* stats = nullptr; };
 
 enum OpKind { OP_MEMSET, OP_TEMB, OP_BEGIN, OP_CONV, OP_SOFTMAX, OP_ATTN, OP_END, OP_GN_COEF,
+              // NCSN++ net (engine_ncsnpp.inc)
+              OP_NX_TEMB, OP_NX_IMG_IN, OP_NX_FIR, OP_NX_IMG_OUT,
               // backward-only
               OP_GN_FWD_COEF, OP_GN_BWD_PRE, OP_GN_BWD_COEF, OP_GN_BWD_POST, OP_TRANSPOSE, OP_SOFTMAX_BWD, OP_SUMPOOL };
 struct Op {
@@ -47,6 +50,8 @@ struct Op {
     float* sm = nullptr; int64_t sm_rows = 0; int sm_cols = 0;
     AttnParams ap{};
     GnCoefParams gp{};
+    FirParams fp{};
+    NxTembParams ntp{};
     size_t flops = 0;
     // generic slots of the backward helper ops
     const void* P[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -99,9 +104,19 @@ struct SolverBufs {
 
 }  // namespace
 
+struct NxMod {                 // one entry of NCSNpp.all_modules (ncsnpp.py:72-206), in construction order
+    enum Kind { FOURIER, LINEAR, CONV_IN, RES, ATTN, COMBINE, GN, CONV_OUT } kind;
+    int in_ch = 0, out_ch = 0;   // RES: in_ch is the (concatenated) input width
+    bool up = false, down = false;
+};
+
 struct pf_engine {
     int device = 0;
     pf_unet_cfg cfg{};
+    int arch = 0;                    // 0: the OT U-Net (pnpflow/models.py); 1: NCSN++ (pnpflow/image_generation/models/ncsnpp.py)
+    pf_ncsnpp_cfg ncfg{};
+    std::vector<NxMod> nx_mods;
+    float solver_time_scale = 1.0f;  // model label = t * this inside the solver loops (methods/pnp_flow.py:23-27)
     std::string err;
     std::vector<std::pair<std::string, std::vector<int64_t>>> expected;   // state_dict order
     std::map<std::string, HostTensor> host;
@@ -363,7 +378,7 @@ struct Builder {
 static ConvParams base_params(int B, int H, int W, int Hs, int Ws, const Tensor& out) {
     ConvParams p{};
     p.B = B; p.H = H; p.W = W; p.Hs = Hs; p.Ws = Ws; p.Cout = out.C; p.out = out.p; p.out_cstride = out.C;
-    p.out_scale = 1.0f; p.stats_out = out.stats; p.gn_eps = 1e-6f;
+    p.out_scale = 1.0f; p.res_scale = 1.0f; p.stats_out = out.stats; p.gn_eps = 1e-6f;
     { const char* d = getenv("PNPFLOW_HIP_DBG"); p.dbg = d ? atoi(d) : 0; }
     return p;
 }
@@ -375,14 +390,18 @@ static void add_seg(ConvParams& p, const Tensor& t, int xform, int taps, int gn_
 
 // GroupNorm coefficients (and, in the split-fp16 mode, the power-of-two operand scale) of a conv launch are finalised by a
 // micro-launch right before it; returns the ConvParams with coef / scale filled in
+static void ensure_coef(Builder& bd) {
+    Plan* plan = bd.plan;
+    if (plan->coef) return;
+    plan->coef = bd.acquire((size_t)bd.B * 2 * Plan::COEF_STRIDE);
+    plan->scale = bd.acquire((size_t)bd.B * 8);
+    plan->flags = reinterpret_cast<unsigned int*>(bd.acquire(64));
+    if (plan->flags) hipMemset(plan->flags, 0, 64);
+}
+
 static ConvParams with_coef(Builder& bd, ConvParams p, std::vector<Op>& ops) {
     Plan* plan = bd.plan;
-    if (!plan->coef) {
-        plan->coef = bd.acquire((size_t)bd.B * 2 * Plan::COEF_STRIDE);
-        plan->scale = bd.acquire((size_t)bd.B * 8);
-        plan->flags = reinterpret_cast<unsigned int*>(bd.acquire(64));
-        if (plan->flags) hipMemset(plan->flags, 0, 64);
-    }
+    ensure_coef(bd);
     bool raw_stats = false, packed16 = true;
     for (int i = 0; i < p.nseg; ++i) {
         raw_stats |= p.seg[i].xform == 0 && p.seg[i].stats != nullptr;
@@ -469,7 +488,9 @@ static Tensor res_block(Builder& bd, const ResDesc& r, const Tensor& in0, const 
 }
 
 // SelfAttention (models.py:145-162)
-static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x) {
+// groups / s: the NCSN++ variant (AttnBlockpp, layerspp.py:61-94) normalises over min(C/4, 32) groups and returns (x + h) * s with
+// s = 1/sqrt(2); its NIN weights reach this function as 1x1-conv aliases whose proj_out weight/bias are NOT pre-scaled
+static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x, int groups = 32, float s_out = 1.0f) {
     pf_engine* e = bd.e; const int B = bd.B, H = x.H, Wd = x.W, C = x.C, HW = H * Wd;
     // qkv = 1x1 convs of GroupNorm(x) (no activation), stacked: [B][HW][3C]
     std::string key = pfx + "qkv";
@@ -490,7 +511,7 @@ static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x) {
         add_seg(p, x, 1, 1, 0);
         fill_packed_seg(p.seg[0], e->dev.at(key + ".w"), 1, 3 * C);
         p.seg[0].w16 = packed_conv16(e, key + ".w", 0, C);
-        p.gn_C = C; p.gn_cpg = C / 32;
+        p.gn_C = C; p.gn_cpg = C / groups;
         p.gamma = upload(e, pfx + "norm.weight", W(e, pfx + "norm.weight").data);
         p.beta = upload(e, pfx + "norm.bias", W(e, pfx + "norm.bias").data);
         p.addvec = e->dev.at(key + ".b"); p.addvec_bs = 0;
@@ -533,7 +554,15 @@ static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x) {
         add_seg(p, o, 0, 1, 0);
         fill_packed_seg(p.seg[0], packed_conv(e, pfx + "proj_out.weight", 0, C), 1, C);
         p.seg[0].w16 = packed_conv16(e, pfx + "proj_out.weight", 0, C);
-        p.addvec = upload(e, pfx + "proj_out.bias", W(e, pfx + "proj_out.bias").data); p.addvec_bs = 0;
+        if (s_out == 1.0f) {
+            p.addvec = upload(e, pfx + "proj_out.bias", W(e, pfx + "proj_out.bias").data);
+        } else {
+            std::vector<float> bs = W(e, pfx + "proj_out.bias").data;
+            for (auto& v : bs) v *= s_out;
+            p.addvec = upload(e, pfx + "proj_out.bias*s", bs);
+            p.out_scale = s_out; p.res_scale = s_out;
+        }
+        p.addvec_bs = 0;
         p.residual = x.p; p.res_cstride = C;
         push_conv(bd, p);
     }
@@ -567,6 +596,7 @@ static void fix_stats(Op& op, double* slab) {
     auto fxm = [&](double*& p) { if (p) p = (double*)((char*)slab + ((uintptr_t)p - 1)); };
     if (op.kind == OP_CONV) { for (int i = 0; i < op.cp.nseg; ++i) fx(op.cp.seg[i].stats); fxm(op.cp.stats_out); fxm(op.cp.gnb_sum); }
     if (op.kind == OP_GN_COEF) for (int i = 0; i < op.gp.nseg; ++i) fx(op.gp.st[i]);
+    if (op.kind == OP_NX_FIR) fxm(op.fp.stats_raw);
     if (op.kind == OP_END) fx(op.ep.stats);
     if (op.kind == OP_BEGIN) fxm(op.ep.stats_out);
     if (op.kind == OP_GN_FWD_COEF) { const double* a = (const double*)op.P[0]; const double* b2 = (const double*)op.P[1]; fx(a); fx(b2); op.P[0] = a; op.P[1] = b2; }
@@ -575,32 +605,11 @@ static void fix_stats(Op& op, double* slab) {
 
 static int build_backward(pf_engine* e, Plan* plan, struct Builder& bd);
 
-static int build_plan(pf_engine* e, int B, bool retain, Plan** out_plan) {
-    const int key = (B * 2 + (retain ? 1 : 0)) * 2 + (e->precision ? 1 : 0);      // the precision mode selects kernels at build time
-    auto it = e->plans.find(key);
-    if (it != e->plans.end()) { *out_plan = e->last_plan = it->second.get(); it->second->last_used = ++e->plan_clock; return PF_OK; }
-    // bounded cache: a plan owns its activation buffers (GBs at the BASELINE sizes), so the least recently used one is
-    // dropped before a ninth is built (never the retained one a pf_unet_backward may still walk, nor the graph's)
-    while (e->plans.size() >= 8) {
-        auto victim = e->plans.end();
-        for (auto jt = e->plans.begin(); jt != e->plans.end(); ++jt) {
-            if (jt->second.get() == e->retained_plan || jt->second.get() == e->gkey.plan || jt->second.get() == e->okey.plan) continue;
-            if (victim == e->plans.end() || jt->second->last_used < victim->second->last_used) victim = jt;
-        }
-        if (victim == e->plans.end()) break;
-        hipDeviceSynchronize();
-        for (void* p : victim->second->allocs) hipFree(p);
-        e->bytes -= victim->second->bytes;
-        if (e->last_plan == victim->second.get()) e->last_plan = nullptr;
-        e->plans.erase(victim);
-    }
-    auto plan = std::make_unique<Plan>(); plan->B = B; plan->retain = retain; plan->last_used = ++e->plan_clock;
-    Builder bd{e, plan.get(), B};
-    if (retain) bd.keep = true;
+// the OT U-Net's forward walk (models.py:442-495): op 1 = time embedding, ...
+static int unet_walk(pf_engine* e, Builder& bd, Plan* plan) {
+    const int B = bd.B;
     const pf_unet_cfg& c = e->cfg;
     const int H0 = c.input_height, ch = c.ch, tch = 4 * ch;
-    // op 0: zero the statistics slab (filled in below); op 1: time embedding
-    { Op op{}; op.kind = OP_MEMSET; plan->ops.push_back(op); }
     float* temb_vec = bd.acquire((size_t)B * e->temb_total);
     {
         // stacked temb projections; bias = temb_proj.bias + conv1.bias
@@ -703,6 +712,43 @@ static int build_plan(pf_engine* e, int B, bool retain, Plan** out_plan) {
         plan->ops.push_back(op);
         plan->t_last = h;
     }
+    return PF_OK;
+}
+
+#include "engine_ncsnpp.inc"
+
+static int build_plan(pf_engine* e, int B, bool retain, Plan** out_plan) {
+    const int key = (B * 2 + (retain ? 1 : 0)) * 2 + (e->precision ? 1 : 0);      // the precision mode selects kernels at build time
+    auto it = e->plans.find(key);
+    if (it != e->plans.end()) { *out_plan = e->last_plan = it->second.get(); it->second->last_used = ++e->plan_clock; return PF_OK; }
+    // bounded cache: a plan owns its activation buffers (GBs at the BASELINE sizes), so the least recently used one is
+    // dropped before a ninth is built (never the retained one a pf_unet_backward may still walk, nor the graph's)
+    while (e->plans.size() >= 8) {
+        auto victim = e->plans.end();
+        for (auto jt = e->plans.begin(); jt != e->plans.end(); ++jt) {
+            if (jt->second.get() == e->retained_plan || jt->second.get() == e->gkey.plan || jt->second.get() == e->okey.plan) continue;
+            if (victim == e->plans.end() || jt->second->last_used < victim->second->last_used) victim = jt;
+        }
+        if (victim == e->plans.end()) break;
+        hipDeviceSynchronize();
+        for (void* p : victim->second->allocs) hipFree(p);
+        e->bytes -= victim->second->bytes;
+        if (e->last_plan == victim->second.get()) e->last_plan = nullptr;
+        e->plans.erase(victim);
+    }
+    auto plan = std::make_unique<Plan>(); plan->B = B; plan->retain = retain; plan->last_used = ++e->plan_clock;
+    Builder bd{e, plan.get(), B};
+    if (retain) bd.keep = true;
+    // op 0: zero the statistics slab (filled in below)
+    { Op op{}; op.kind = OP_MEMSET; plan->ops.push_back(op); }
+    if (e->arch == 1) {
+        if (retain) { e->err = "the VJP of the NCSN++ net is not built"; return PF_ERR_INVALID; }
+        int rc = nx_walk(e, bd, plan.get());
+        if (rc != PF_OK) return rc;
+    } else {
+        int rc = unet_walk(e, bd, plan.get());
+        if (rc != PF_OK) return rc;
+    }
     if (retain) { int rc = build_backward(e, plan.get(), bd); if (rc != PF_OK) return rc; }
     if (!bd.ok) return PF_ERR_HIP;
     for (auto& kv : e->dev) if (kv.second == nullptr) { e->err = "weight upload failed: " + kv.first; return PF_ERR_HIP; }
@@ -781,7 +827,7 @@ struct BwdCtx {
 
 static ConvParams bwd_params(int B, int H, int W, int Hs, int Ws, int Cout) {
     ConvParams p{};
-    p.B = B; p.H = H; p.W = W; p.Hs = Hs; p.Ws = Ws; p.Cout = Cout; p.out_scale = 1.0f; p.gn_eps = 1e-6f;
+    p.B = B; p.H = H; p.W = W; p.Hs = Hs; p.Ws = Ws; p.Cout = Cout; p.out_scale = 1.0f; p.res_scale = 1.0f; p.gn_eps = 1e-6f;
     { const char* d = getenv("PNPFLOW_HIP_DBG"); p.dbg = d ? atoi(d) : 0; }
     return p;
 }
@@ -1057,7 +1103,7 @@ static hipError_t dispatch_conv(pf_engine* e, const Op& op, hipStream_t s) {
     return launch_conv(op.cp, op.stride, op.up, s);
 }
 
-static int run_plan(pf_engine* e, Plan* plan, const float* x, const float* t, float* v, hipStream_t s) {
+static int run_plan(pf_engine* e, Plan* plan, const float* x, const float* t, float* v, hipStream_t s, float t_scale = 1.0f) {
     for (auto& op : plan->ops) {
         hipError_t r = hipSuccess;
         switch (op.kind) {
@@ -1091,6 +1137,10 @@ static int run_plan(pf_engine* e, Plan* plan, const float* x, const float* t, fl
             case OP_ATTN: r = launch_attn_fused(op.ap, s); break;
             case OP_END: { EdgeConvParams ep = op.ep; ep.out = v; r = launch_end_conv(ep, s); break; }
             case OP_GN_COEF: r = launch_gn_coef(op.gp, plan->B, s); break;
+            case OP_NX_TEMB: { NxTembParams tp = op.ntp; tp.t = t; tp.t_scale = t_scale; r = launch_nx_temb(tp, s); break; }
+            case OP_NX_IMG_IN: r = launch_img_to_nhwc32(x, (float*)op.O, plan->B, op.I[0], op.I[1], op.I[2], s); break;
+            case OP_NX_FIR: r = launch_fir_nhwc(op.fp, s); break;
+            case OP_NX_IMG_OUT: r = launch_nhwc32_to_img((const float*)op.P[0], v, t, t_scale, op.I[3], plan->B, op.I[0], op.I[1], op.I[2], s); break;
             default: break;
         }
         if (r != hipSuccess) { e->err = std::string("kernel launch failed: ") + hipGetErrorString(r); return PF_ERR_HIP; }
@@ -1140,6 +1190,40 @@ int pf_engine_create(int device_id, const pf_unet_cfg* cfg, pf_engine** out) {
     int rc = build_arch(e);
     if (rc != PF_OK) { g_create_err = e->err; delete e; return rc; }
     *out = e;
+    return PF_OK;
+}
+
+int pf_ncsnpp_create(int device_id, const pf_ncsnpp_cfg* cfg, pf_engine** out) {
+    if (!cfg || !out) { g_create_err = "null argument"; return PF_ERR_INVALID; }
+    bool ok = cfg->num_levels >= 1 && cfg->num_levels <= 8 && cfg->num_attn_resolutions >= 0 && cfg->num_attn_resolutions <= 8 &&
+              cfg->nf >= 32 && cfg->nf <= 128 && cfg->nf % 32 == 0 && cfg->num_channels >= 1 && cfg->num_channels <= 3 && cfg->num_res_blocks >= 1 &&
+              cfg->fir_taps >= 2 && cfg->fir_taps <= 8 && cfg->fir_taps % 2 == 0 && cfg->centered == 1 && cfg->image_size > 0 &&
+              cfg->image_size % (1 << (cfg->num_levels - 1)) == 0;
+    for (int i = 0; ok && i < cfg->num_levels; ++i) ok = cfg->ch_mult[i] >= 1 && cfg->nf * cfg->ch_mult[i] <= 256;   // GroupNorm of a cat input parks <= 1024 channels; FIR lanes <= 512
+    if (!ok) {
+        g_create_err = "unsupported NCSN++ configuration (need nf in {32,64,96,128}, nf*ch_mult <= 256, 1..3 image channels, centered data, "
+                       "an even-length FIR kernel, image_size divisible by 2^(levels-1))";
+        return PF_ERR_INVALID;
+    }
+    int ndev = 0;
+    hipError_t r = hipGetDeviceCount(&ndev);
+    if (r != hipSuccess || ndev <= 0) { g_create_err = std::string("no HIP device: ") + hipGetErrorString(r); return PF_ERR_HIP; }
+    if (device_id < 0 || device_id >= ndev) { g_create_err = "bad device id"; return PF_ERR_INVALID; }
+    if ((r = hipSetDevice(device_id)) != hipSuccess) { g_create_err = hipGetErrorString(r); return PF_ERR_HIP; }
+    auto* e = new pf_engine();
+    e->device = device_id; e->arch = 1; e->ncfg = *cfg;
+    e->cfg.input_channels = e->cfg.output_channels = cfg->num_channels; e->cfg.input_height = cfg->image_size;      // what the solver loops read
+    int rc = nx_build_arch(e);
+    if (rc != PF_OK) { g_create_err = e->err; delete e; return rc; }
+    *out = e;
+    return PF_OK;
+}
+
+static void drop_graph(pf_engine* e);
+static void drop_ode_graph(pf_engine* e);
+int pf_engine_set_solver_time_scale(pf_engine* e, float scale) {
+    if (!e || !(scale > 0.f)) return PF_ERR_INVALID;
+    if (scale != e->solver_time_scale) { drop_graph(e); drop_ode_graph(e); e->solver_time_scale = scale; }   // the captured graphs bake the scale in
     return PF_OK;
 }
 
@@ -1448,7 +1532,7 @@ static int enqueue_iteration(pf_engine* e, Plan* plan, const DegView& dv, const 
             r = launch_interp_iter(b.z, b.t_cur, prm->noise, b.rng, b.iter, prm->num_samples, smp, b.zt + smp * tot, B, n, s);
             if (r != hipSuccess) { e->err = std::string("interpolate: ") + hipGetErrorString(r); return PF_ERR_HIP; }
         }
-        int rc = run_plan(e, plan, b.zt, b.t_cur, b.v, s);
+        int rc = run_plan(e, plan, b.zt, b.t_cur, b.v, s, e->solver_time_scale);
         if (rc != PF_OK) return rc;
         for (int smp = 0; smp < prm->num_samples; ++smp) {
             const int mode = (smp == 0 ? 1 : 0) | (smp == prm->num_samples - 1 ? 2 : 0);
@@ -1459,7 +1543,7 @@ static int enqueue_iteration(pf_engine* e, Plan* plan, const DegView& dv, const 
     for (int smp = 0; smp < prm->num_samples; ++smp) {
         r = launch_interp_iter(b.z, b.t_cur, prm->noise, b.rng, b.iter, prm->num_samples, smp, b.zt, B, n, s);
         if (r != hipSuccess) { e->err = std::string("interpolate: ") + hipGetErrorString(r); return PF_ERR_HIP; }
-        int rc = run_plan(e, plan, b.zt, b.t_cur, b.v, s);
+        int rc = run_plan(e, plan, b.zt, b.t_cur, b.v, s, e->solver_time_scale);
         if (rc != PF_OK) return rc;
         const int mode = (smp == 0 ? 1 : 0) | (smp == prm->num_samples - 1 ? 2 : 0);
         r = launch_denoise_accum(b.x, b.zt, b.v, b.t_cur, mode, (float)prm->num_samples, B, n, s);
@@ -1602,7 +1686,7 @@ static int enqueue_ode_step(pf_engine* e, Plan* plan, const DegView& dv, const p
     const int n = C * H * H;
     hipLaunchKernelGGL(ode_prep_kernel, dim3(1), dim3(256), 0, s, (const int*)b.iter, (const float*)b.tab, b.steps, b.cur, B);
     const float* t_cur = b.cur; const float* omt = b.cur + B; const float* rt2 = b.cur + 2 * B; const float* coef = b.cur + 3 * B;
-    int rc = run_plan(e, plan, b.x, t_cur, b.vt, s);                                        // v_t = v_theta(x, t), activations retained
+    int rc = run_plan(e, plan, b.x, t_cur, b.vt, s, e->solver_time_scale);                                        // v_t = v_theta(x, t), activations retained
     if (rc != PF_OK) return rc;
     hipError_t r = dv.kind == DEG_BLUR
         ? launch_ot_ode_vec_blur(dv, b.x, b.vt, b.y, omt, rt2, prm->sigma2, b.vec, B, C, H, H, b.scratch, s)

@@ -33,8 +33,9 @@ struct ConvParams {
     int out_cstride;
     const float* addvec;  // bias (+ time-embedding projection): [b*addvec_bs + n], or nullptr
     int addvec_bs;
-    const float* residual;  // NHWC, added in the epilogue, or nullptr
+    const float* residual;  // NHWC, added in the epilogue (times res_scale), or nullptr
     int res_cstride;
+    float res_scale;      // 1 for the DDPM blocks; 1/sqrt(2) for the NCSN++ blocks' (x + h)/sqrt(2) (layerspp.py:272-274)
     double* stats_out;    // [B][Cout][2] += per-channel (sum, sumsq) of the result, or nullptr
     float out_scale;      // applied to the accumulator before bias/residual
     // GroupNorm of the (concatenated) transformed segments
@@ -169,6 +170,37 @@ hipError_t launch_ot_ode_vec_blur(const DegView& d, const float* x, const float*
 hipError_t launch_ot_ode_update(float* x, const float* vt, const float* vec, const float* g, const float* one_minus_t, const float* coef,
                                 float delta, int B, int n, hipStream_t s);
 
+// ---- NCSN++ ("rectified") velocity net, the ops that are not convs (ncsnpp_ops.hip) ----------------------------------------
+// FIR resampling of an NHWC activation (upfirdn2d of up_or_down_sampling.py:204-259 on every channel), optionally of TWO views of
+// the same source in one pass: `out_act` takes act(GroupNorm(src)) (the per-image sc/sh of `coef`, SiLU), `out_raw` the raw
+// values (+ their per-channel statistics for the consumer's range guard)  -  ResnetBlockBigGANpp.forward, layerspp.py:238-254.
+struct FirParams {
+    const float* src;              // NHWC [B][Hs][Ws][C]
+    float* out_act; float* out_raw;          // NHWC [B][H][W][C], either may be nullptr
+    const float* coef; int coef_stride;      // ConvParams::coef layout; needed for out_act
+    double* stats_raw;             // [B][C][2] += (sum, sumsq) of out_raw, or nullptr
+    int B, Hs, Ws, H, W, C;
+    int up, down, pad0, K;         // same along both axes
+    float k2d[64];                 // [K][K], already normalised / gained (up_or_down_sampling.py:197-204)
+};
+hipError_t launch_fir_nhwc(const FirParams& p, hipStream_t s);
 
+// time conditioning of NCSNpp.forward (ncsnpp.py:223-246) + every block's Dense_0(act(temb)) (layerspp.py:258-260) in one launch:
+// out[b][j] = bp[j] + Wp[j] . silu(Linear1(silu(Linear0([sin, cos](2 pi W log(t[b] * t_scale))))))
+struct NxTembParams {
+    const float* t; float t_scale;
+    const float* Wf;               // [nf] GaussianFourierProjection.W (layerspp.py:31-41)
+    const float* w0; const float* b0;        // Linear(2nf -> 4nf)  (out, in)
+    const float* w1; const float* b1;        // Linear(4nf -> 4nf)
+    const float* wp; const float* bp;        // stacked Dense_0 weights [total_out][4nf], biases (+ Conv_0.bias)
+    float* out; int B, nf, total_out;
+};
+hipError_t launch_nx_temb(const NxTembParams& p, hipStream_t s);
+
+// image boundary: NCHW image -> zero-padded NHWC-32 operand of the MFMA conv, and back (the first Cimg channels of the NHWC-32
+// output-skip pyramid, divided by sigma = t * t_scale when scale_by_sigma; ncsnpp.py:378-381)
+hipError_t launch_img_to_nhwc32(const float* img, float* out, int B, int Cimg, int H, int W, hipStream_t s);
+hipError_t launch_nhwc32_to_img(const float* in, float* img, const float* t, float t_scale, int scale_by_sigma, int B, int Cimg, int H, int W,
+                                hipStream_t s);
 
 }  // namespace pf

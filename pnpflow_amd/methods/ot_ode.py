@@ -37,7 +37,9 @@ class OT_ODE(object):
     def model_forward(self, x, t):
         if self.args.model == "ot":
             return self.model(x, t)
-        raise NotImplementedError("only the 'ot' U-Net is implemented")
+        if self.args.model == "rectified":        # ot_ode.py:21-25: model_fn(x, t * 999)
+            return self.model(x.type(torch.float), t * 999)
+        raise NotImplementedError("only the 'ot' U-Net and the 'rectified' NCSN++ net are implemented")
 
     def initialization(self, noisy_img, t0):
         noise = self.init_noise if self.init_noise is not None else torch.randn(noisy_img.shape).to(noisy_img.device)
@@ -64,6 +66,8 @@ class OT_ODE(object):
         iterations in `cb_iterations` (None = every iteration)."""
         args = self.args
         problem = args.problem
+        if args.model == "rectified":
+            raise NotImplementedError("ot_ode needs the VJP of the velocity net (ot_ode.py:137-138); the NCSN++ engine is forward-only")
         if problem not in ("denoising", "inpainting", "random_inpainting", "paintbrush_inpainting", "superresolution", "gaussian_deblurring_FFT"):
             # the reference's remaining branch is a per-image GMRES on H H^T (ot_ode.py:118-128); none of its operators reach it
             raise NotImplementedError(f"ot_ode linear solve for '{problem}' is not implemented by this engine")

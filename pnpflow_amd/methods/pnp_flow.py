@@ -44,7 +44,9 @@ class PNP_FLOW(object):
     def model_forward(self, x, t):
         if self.coupling in {"ot", "indep"}:
             return self.model(x, t)
-        raise NotImplementedError("only the 'ot'/'indep' U-Net is implemented")
+        if self.coupling == "rectified":          # pnp_flow.py:23-27: model_fn(x, t * 999)
+            return self.model(x.type(torch.float), t * 999)
+        raise NotImplementedError("only the 'ot'/'indep' U-Net and the 'rectified' NCSN++ net are implemented")
 
     def learning_rate_strat(self, lr, t):
         t = t.view(-1, 1, 1, 1)
@@ -103,6 +105,10 @@ class PNP_FLOW(object):
         B = noisy_img.shape[0]
         Cc, Hh = self.model.input_channels, self.model.input_height
         t_vals, coef = self._schedule(steps, lr, sigma_noise)
+        if hasattr(self.model, "set_solver_time_scale"):
+            # the engine's loop evaluates model(x, t * 999) for the rectified coupling (model_forward above).  NB the reference's
+            # first iteration has t = 0, log(0 * 999) = -inf: its output is NaN from there on; the engine raises PF_ERR_NUMERIC.
+            self.model.set_solver_time_scale(999.0 if self.coupling == "rectified" else 1.0)
         d = degradation.descriptor(B, Hh, Hh, noisy_img.device)
         prm = _lib.PfPnpParams()
         prm.steps, prm.num_samples = steps, ns

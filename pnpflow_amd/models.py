@@ -16,35 +16,8 @@ import torch
 from . import _lib
 
 
-class UNet:
-    def __init__(self, input_channels, input_height, ch, output_channels=None, ch_mult=(1, 2, 4, 8),
-                 num_res_blocks=2, attn_resolutions=(16,), dropout=0., resamp_with_conv=True, act=None,
-                 normalize=None, device_index: int = 0):
-        if dropout != 0. or not resamp_with_conv:
-            raise NotImplementedError("engine implements the configuration define_model uses: dropout=0, resamp_with_conv=True")
-        self.input_channels = input_channels
-        self.input_height = input_height
-        self.ch = ch
-        self.output_channels = input_channels if output_channels is None else output_channels
-        self.ch_mult = tuple(ch_mult)
-        self.num_res_blocks = num_res_blocks
-        self.attn_resolutions = tuple(attn_resolutions)
-        self.num_resolutions = len(self.ch_mult)
-        self._lib = _lib.load()
-        cfg = _lib.PfUnetCfg()
-        cfg.input_channels, cfg.output_channels, cfg.input_height, cfg.ch = input_channels, self.output_channels, input_height, ch
-        cfg.num_levels, cfg.num_res_blocks = len(self.ch_mult), num_res_blocks
-        for i, m in enumerate(self.ch_mult):
-            cfg.ch_mult[i] = m
-        cfg.num_attn_resolutions = len(self.attn_resolutions)
-        for i, r in enumerate(self.attn_resolutions):
-            cfg.attn_resolutions[i] = r
-        self._device_index = device_index
-        h = C.c_void_p()
-        _lib.check(self._lib.pf_engine_create(device_index, C.byref(cfg), C.byref(h)), None, "pf_engine_create")
-        self._h = h
-        self._loaded = False
-        self.training = False
+class _EngineNet:
+    """What UNet and NCSNpp share: the torch.nn.Module-like surface the reference's callers use, on a pf_engine handle."""
 
     # ---- torch.nn.Module-like surface used by the reference's callers -------------------
     def to(self, device=None):
@@ -94,7 +67,7 @@ class UNet:
 
     def forward(self, x: torch.Tensor, temp: torch.Tensor) -> torch.Tensor:
         if not x.is_cuda:
-            raise _lib.PnpFlowHipError("UNet.forward needs tensors on the GPU (there is no CPU path)")
+            raise _lib.PnpFlowHipError(f"{type(self).__name__}.forward needs tensors on the GPU (there is no CPU path)")
         x = x.contiguous().float()
         t = temp.contiguous().float().to(x.device)
         B, Cc, H, W = x.shape
@@ -103,29 +76,6 @@ class UNet:
         _lib.check(self._lib.pf_unet_forward(self._h, x.data_ptr(), t.data_ptr(), v.data_ptr(), B, _lib.current_stream_ptr()),
                    self._h, "pf_unet_forward")
         return v
-
-    def forward_retain(self, x: torch.Tensor, temp: torch.Tensor) -> torch.Tensor:
-        """Forward that keeps every activation on the device, for a following `backward`."""
-        x = x.contiguous().float(); t = temp.contiguous().float().to(x.device)
-        B = x.shape[0]
-        v = torch.empty((B, self.output_channels, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
-        _lib.check(self._lib.pf_unet_forward_retain(self._h, x.data_ptr(), t.data_ptr(), v.data_ptr(), B, _lib.current_stream_ptr()),
-                   self._h, "pf_unet_forward_retain")
-        return v
-
-    def backward(self, vec: torch.Tensor) -> torch.Tensor:
-        """J^T vec (input gradient) at the last `forward_retain`."""
-        vec = vec.contiguous().float()
-        g = torch.empty((vec.shape[0], self.input_channels, vec.shape[2], vec.shape[3]), dtype=torch.float32, device=vec.device)
-        _lib.check(self._lib.pf_unet_backward(self._h, vec.data_ptr(), g.data_ptr(), vec.shape[0], _lib.current_stream_ptr()),
-                   self._h, "pf_unet_backward")
-        return g
-
-    def vjp(self, x: torch.Tensor, temp: torch.Tensor, vec: torch.Tensor):
-        """(v_theta(x,t), J^T vec) - what torch.autograd.functional.vjp(lambda z: model(z,t), x, vec) returns
-        (reference pnpflow/methods/ot_ode.py:137-138)."""
-        v = self.forward_retain(x, temp)
-        return v, self.backward(vec)
 
     # ---- debugging: named internal activations of the last forward (NCHW numpy) -----------
     def read_taps(self, B):
@@ -171,3 +121,57 @@ class UNet:
                 self._h = None
         except Exception:
             pass
+
+
+class UNet(_EngineNet):
+    def __init__(self, input_channels, input_height, ch, output_channels=None, ch_mult=(1, 2, 4, 8),
+                 num_res_blocks=2, attn_resolutions=(16,), dropout=0., resamp_with_conv=True, act=None,
+                 normalize=None, device_index: int = 0):
+        if dropout != 0. or not resamp_with_conv:
+            raise NotImplementedError("engine implements the configuration define_model uses: dropout=0, resamp_with_conv=True")
+        self.input_channels = input_channels
+        self.input_height = input_height
+        self.ch = ch
+        self.output_channels = input_channels if output_channels is None else output_channels
+        self.ch_mult = tuple(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.attn_resolutions = tuple(attn_resolutions)
+        self.num_resolutions = len(self.ch_mult)
+        self._lib = _lib.load()
+        cfg = _lib.PfUnetCfg()
+        cfg.input_channels, cfg.output_channels, cfg.input_height, cfg.ch = input_channels, self.output_channels, input_height, ch
+        cfg.num_levels, cfg.num_res_blocks = len(self.ch_mult), num_res_blocks
+        for i, m in enumerate(self.ch_mult):
+            cfg.ch_mult[i] = m
+        cfg.num_attn_resolutions = len(self.attn_resolutions)
+        for i, r in enumerate(self.attn_resolutions):
+            cfg.attn_resolutions[i] = r
+        self._device_index = device_index
+        h = C.c_void_p()
+        _lib.check(self._lib.pf_engine_create(device_index, C.byref(cfg), C.byref(h)), None, "pf_engine_create")
+        self._h = h
+        self._loaded = False
+        self.training = False
+
+    def forward_retain(self, x: torch.Tensor, temp: torch.Tensor) -> torch.Tensor:
+        """Forward that keeps every activation on the device, for a following `backward`."""
+        x = x.contiguous().float(); t = temp.contiguous().float().to(x.device)
+        B = x.shape[0]
+        v = torch.empty((B, self.output_channels, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+        _lib.check(self._lib.pf_unet_forward_retain(self._h, x.data_ptr(), t.data_ptr(), v.data_ptr(), B, _lib.current_stream_ptr()),
+                   self._h, "pf_unet_forward_retain")
+        return v
+
+    def backward(self, vec: torch.Tensor) -> torch.Tensor:
+        """J^T vec (input gradient) at the last `forward_retain`."""
+        vec = vec.contiguous().float()
+        g = torch.empty((vec.shape[0], self.input_channels, vec.shape[2], vec.shape[3]), dtype=torch.float32, device=vec.device)
+        _lib.check(self._lib.pf_unet_backward(self._h, vec.data_ptr(), g.data_ptr(), vec.shape[0], _lib.current_stream_ptr()),
+                   self._h, "pf_unet_backward")
+        return g
+
+    def vjp(self, x: torch.Tensor, temp: torch.Tensor, vec: torch.Tensor):
+        """(v_theta(x,t), J^T vec) - what torch.autograd.functional.vjp(lambda z: model(z,t), x, vec) returns
+        (reference pnpflow/methods/ot_ode.py:137-138)."""
+        v = self.forward_retain(x, temp)
+        return v, self.backward(vec)

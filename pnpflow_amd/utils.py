@@ -87,10 +87,30 @@ def define_model(args):
                      num_res_blocks=6, attn_resolutions=(16, 8), resamp_with_conv=True,
                      device_index=int(getattr(args, "device_index", 0)))
         return (model, None)
-    raise Exception("Unknown model! (this engine implements the 'ot'/'indep' U-Net velocity field)")
+    if args.model == "rectified":
+        # utils.py:186-204 of the reference: the NCSN++ net of the dataset's rectified-flow config.  `state` keeps the key the
+        # reference's load_model fills ('model'); the optimizer / EMA entries of the training state are not part of inference.
+        from .image_generation.models import utils as mutils
+        from .image_generation.configs.rectified_flow.celeba_hq_pytorch_rf_gaussian import get_config as get_config_celebahq
+        from .image_generation.configs.rectified_flow.afhq_cat_pytorch_rf_gaussian import get_config as get_config_afhq_cat
+        if args.dataset == "celebahq":
+            config = get_config_celebahq()
+        elif args.dataset == "afhq_cat":
+            config = get_config_afhq_cat()
+        else:
+            raise Exception("the rectified model exists for celebahq and afhq_cat")
+        score_model = mutils.create_model(config, device_index=int(getattr(args, "device_index", 0)))
+        return score_model, dict(model=score_model, step=0)
+    raise Exception("Unknown model! (this engine implements the 'ot'/'indep' U-Net and the 'rectified' NCSN++ velocity fields)")
 
 
 def load_model(name_model, model, state, download=False, checkpoint_path=None, dataset=None, device='cuda'):
+    if name_model == "rectified":
+        # image_generation/utils.py:7-13 `restore_checkpoint`: state['model'].load_state_dict(loaded_state['model'], strict=False)
+        loaded_state = torch.load(checkpoint_path, map_location='cpu')
+        state['model'].load_state_dict(loaded_state['model'], strict=False)
+        state['step'] = loaded_state.get('step', 0)
+        return state
     if name_model not in ("ot", "indep"):
         raise NotImplementedError(name_model)
     if download:

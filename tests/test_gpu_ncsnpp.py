@@ -1,0 +1,181 @@
+"""GPU parity of the NCSN++ ("rectified" coupling) velocity net through the C ABI: engine vs the CPU oracle
+(oracle/ncsnpp_oracle.py) and vs golden outputs of the REAL reference module (tests/golden/ncsnpp_*.npz, tools/make_golden.py
+`gen_ncsnpp`).
+
+Tolerance: the net's output is h / (t * 999) (scale_by_sigma), so errors are measured relative to max|reference output|;
+NX_RTOL = 1e-5 is ~5x the measured error (1-2e-6 in both precision modes, tools/gpu_ncsnpp_dev.py) and the same fp32-equivalence
+bar the OT U-Net tests hold (2e-5 absolute on O(1) outputs).
+"""
+import ctypes as C
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ncsnpp_oracle as NO          # noqa: E402
+from oracle import pnpflow_oracle as O          # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+NX_RTOL = 1e-5
+
+CFGS = {
+    "tiny": dict(image_size=32, nf=32, ch_mult=(1, 1, 2), num_res_blocks=2, attn_resolutions=(16,)),
+    "wide": dict(image_size=32, nf=128, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(16,)),
+    "afhq256": dict(image_size=256, nf=128, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, attn_resolutions=(16,)),
+}
+
+
+def ref_config(c):
+    NS = types.SimpleNamespace
+    return NS(model=NS(name="ncsnpp", nf=c["nf"], ch_mult=c["ch_mult"], num_res_blocks=c["num_res_blocks"], attn_resolutions=c["attn_resolutions"],
+                       dropout=0., conditional=True, fir=True, fir_kernel=[1, 3, 3, 1], skip_rescale=True, resblock_type="biggan",
+                       progressive="output_skip", progressive_input="input_skip", progressive_combine="sum", embedding_type="fourier",
+                       nonlinearity="swish", scale_by_sigma=True),
+              data=NS(image_size=c["image_size"], num_channels=3, centered=True), training=NS(continuous=False, sde="rectified_flow"))
+
+
+def det_normal(shape, seed, idx=0):
+    g = np.random.Generator(np.random.Philox(key=[seed, idx]))
+    return torch.from_numpy(g.standard_normal(size=shape, dtype=np.float32))
+
+
+_models = {}
+
+
+def get_model(name):
+    from pnpflow_amd.image_generation.models.ncsnpp import NCSNpp
+    if name not in _models:
+        c = CFGS[name]
+        cfg = NO.ncsnpp_config(**c)
+        sd = NO.synthetic_state_dict(cfg, 0)
+        m = NCSNpp(ref_config(c))
+        m.load_state_dict(sd)
+        _models[name] = (m, cfg, sd)
+    return _models[name]
+
+
+@pytest.mark.parametrize("name", ["tiny", "wide"])
+@pytest.mark.parametrize("precision", [1, 0])
+def test_ncsnpp_forward_oracle_and_reference_golden(name, precision):
+    m, cfg, sd = get_model(name)
+    g = np.load(os.path.join(GOLD, f"ncsnpp_{name}.npz"))
+    S = cfg["image_size"]
+    x = det_normal((2, 3, S, S), 81); t = torch.from_numpy(g["t"])
+    m.set_precision(precision)
+    try:
+        y = m(x.cuda(), (t * 999).cuda()).cpu()
+        m.check_numerics()
+    finally:
+        m.set_precision(1)
+    ref = NO.ncsnpp_forward(sd, cfg, x, t * 999)
+    scale = float(g["y_absmax"])
+    assert (y - ref).abs().max().item() <= NX_RTOL * scale
+    assert np.abs(y.numpy() - g["y"]).max() <= NX_RTOL * scale           # the real reference module's output
+
+
+def test_ncsnpp_reference_config_256_golden():
+    """The reference's rectified-flow config (nf 128, ch_mult (1,1,2,2,2,2,2), 256^2, attention at 16^2 and on the 4^2 middle
+    block: 65.6 M parameters) against the real module's output (crop, corner, float64 checksums)."""
+    m, cfg, sd = get_model("afhq256")
+    g = np.load(os.path.join(GOLD, "ncsnpp_afhq256.npz"))
+    x = det_normal((1, 3, 256, 256), 81); t = torch.from_numpy(g["t"])
+    y = m(x.cuda(), (t * 999).cuda()).cpu()
+    m.check_numerics()
+    scale = float(g["y_absmax"])
+    assert np.abs(y[:, :, 112:144, 112:144].numpy() - g["y_crop"]).max() <= NX_RTOL * scale
+    assert np.abs(y[:, :, :8, :8].numpy() - g["y_corner"]).max() <= NX_RTOL * scale
+    d = y.double()
+    cs = np.array([d.sum().item(), d.abs().sum().item(), (d * d).sum().item()])
+    n = y.numel()
+    assert abs(cs[0] - g["y_checksum"][0]) <= NX_RTOL * scale * n ** 0.5 * 4
+    assert abs(cs[1] - g["y_checksum"][1]) <= NX_RTOL * g["y_checksum"][1]
+    assert abs(cs[2] - g["y_checksum"][2]) <= 2 * NX_RTOL * g["y_checksum"][2]
+
+
+def test_ncsnpp_batch_independence_and_per_image_labels():
+    m, cfg, sd = get_model("tiny")
+    x = det_normal((3, 3, 32, 32), 82); lab = torch.tensor([5.0, 400.0, 998.0])
+    yb = m(x.cuda(), lab.cuda()).cpu()
+    for b in range(3):
+        y1 = m(x[b:b + 1].cuda(), lab[b:b + 1].cuda()).cpu()
+        ref = NO.ncsnpp_forward(sd, cfg, x[b:b + 1], lab[b:b + 1])
+        s = ref.abs().max().item()
+        assert (yb[b:b + 1] - y1).abs().max().item() <= 1e-6 * s      # only the order of the fp64 statistics atomics differs
+        assert (y1 - ref).abs().max().item() <= NX_RTOL * s
+
+
+def test_ncsnpp_checkpoint_key_forms_and_errors():
+    from pnpflow_amd import _lib
+    from pnpflow_amd.image_generation.models.ncsnpp import NCSNpp
+    c = CFGS["tiny"]; cfg = NO.ncsnpp_config(**c); sd = NO.synthetic_state_dict(cfg, 0)
+    m = NCSNpp(ref_config(c))
+    assert list(m.state_dict_keys()) == list(NO.ncsnpp_param_shapes(cfg).keys())
+    assert m.state_dict_shapes() == {k: tuple(v) for k, v in NO.ncsnpp_param_shapes(cfg).items()}
+    # the reference checkpoint's form: DataParallel prefix + the sigmas buffer, loaded with strict=False (image_generation/utils.py:10)
+    ck = {"module." + k: v for k, v in sd.items()}; ck["module.sigmas"] = torch.zeros(2000)
+    m.load_state_dict(ck, strict=False)
+    x = det_normal((1, 3, 32, 32), 83); lab = torch.tensor([321.0])
+    y = m(x.cuda(), lab.cuda()).cpu()
+    ref = NO.ncsnpp_forward(sd, cfg, x, lab)
+    assert (y - ref).abs().max().item() <= NX_RTOL * ref.abs().max().item()
+    m2 = NCSNpp(ref_config(c))
+    bad = dict(sd); bad.pop("all_modules.4.Conv_0.weight")
+    with pytest.raises(RuntimeError):
+        m2.load_state_dict(bad)
+    # forward-only: the VJP entry points refuse this net
+    lib = _lib.load()
+    xx = x.cuda(); ll = lab.cuda(); v = torch.empty_like(xx)
+    rc = lib.pf_unet_forward_retain(m.handle, xx.data_ptr(), ll.data_ptr(), v.data_ptr(), 1, _lib.current_stream_ptr())
+    assert rc == -1 and b"VJP" in lib.pf_last_error(m.handle)
+    # unsupported switches are rejected loudly
+    cfg_bad = ref_config(c); cfg_bad.model.resblock_type = "ddpm"
+    with pytest.raises(NotImplementedError):
+        NCSNpp(cfg_bad)
+    # t = 0 (the first PnP-Flow iteration of the reference's schedule): log(0) -> the reference returns NaN, the engine reports it
+    m(xx, torch.zeros(1, device="cuda"))
+    with pytest.raises(_lib.PnpFlowHipError):
+        m.check_numerics()
+
+
+def test_ncsnpp_in_the_pnp_flow_loop_time_scale():
+    """PNP_FLOW with model='rectified' evaluates model(x, t * 999) (pnp_flow.py:23-27) inside the engine's loop
+    (pf_engine_set_solver_time_scale).  The reference's own schedule starts at t = 0 where the label's logarithm is -inf, so
+    the schedule is shifted into (0, 1) here and the loop is restated with the oracle's pieces."""
+    import pnpflow_amd.degradations as D
+    from pnpflow_amd import _lib
+    from pnpflow_amd.methods.pnp_flow import PNP_FLOW
+    from pnpflow_amd.utils import CfgNode
+    m, cfg, sd = get_model("tiny")
+    B, steps, ns, sigma, lr = 2, 3, 2, 0.05, 1.0
+    args = CfgNode(dict(method="pnp_flow", model="rectified", problem="inpainting", noise_type="gaussian", num_samples=ns, steps_pnp=steps,
+                        lr_pnp=lr, gamma_style="constant", alpha=1.0, max_batch=1, batch_size_ip=B, dim_image=32, num_channels=3,
+                        sigma_noise=sigma, batch=0))
+    solver = PNP_FLOW(m, "cuda", args)
+    tv = np.array([0.2, 0.45, 0.7], dtype=np.float32)
+    lr_eff = lr * sigma ** 2                                             # solve_ip: lr = sigma_noise**2 * lr_pnp (pnp_flow.py:60-62)
+    solver._schedule = lambda s_, l_, sn_: (tv, np.full(steps, l_ / sn_ ** 2, dtype=np.float32))     # gamma_style 'constant'
+    noise = det_normal((steps * ns, B, 3, 32, 32), 84)
+    clean = torch.tanh(det_normal((B, 3, 32, 32), 85))
+    deg_o = O.BoxInpainting(6)
+    y = O.make_measurement(clean, deg_o, sigma, 0, noise=det_normal((B, 3, 32, 32), 86))
+    solver.noise = noise.cuda()
+    x_hip = solver.restore_batch(y.cuda(), D.BoxInpainting(6), sigma, lr_eff).cpu()
+    # the same loop with the oracle's pieces (pnp_flow.py:93, 102-121)
+    x = deg_o.H_adj(torch.ones_like(y))
+    for it in range(steps):
+        t1 = torch.ones(B) * float(tv[it]); t4 = t1.view(-1, 1, 1, 1)
+        z = x - lr_eff * (deg_o.H_adj(deg_o.H(x) - y) / sigma ** 2)
+        x_new = torch.zeros_like(x)
+        for s in range(ns):
+            zt = t4 * z + noise[it * ns + s] * (1 - t4)
+            x_new += zt + (1 - t4) * NO.ncsnpp_forward(sd, cfg, zt, t1 * 999)
+        x = x_new / ns
+    assert (x_hip - x).abs().max().item() <= 2e-5
+    # and with the reference's own schedule the first label is 0: reported, not propagated
+    solver2 = PNP_FLOW(m, "cuda", args); solver2.noise = noise.cuda()
+    with pytest.raises(_lib.PnpFlowHipError):
+        solver2.restore_batch(y.cuda(), D.BoxInpainting(6), sigma, lr_eff)

@@ -268,3 +268,36 @@ def test_paintbrush_masks_are_seeded_prefix_consistent_and_match_the_oracle():
     assert m4[0, min(max(y1, 0), 63), min(max(x1, 0), 95)] == 0 and m4[0, min(max(y2, 0), 63), min(max(x2, 0), 95)] == 0
     with pytest.raises(Exception):
         paintbrush_masks(1, 32, 32)
+
+
+def test_rectified_model_surface():
+    """The reference's import paths for the rectified (NCSN++) net resolve to the engine classes; configs carry the reference's
+    hyper-parameters; unsupported switches and a missing device fail loudly (no fallback)."""
+    import pnpflow_amd._lib as L
+    from pnpflow.image_generation.models.ncsnpp import NCSNpp
+    from pnpflow.image_generation.models import utils as mutils
+    from pnpflow.image_generation.configs.rectified_flow.celeba_hq_pytorch_rf_gaussian import get_config as cfg_celeba
+    from pnpflow.image_generation.configs.rectified_flow.afhq_cat_pytorch_rf_gaussian import get_config as cfg_afhq
+    import pnpflow_amd.image_generation.models.ncsnpp as A
+    assert NCSNpp is A.NCSNpp and mutils.get_model("ncsnpp") is NCSNpp
+    for get, ds in ((cfg_celeba, "CelebA-HQ-Pytorch"), (cfg_afhq, "AFHQ-CAT-Pytorch")):
+        c = get()
+        assert c.data.dataset == ds and c.data.image_size == 256 and c.data.centered is True
+        m = c.model
+        assert (m.name, m.nf, tuple(m.ch_mult), m.num_res_blocks, tuple(m.attn_resolutions)) == ("ncsnpp", 128, (1, 1, 2, 2, 2, 2, 2), 2, (16,))
+        assert m.fir and list(m.fir_kernel) == [1, 3, 3, 1] and m.skip_rescale and m.scale_by_sigma and m.resblock_type == "biggan"
+        assert (m.progressive, m.progressive_input, m.progressive_combine, m.embedding_type) == ("output_skip", "input_skip", "sum", "fourier")
+        assert c.training.sde == "rectified_flow" and c.training.continuous is False
+    bad = cfg_afhq(); bad.model.progressive = "residual"
+    with pytest.raises(NotImplementedError):
+        NCSNpp(bad)
+    bad = cfg_afhq(); bad.data.centered = False
+    with pytest.raises(NotImplementedError):
+        NCSNpp(bad)
+    if not torch.cuda.is_available():
+        with pytest.raises(L.PnpFlowHipError):
+            NCSNpp(cfg_afhq())
+    # the module order of the oracle's restatement = the engine's expected state_dict (checked on the GPU box against the engine)
+    from oracle import ncsnpp_oracle as NO
+    shapes = NO.ncsnpp_param_shapes(NO.ncsnpp_config())
+    assert len(shapes) == 645 and shapes["all_modules.0.W"] == (128,) and shapes["all_modules.3.weight"] == (128, 3, 3, 3)

@@ -294,3 +294,35 @@ def test_fir_resampling_and_fused_act_match_reference(golden):
     xb = det_normal((2, 5, 6, 7), 73); bias = det_normal((5,), 74)
     np.testing.assert_allclose(O.fused_leaky_relu(xb, bias).numpy(), g["fused_leaky_relu"], atol=1e-6)
     np.testing.assert_allclose(O.fused_leaky_relu(det_normal((3, 5), 75), bias).numpy(), g["fused_leaky_relu_2d"], atol=1e-6)
+
+
+# ---- NCSN++ ("rectified") velocity net: oracle/ncsnpp_oracle.py vs the REAL reference module -----------------------------------
+NCSNPP_CFGS = {
+    "tiny": dict(image_size=32, nf=32, ch_mult=(1, 1, 2), num_res_blocks=2, attn_resolutions=(16,)),
+    "wide": dict(image_size=32, nf=128, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(16,)),
+    "afhq256": dict(image_size=256, nf=128, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, attn_resolutions=(16,)),
+}
+
+
+@pytest.mark.parametrize("name", ["tiny", "wide", "afhq256"])
+def test_ncsnpp_oracle_matches_reference_module(golden, name):
+    """tools/make_golden.py `gen_ncsnpp` ran pnpflow/image_generation/models/ncsnpp.py NCSNpp.forward on these weights / inputs."""
+    from oracle import ncsnpp_oracle as NO
+    c = NCSNPP_CFGS[name]
+    cfg = NO.ncsnpp_config(**c)
+    sd = NO.synthetic_state_dict(cfg, 0)
+    g = golden(f"ncsnpp_{name}")
+    B = 1 if name == "afhq256" else 2
+    x = det_normal((B, 3, c["image_size"], c["image_size"]), 81)
+    t = torch.from_numpy(g["t"])
+    taps = {}
+    y = NO.ncsnpp_forward(sd, cfg, x, t * 999, taps)
+    tol = 1e-6 * float(g["y_absmax"])          # same ops in the same order: observed 0
+    if name == "afhq256":
+        assert sum(int(np.prod(s)) for s in NO.ncsnpp_param_shapes(cfg).values()) == 65574549      # the reference prints it (models/utils.py:97-100); + 2000 sigmas
+        _check_crops(y, g, "y", tol)
+    else:
+        np.testing.assert_allclose(y.numpy(), g["y"], atol=tol)
+        for k in g.files:
+            if k.startswith("tap_"):
+                np.testing.assert_allclose(taps[k[4:]].numpy(), g[k], atol=1e-6)

@@ -383,10 +383,83 @@ def gen_ops():
     print("native ops ok")
 
 
+NCSNPP_CFGS = {
+    # 3 levels 32/16/8: attention on the 16^2 level (down: per block, up: once), 1x1 shortcuts, down/up FIR blocks, both pyramids
+    "tiny": dict(image_size=32, nf=32, ch_mult=(1, 1, 2), num_res_blocks=2, attn_resolutions=(16,)),
+    # the widths of the real net (128/256 channels -> the fused attention kernel) on a 2-level 32^2 net
+    "wide": dict(image_size=32, nf=128, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(16,)),
+    # the reference's rectified-flow config (configs/rectified_flow/afhq_cat_pytorch_rf_gaussian.py): 65.6 M parameters
+    "afhq256": dict(image_size=256, nf=128, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, attn_resolutions=(16,)),
+}
+
+
+def gen_ncsnpp():
+    """NCSNpp.forward of the REAL reference module (pnpflow/image_generation/models/ncsnpp.py) on the oracle's synthetic weights.
+    The reference's op/ modules JIT-compile CUDA sources at import: torch.utils.cpp_extension.load is stubbed for the import,
+    and on CPU tensors the reference itself takes its pure-torch `upfirdn2d_native` branch (op/upfirdn2d.py:128-139).  The
+    ml_collections config object is replaced by a plain attribute namespace with the fields NCSNpp.__init__ reads."""
+    import importlib
+    import types
+    import torch.utils.cpp_extension as ce
+    from oracle import ncsnpp_oracle as NO
+    saved = ce.load
+    ce.load = lambda *a, **k: types.SimpleNamespace()
+    try:
+        from ref_import import install_stubs, REF
+        install_stubs()
+        if REF not in sys.path:
+            sys.path.insert(0, REF)
+        nc = importlib.import_module("pnpflow.image_generation.models.ncsnpp")
+    finally:
+        ce.load = saved
+    NS = types.SimpleNamespace
+
+    def ref_config(c):      # default_lsun_configs.py:52-70 + celeba_hq_pytorch_rf_gaussian.py:43-64
+        return NS(model=NS(nf=c["nf"], ch_mult=c["ch_mult"], num_res_blocks=c["num_res_blocks"], attn_resolutions=c["attn_resolutions"],
+                           dropout=0., resamp_with_conv=True, conditional=True, fir=True, fir_kernel=[1, 3, 3, 1], skip_rescale=True,
+                           resblock_type='biggan', progressive='output_skip', progressive_input='input_skip', progressive_combine='sum',
+                           attention_type='ddpm', embedding_type='fourier', init_scale=0., fourier_scale=16, conv_size=3,
+                           nonlinearity='swish', scale_by_sigma=True, sigma_max=378, sigma_min=0.01, num_scales=2000, name='ncsnpp'),
+                  data=NS(image_size=c["image_size"], num_channels=3, centered=True),
+                  training=NS(continuous=False, sde='rectified_flow'))
+
+    for name, c in NCSNPP_CFGS.items():
+        cfg = NO.ncsnpp_config(**c)
+        sd = NO.synthetic_state_dict(cfg, 0)
+        m = nc.NCSNpp(ref_config(c)).eval()
+        own = m.state_dict()
+        assert set(own) - {"sigmas"} == set(sd), (set(own) ^ set(sd))
+        for k, v in sd.items():
+            assert tuple(own[k].shape) == tuple(v.shape), k
+        m.load_state_dict(sd, strict=False)
+        S = c["image_size"]
+        B = 1 if name == "afhq256" else 2
+        x = det_normal((B, 3, S, S), 81)
+        t = torch.tensor([0.37, 0.81][:B])
+        feats = {}
+        hooks = []
+        if name == "tiny":        # a few intermediate activations: first conv, first down block, the mid block's last module input
+            hooks.append(m.all_modules[3].register_forward_hook(lambda mod, i, o: feats.__setitem__("conv_in", o.detach())))
+            hooks.append(m.all_modules[4].register_forward_hook(lambda mod, i, o: feats.__setitem__("down0_0", o.detach())))
+        with torch.no_grad():
+            y = m(x, t * 999)
+        for h in hooks:
+            h.remove()
+        rec = dict(t=t.numpy(), y_absmax=np.array(float(y.abs().max())))
+        if name == "afhq256":
+            rec.update(crop_rec("y", y))
+        else:
+            rec["y"] = y.numpy()
+            for k, v in feats.items():
+                rec["tap_" + k] = v.numpy()
+        np.savez_compressed(os.path.join(OUT, f"ncsnpp_{name}.npz"), **rec)
+        print("ncsnpp", name, float(y.abs().mean()), float(y.abs().max()))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     models, degr, utils, pnp = import_reference()
-    which = sys.argv[1:] or ["unet", "degr", "traj", "ot_ode", "big", "ops"]
+    which = sys.argv[1:] or ["unet", "degr", "traj", "ot_ode", "big", "ops", "ncsnpp"]
     if "unet" in which:
         gen_unet(models)
     if "degr" in which:
@@ -399,3 +472,5 @@ if __name__ == "__main__":
         gen_big(models, degr, utils)
     if "ops" in which:
         gen_ops()
+    if "ncsnpp" in which:
+        gen_ncsnpp()

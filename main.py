@@ -96,7 +96,8 @@ def main():
     args.device_index = local
     (model, state) = define_model(args)
     if args.eval:
-        model_path = args.output_root + 'model/{}/{}/model_final.pt'.format(args.dataset, args.model)
+        # main.py:91-102 of the reference: the OT checkpoint is model_final.pt, the rectified (NCSN++) training state model_final.pth
+        model_path = args.output_root + 'model/{}/{}/model_final.{}'.format(args.dataset, args.model, 'pth' if args.model == 'rectified' else 'pt')
         if os.path.isfile(model_path):
             load_model(args.model, model, state, download=False, checkpoint_path=model_path, dataset=None, device=device)
         elif synthetic:

@@ -328,6 +328,31 @@ def cpu_baseline_ot_ode(wl, budget_s=15.0):
                        f"on {cores} threads, scaled linearly to {total} steps")
 
 
+def ncsnpp_forward_block(dev, B=32, reps=3):
+    """Velocity evaluations of the NCSN++ ("rectified") net at the reference's 256^2 config, synthetic weights.
+    Forward only: the reference's PnP-Flow schedule starts at t = 0 where this net's log-sigma conditioning is singular, and its
+    OT-ODE use needs the VJP, which is not built - so the measured unit is model(x, t * 999) itself."""
+    from pnpflow_amd.image_generation.configs.rectified_flow.afhq_cat_pytorch_rf_gaussian import get_config
+    from pnpflow_amd.image_generation.models.ncsnpp import NCSNpp
+    from tools.synthetic_weights import synthetic_state_dict
+    m = NCSNpp(get_config(), device_index=dev.index or 0)
+    m.load_state_dict(synthetic_state_dict(m))
+    g = torch.Generator(device="cpu"); g.manual_seed(0)
+    x = torch.randn(B, 3, 256, 256, generator=g).to(dev); lab = torch.full((B,), 0.5 * 999, device=dev)
+    m(x, lab); torch.cuda.synchronize(); m.check_numerics()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m(x, lab)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    flop = 0.5318e12          # convs + attention matmuls per 256^2 image, from the module list (DESIGN.md 4.10)
+    rec = {"workload": f"NCSN++ rectified-flow net (nf 128, 7 levels, 65.6 M parameters) forward at 256x256, B={B}",
+           "images_per_s": round(B / dt, 2), "ms_per_forward": round(dt * 1e3, 1), "algorithmic_tflops": round(B * flop / dt / 1e12, 1),
+           "frac_of_2p5pf": round(B * flop / dt / 2.5e15, 4)}
+    del m
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -440,6 +465,7 @@ def main():
                     rec["cpu_baseline"] = cpu_baseline_ot_ode(w2, budget_s=12.0)
                 extra[name] = rec
                 del rr
+            extra["n4_ncsnpp_forward"] = ncsnpp_forward_block(dev)
             out["configs"] = extra
             out["pointwise"] = pointwise_block(dev, D)
         print(json.dumps(out), flush=True)

@@ -80,7 +80,7 @@ typedef struct pf_ncsnpp_cfg {
 /* replaces mutils.create_model(config) (models/utils.py:91-103).  The handle is a pf_engine: weights are loaded with
  * pf_engine_load_weight under NCSNpp's own state_dict keys ("all_modules.<i>.<...>", without DataParallel's "module."),
  * pf_unet_forward(e, x, labels, out, B, stream) is model(x, labels) with labels = the reference's time_cond (t * 999,
- * methods/pnp_flow.py:23-27).  The VJP entry points return PF_ERR_INVALID for this net. */
+ * methods/pnp_flow.py:23-27); pf_unet_forward_retain / pf_unet_backward give its input-gradient VJP (ot_ode.py:137-138). */
 int pf_ncsnpp_create(int device_id, const pf_ncsnpp_cfg* cfg, pf_engine** out);
 /* label = t * scale inside pf_pnp_flow_restore / pf_ot_ode_restore (PNP_FLOW.model_forward: `t * 999`); 1 for the OT net */
 int pf_engine_set_solver_time_scale(pf_engine* e, float scale);

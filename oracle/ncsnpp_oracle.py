@@ -164,11 +164,22 @@ def _attn_block(sd, P, x, skip_rescale):
 def ncsnpp_forward(sd: Dict[str, torch.Tensor], cfg: dict, x: torch.Tensor, time_cond: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
     """NCSNpp.forward (ncsnpp.py:219-383) for data.centered = True; `time_cond` is what the solvers pass as `t * 999`
     (methods/pnp_flow.py:23-27).  `taps`, when given, receives named intermediate activations."""
+    with torch.no_grad():
+        return _forward(sd, cfg, x, time_cond, taps)
+
+
+def ncsnpp_vjp(sd: Dict[str, torch.Tensor], cfg: dict, x: torch.Tensor, time_cond: torch.Tensor, vec: torch.Tensor) -> torch.Tensor:
+    """J^T vec w.r.t. the image, as OT_ODE takes it: torch.autograd.functional.vjp(lambda x: model_forward(x, t), x, vec)[1]
+    (ot_ode.py:137-138) - autograd through the restated forward."""
+    return torch.autograd.functional.vjp(lambda z: _forward(sd, cfg, z, time_cond, None), x, vec)[1]
+
+
+def _forward(sd, cfg, x, time_cond, taps):
     mods = _modules(cfg)
     fir, sr = cfg["fir_kernel"], cfg["skip_rescale"]
     nlev, nres = len(cfg["ch_mult"]), cfg["num_res_blocks"]
     name = lambda i: f"all_modules.{i}."
-    with torch.no_grad():
+    if True:
         # Gaussian Fourier features of log(sigma) (ncsnpp.py:226-230; layerspp.py:39-41), then the conditioning MLP (:240-246)
         used_sigmas = time_cond
         x_proj = torch.log(used_sigmas)[:, None] * sd[name(0) + "W"][None, :] * 2 * np.pi

@@ -60,13 +60,21 @@ struct Op {
     float F = 0.f;
 };
 
-enum TapeKind { TP_RES, TP_ATTN, TP_DOWN, TP_UP };
+enum TapeKind { TP_RES, TP_ATTN, TP_DOWN, TP_UP,
+                // NCSN++ (engine_ncsnpp.inc): BigGAN block, input conv, input-pyramid FIR step, output-skip conv (+ pyramid FIR step)
+                TP_NX_RES, TP_NX_CONV_IN, TP_NX_PYR_DOWN, TP_NX_OUT_SKIP };
 struct TapeRec {
     TapeKind kind;
     const ResDesc* r = nullptr;
     std::string pfx;
     Tensor in0, in1, h1, out, qkv, S, o;
     bool has_in1 = false;
+    // attention variants: GroupNorm groups and the (x + h) * s of AttnBlockpp
+    int groups = 32; float s = 1.0f;
+    // NCSN++ records
+    int idx = 0;                       // module index (all_modules.<idx>)
+    Tensor hact, xres, pyr, pyr_old;   // FIR views of a resampling block; Combine input; output pyramid before this level
+    bool resample = false, up = false, has_pyr = false, has_old = false;
 };
 
 struct Tap { std::string name; Tensor t; };
@@ -90,6 +98,7 @@ struct Plan {
     std::vector<Op> bops;
     size_t bwd_flops = 0;
     float* vec_scaled = nullptr; float* vjp_scale = nullptr; unsigned int* vjp_amax = nullptr;   // VJP input normalisation
+    float* nx_sigma = nullptr;         // NCSN++ retained forward: the divisor t * t_scale of its output, per image (read by the backward)
 };
 
 struct SolverBufs {
@@ -568,7 +577,7 @@ static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x, i
     }
     bd.release(qkv.p); if (S.p) bd.release(S.p); bd.release(o.p);
     if (bd.plan->retain) {
-        TapeRec tr; tr.kind = TP_ATTN; tr.pfx = pfx; tr.in0 = x; tr.qkv = qkv; tr.S = S; tr.o = o; tr.out = out;
+        TapeRec tr; tr.kind = TP_ATTN; tr.pfx = pfx; tr.in0 = x; tr.qkv = qkv; tr.S = S; tr.o = o; tr.out = out; tr.groups = groups; tr.s = s_out;
         bd.plan->tape.push_back(tr);
     }
     return out;
@@ -604,6 +613,7 @@ static void fix_stats(Op& op, double* slab) {
 }
 
 static int build_backward(pf_engine* e, Plan* plan, struct Builder& bd);
+static int nx_build_backward(pf_engine* e, Plan* plan, struct Builder& bd);
 
 // the OT U-Net's forward walk (models.py:442-495): op 1 = time embedding, ...
 static int unet_walk(pf_engine* e, Builder& bd, Plan* plan) {
@@ -742,14 +752,13 @@ static int build_plan(pf_engine* e, int B, bool retain, Plan** out_plan) {
     // op 0: zero the statistics slab (filled in below)
     { Op op{}; op.kind = OP_MEMSET; plan->ops.push_back(op); }
     if (e->arch == 1) {
-        if (retain) { e->err = "the VJP of the NCSN++ net is not built"; return PF_ERR_INVALID; }
         int rc = nx_walk(e, bd, plan.get());
         if (rc != PF_OK) return rc;
     } else {
         int rc = unet_walk(e, bd, plan.get());
         if (rc != PF_OK) return rc;
     }
-    if (retain) { int rc = build_backward(e, plan.get(), bd); if (rc != PF_OK) return rc; }
+    if (retain) { int rc = e->arch == 1 ? nx_build_backward(e, plan.get(), bd) : build_backward(e, plan.get(), bd); if (rc != PF_OK) return rc; }
     if (!bd.ok) return PF_ERR_HIP;
     for (auto& kv : e->dev) if (kv.second == nullptr) { e->err = "weight upload failed: " + kv.first; return PF_ERR_HIP; }
     // statistics slab
@@ -856,11 +865,11 @@ struct GnBwd {
     std::vector<bool> fused;
 };
 
-static GnBwd gn_bwd_begin(BwdCtx& c, const std::vector<Tensor>& srcs, const std::string& norm_prefix, bool silu) {
+static GnBwd gn_bwd_begin(BwdCtx& c, const std::vector<Tensor>& srcs, const std::string& norm_prefix, bool silu, int groups = 32) {
     pf_engine* e = c.e; const int B = c.B;
     GnBwd g; g.srcs = srcs; g.silu = silu; g.HW = srcs[0].H * srcs[0].W;
     for (auto& t : srcs) g.Ct += t.C;
-    g.cpg = g.Ct / 32; g.fused.assign(srcs.size(), false);
+    g.cpg = g.Ct / groups; g.fused.assign(srcs.size(), false);
     g.mu = c.fvec((size_t)B * g.Ct); g.rs = c.fvec((size_t)B * g.Ct); g.m1 = c.fvec((size_t)B * g.Ct); g.m2 = c.fvec((size_t)B * g.Ct);
     g.bsum = c.dsum((size_t)B * g.Ct * 2);
     g.gamma = upload(e, norm_prefix + "weight", W(e, norm_prefix + "weight").data);
@@ -884,7 +893,7 @@ static bool gn_bwd_fuse(BwdCtx& c, GnBwd& g, size_t j, ConvParams& p, int stride
 }
 
 static void gn_bwd_finish(BwdCtx& c, GnBwd& g, const std::vector<Tensor>& gtmp, const std::vector<GradEntry*>& dst,
-                          const std::vector<const float*>& add) {
+                          const std::vector<const float*>& add, float add_scale = 1.0f) {
     int coff = 0;
     for (size_t j = 0; j < g.srcs.size(); ++j) {
         if (!g.fused[j]) {
@@ -897,7 +906,7 @@ static void gn_bwd_finish(BwdCtx& c, GnBwd& g, const std::vector<Tensor>& gtmp, 
     coff = 0;
     for (size_t j = 0; j < g.srcs.size(); ++j) {
         Op op{}; op.kind = OP_GN_BWD_POST; op.P[0] = gtmp[j].p; op.P[1] = g.srcs[j].p; op.P[2] = g.mu; op.P[3] = g.rs; op.P[4] = g.m1; op.P[5] = g.m2;
-        op.P[7] = add[j]; op.O = dst[j]->t.p; op.I[0] = g.HW; op.I[1] = g.srcs[j].C; op.I[2] = coff; op.I[3] = g.Ct; op.I[4] = dst[j]->has ? 1 : 0;
+        op.P[7] = add[j]; op.F = add_scale; op.O = dst[j]->t.p; op.I[0] = g.HW; op.I[1] = g.srcs[j].C; op.I[2] = coff; op.I[3] = g.Ct; op.I[4] = dst[j]->has ? 1 : 0;
         dst[j]->has = true; c.push(op);
         coff += g.srcs[j].C;
     }
@@ -908,6 +917,47 @@ static void gn_backward(BwdCtx& c, const std::vector<Tensor>& srcs, const std::v
                         const std::vector<const float*>& add, const std::string& norm_prefix, bool silu) {
     GnBwd g = gn_bwd_begin(c, srcs, norm_prefix, silu);
     gn_bwd_finish(c, g, gtmp, dst, add);
+}
+
+// SelfAttention / AttnBlockpp backward (models.py:145-162; layerspp.py:76-94: out = (x + proj(attn(norm(x)))) * s)
+static void bwd_attn(BwdCtx& c, const TapeRec& tr, GradEntry& gout) {
+    pf_engine* e = c.e; Builder& bd = *c.bd; const int B = c.B;
+    const int H = tr.out.H, Wd = tr.out.W;
+    const Tensor& x = tr.in0; const int C = x.C, HW = H * Wd;
+    const float scale = 1.0f / sqrtf((float)C);
+    // d(o) = dout . Wproj
+    Tensor d_o = c.tmp(C, H, Wd);
+    { ConvParams p = bwd_params(B, H, Wd, H, Wd, C);
+      raw_seg(p, gout.t.p, C, C, 1, packed_conv_T(e, tr.pfx + "proj_out.weight", 0, C), packed_conv16_T(e, tr.pfx + "proj_out.weight", 0, C)); p.out = d_o.p; p.out_cstride = C;
+      p.out_scale = tr.s; c.conv_plain(p); }
+    // dA[i][j] = sum_c d_o[i][c] v[j][c]
+    Tensor dA = c.tmp(HW, H, Wd);
+    { ConvParams p = bwd_params(B, H, Wd, H, Wd, HW);
+      gen_seg(p, d_o.p, C, C, tr.qkv.p + 2 * C, (int64_t)HW * 3 * C, 3 * C, 1); p.out = dA.p; p.out_cstride = HW; c.conv_plain(p); }
+    Tensor dqkv = c.tmp(3 * C, H, Wd);
+    // dv[j][c] = sum_i A[i][j] d_o[i][c]   (A^T as the pixel-major operand)
+    Tensor AT = c.tmp(HW, H, Wd);
+    { Op op{}; op.kind = OP_TRANSPOSE; op.P[0] = tr.S.p; op.O = AT.p; op.I[0] = HW; op.I[1] = HW; c.push(op); }
+    { ConvParams p = bwd_params(B, H, Wd, H, Wd, C);
+      gen_seg(p, AT.p, HW, HW, d_o.p, (int64_t)HW * C, 1, C); p.out = dqkv.p + 2 * C; p.out_cstride = 3 * C; c.conv_plain(p); }
+    // dS = scale * A .* (dA - rowsum(dA .* A))   in place
+    { Op op{}; op.kind = OP_SOFTMAX_BWD; op.P[0] = tr.S.p; op.O = dA.p; op.sm_rows = (int64_t)B * HW; op.sm_cols = HW; op.F = scale; c.push(op); }
+    // dq[i][c] = sum_j dS[i][j] k[j][c]
+    { ConvParams p = bwd_params(B, H, Wd, H, Wd, C);
+      gen_seg(p, dA.p, HW, HW, tr.qkv.p + C, (int64_t)HW * 3 * C, 1, 3 * C); p.out = dqkv.p; p.out_cstride = 3 * C; c.conv_plain(p); }
+    // dk[j][c] = sum_i dS[i][j] q[i][c]
+    { Op op{}; op.kind = OP_TRANSPOSE; op.P[0] = dA.p; op.O = AT.p; op.I[0] = HW; op.I[1] = HW; c.push(op); }
+    { ConvParams p = bwd_params(B, H, Wd, H, Wd, C);
+      gen_seg(p, AT.p, HW, HW, tr.qkv.p, (int64_t)HW * 3 * C, 1, 3 * C); p.out = dqkv.p + C; p.out_cstride = 3 * C; c.conv_plain(p); }
+    // d(hn) = dqkv . Wqkv ; GroupNorm backward (no activation) ; + identity path
+    Tensor dhn = c.tmp(C, H, Wd);
+    GnBwd gna = gn_bwd_begin(c, {x}, tr.pfx + "norm.", false, tr.groups);
+    { ConvParams p = bwd_params(B, H, Wd, H, Wd, C);
+      raw_seg(p, dqkv.p, 3 * C, 3 * C, 1, packed_conv_T(e, tr.pfx + "qkv.w", 0, C), packed_conv16_T(e, tr.pfx + "qkv.w", 0, C)); p.out = dhn.p; p.out_cstride = C;
+      gn_bwd_fuse(c, gna, 0, p);
+      c.conv_plain(p); }
+    gn_bwd_finish(c, gna, {dhn}, {&c.G(x)}, {gout.t.p}, tr.s);
+    for (float* q : {d_o.p, dA.p, dqkv.p, AT.p, dhn.p}) bd.recycle(q);
 }
 
 static int build_backward(pf_engine* e, Plan* plan, Builder& bd) {
@@ -1000,40 +1050,7 @@ static int build_backward(pf_engine* e, Plan* plan, Builder& bd) {
             for (auto& u : us) bd.recycle(u.p);
             bd.recycle(gh1.t.p);
         } else {   // TP_ATTN  (models.py:145-162)
-            const Tensor& x = tr.in0; const int C = x.C, HW = H * Wd;
-            const float scale = 1.0f / sqrtf((float)C);
-            // d(o) = dout . Wproj
-            Tensor d_o = c.tmp(C, H, Wd);
-            { ConvParams p = bwd_params(B, H, Wd, H, Wd, C);
-              raw_seg(p, gout.t.p, C, C, 1, packed_conv_T(e, tr.pfx + "proj_out.weight", 0, C), packed_conv16_T(e, tr.pfx + "proj_out.weight", 0, C)); p.out = d_o.p; p.out_cstride = C; c.conv_plain(p); }
-            // dA[i][j] = sum_c d_o[i][c] v[j][c]
-            Tensor dA = c.tmp(HW, H, Wd);
-            { ConvParams p = bwd_params(B, H, Wd, H, Wd, HW);
-              gen_seg(p, d_o.p, C, C, tr.qkv.p + 2 * C, (int64_t)HW * 3 * C, 3 * C, 1); p.out = dA.p; p.out_cstride = HW; c.conv_plain(p); }
-            Tensor dqkv = c.tmp(3 * C, H, Wd);
-            // dv[j][c] = sum_i A[i][j] d_o[i][c]   (A^T as the pixel-major operand)
-            Tensor AT = c.tmp(HW, H, Wd);
-            { Op op{}; op.kind = OP_TRANSPOSE; op.P[0] = tr.S.p; op.O = AT.p; op.I[0] = HW; op.I[1] = HW; c.push(op); }
-            { ConvParams p = bwd_params(B, H, Wd, H, Wd, C);
-              gen_seg(p, AT.p, HW, HW, d_o.p, (int64_t)HW * C, 1, C); p.out = dqkv.p + 2 * C; p.out_cstride = 3 * C; c.conv_plain(p); }
-            // dS = scale * A .* (dA - rowsum(dA .* A))   in place
-            { Op op{}; op.kind = OP_SOFTMAX_BWD; op.P[0] = tr.S.p; op.O = dA.p; op.sm_rows = (int64_t)B * HW; op.sm_cols = HW; op.F = scale; c.push(op); }
-            // dq[i][c] = sum_j dS[i][j] k[j][c]
-            { ConvParams p = bwd_params(B, H, Wd, H, Wd, C);
-              gen_seg(p, dA.p, HW, HW, tr.qkv.p + C, (int64_t)HW * 3 * C, 1, 3 * C); p.out = dqkv.p; p.out_cstride = 3 * C; c.conv_plain(p); }
-            // dk[j][c] = sum_i dS[i][j] q[i][c]
-            { Op op{}; op.kind = OP_TRANSPOSE; op.P[0] = dA.p; op.O = AT.p; op.I[0] = HW; op.I[1] = HW; c.push(op); }
-            { ConvParams p = bwd_params(B, H, Wd, H, Wd, C);
-              gen_seg(p, AT.p, HW, HW, tr.qkv.p, (int64_t)HW * 3 * C, 1, 3 * C); p.out = dqkv.p + C; p.out_cstride = 3 * C; c.conv_plain(p); }
-            // d(hn) = dqkv . Wqkv ; GroupNorm backward (no activation) ; + identity path
-            Tensor dhn = c.tmp(C, H, Wd);
-            GnBwd gna = gn_bwd_begin(c, {x}, tr.pfx + "norm.", false);
-            { ConvParams p = bwd_params(B, H, Wd, H, Wd, C);
-              raw_seg(p, dqkv.p, 3 * C, 3 * C, 1, packed_conv_T(e, tr.pfx + "qkv.w", 0, C), packed_conv16_T(e, tr.pfx + "qkv.w", 0, C)); p.out = dhn.p; p.out_cstride = C;
-              gn_bwd_fuse(c, gna, 0, p);
-              c.conv_plain(p); }
-            gn_bwd_finish(c, gna, {dhn}, {&c.G(x)}, {gout.t.p});
-            for (float* q : {d_o.p, dA.p, dqkv.p, AT.p, dhn.p}) bd.recycle(q);
+            bwd_attn(c, tr, gout);
         }
     }
     // ---- begin: h0 = conv3x3(x) (models.py:451): g = adjoint conv (ch -> image), NCHW out ------------------
@@ -1053,6 +1070,8 @@ static int build_backward(pf_engine* e, Plan* plan, Builder& bd) {
     plan->bops[0].bytes = bd.stats_bytes - bwd_lo;
     return PF_OK;
 }
+
+#include "engine_ncsnpp_bwd.inc"
 
 static hipError_t dispatch_conv(pf_engine* e, const Op& op, hipStream_t s);
 static int run_backward(pf_engine* e, Plan* plan, const float* vec, float* g, hipStream_t s) {
@@ -1080,10 +1099,13 @@ static int run_backward(pf_engine* e, Plan* plan, const float* vec, float* g, hi
                 r = launch_gn_bwd_coeffs((const double*)op.P[6], op.I[0], op.I[1], op.I[2], (float*)op.P[1], (float*)op.P[2], B, s); break;
             case OP_GN_BWD_POST:
                 r = launch_gn_bwd_post((const float*)op.P[0], (const float*)op.P[1], (const float*)op.P[2], (const float*)op.P[3], (const float*)op.P[4],
-                                       (const float*)op.P[5], (const float*)op.P[7], (float*)op.O, B, op.I[0], op.I[1], op.I[2], op.I[3], op.I[4], s); break;
+                                       (const float*)op.P[5], (const float*)op.P[7], (float*)op.O, B, op.I[0], op.I[1], op.I[2], op.I[3], op.I[4], s, op.F); break;
             case OP_TRANSPOSE: r = launch_transpose((const float*)op.P[0], (float*)op.O, B, op.I[0], op.I[1], s); break;
             case OP_SOFTMAX_BWD: r = launch_softmax_bwd((const float*)op.P[0], (float*)op.O, op.sm_rows, op.sm_cols, op.F, s); break;
             case OP_SUMPOOL: r = launch_sumpool2((const float*)op.P[0], (float*)op.O, B, op.I[0], op.I[1], op.I[2], op.I[3], s); break;
+            case OP_NX_IMG_IN: r = launch_img_to_nhwc32(vec, (float*)op.O, B, op.I[0], op.I[1], op.I[2], s, (const float*)op.P[0]); break;
+            case OP_NX_FIR: r = launch_fir_nhwc(op.fp, s); break;
+            case OP_NX_IMG_OUT: r = launch_nhwc32_to_img((const float*)op.P[0], g, (const float*)op.P[1], 1.0f, op.P[1] != nullptr ? 1 : 0, B, op.I[0], op.I[1], op.I[2], s); break;
             default: break;
         }
         if (r != hipSuccess) { e->err = std::string("backward launch failed: ") + hipGetErrorString(r); return PF_ERR_HIP; }
@@ -1140,7 +1162,7 @@ static int run_plan(pf_engine* e, Plan* plan, const float* x, const float* t, fl
             case OP_NX_TEMB: { NxTembParams tp = op.ntp; tp.t = t; tp.t_scale = t_scale; r = launch_nx_temb(tp, s); break; }
             case OP_NX_IMG_IN: r = launch_img_to_nhwc32(x, (float*)op.O, plan->B, op.I[0], op.I[1], op.I[2], s); break;
             case OP_NX_FIR: r = launch_fir_nhwc(op.fp, s); break;
-            case OP_NX_IMG_OUT: r = launch_nhwc32_to_img((const float*)op.P[0], v, t, t_scale, op.I[3], plan->B, op.I[0], op.I[1], op.I[2], s); break;
+            case OP_NX_IMG_OUT: r = launch_nhwc32_to_img((const float*)op.P[0], v, t, t_scale, op.I[3], plan->B, op.I[0], op.I[1], op.I[2], s, (float*)op.O); break;
             default: break;
         }
         if (r != hipSuccess) { e->err = std::string("kernel launch failed: ") + hipGetErrorString(r); return PF_ERR_HIP; }

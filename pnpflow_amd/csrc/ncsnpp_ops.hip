@@ -141,8 +141,9 @@ hipError_t launch_nx_temb(const NxTembParams& p, hipStream_t s) {
 }
 
 // ---- image boundary ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void img_to_nhwc32_kernel(const float* __restrict__ img, float* __restrict__ out, int Cimg, int HW) {
+__global__ __launch_bounds__(256) void img_to_nhwc32_kernel(const float* __restrict__ img, float* __restrict__ out, int Cimg, int HW, const float* __restrict__ div) {
     const int b = blockIdx.y;
+    const float dv = div != nullptr ? div[b] : 1.0f;
     const size_t n4 = (size_t)HW * 8;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const int q = (int)(i & 7); const size_t pix = i >> 3;
@@ -153,21 +154,23 @@ __global__ __launch_bounds__(256) void img_to_nhwc32_kernel(const float* __restr
             if (Cimg > 1) v.y = src[HW];
             if (Cimg > 2) v.z = src[2 * (size_t)HW];
             if (Cimg > 3) v.w = src[3 * (size_t)HW];
+            if (div != nullptr) { v.x /= dv; v.y /= dv; v.z /= dv; v.w /= dv; }
         }
         reinterpret_cast<float4*>(out + (size_t)b * HW * 32)[i] = v;
     }
 }
-hipError_t launch_img_to_nhwc32(const float* img, float* out, int B, int Cimg, int H, int W, hipStream_t s) {
+hipError_t launch_img_to_nhwc32(const float* img, float* out, int B, int Cimg, int H, int W, hipStream_t s, const float* div) {
     if (Cimg < 1 || Cimg > 4) return hipErrorInvalidValue;
     const size_t n4 = (size_t)H * W * 8;
-    hipLaunchKernelGGL(img_to_nhwc32_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 4096), B), dim3(256), 0, s, img, out, Cimg, H * W);
+    hipLaunchKernelGGL(img_to_nhwc32_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 4096), B), dim3(256), 0, s, img, out, Cimg, H * W, div);
     return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void nhwc32_to_img_kernel(const float* __restrict__ in, float* __restrict__ img, const float* __restrict__ t,
-                                                          float t_scale, int scale_by_sigma, int Cimg, int HW) {
+                                                          float t_scale, int scale_by_sigma, int Cimg, int HW, float* __restrict__ sigma_out) {
     const int b = blockIdx.y;
     const float sig = scale_by_sigma ? t[b] * t_scale : 1.0f;
+    if (sigma_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) sigma_out[b] = sig;
     for (int pix = blockIdx.x * 256 + threadIdx.x; pix < HW; pix += gridDim.x * 256) {
         const float4 v = *reinterpret_cast<const float4*>(in + ((size_t)b * HW + pix) * 32);
         float* dst = img + (size_t)b * Cimg * HW + pix;
@@ -176,10 +179,10 @@ __global__ __launch_bounds__(256) void nhwc32_to_img_kernel(const float* __restr
     }
 }
 hipError_t launch_nhwc32_to_img(const float* in, float* img, const float* t, float t_scale, int scale_by_sigma, int B, int Cimg, int H, int W,
-                                hipStream_t s) {
+                                hipStream_t s, float* sigma_out) {
     if (Cimg < 1 || Cimg > 4) return hipErrorInvalidValue;
     hipLaunchKernelGGL(nhwc32_to_img_kernel, dim3((unsigned)std::min((H * W + 255) / 256, 4096), B), dim3(256), 0, s, in, img, t, t_scale,
-                       scale_by_sigma, Cimg, H * W);
+                       scale_by_sigma, Cimg, H * W, sigma_out);
     return hipGetLastError();
 }
 

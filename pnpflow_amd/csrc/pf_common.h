@@ -128,7 +128,7 @@ hipError_t launch_gn_bwd_pre(float* g, const float* x, const float* mu, const fl
                              int B, int HW, int C, int coff, int Ct, int silu, hipStream_t s);
 hipError_t launch_gn_bwd_coeffs(const double* bsum, int Ct, int cpg, int HW, float* m1, float* m2, int B, hipStream_t s);
 hipError_t launch_gn_bwd_post(const float* dy, const float* x, const float* mu, const float* rs, const float* m1, const float* m2,
-                              const float* add, float* out, int B, int HW, int C, int coff, int Ct, int accumulate, hipStream_t s);
+                              const float* add, float* out, int B, int HW, int C, int coff, int Ct, int accumulate, hipStream_t s, float add_scale = 1.0f);
 hipError_t launch_transpose(const float* in, float* out, int B, int R, int Cc, hipStream_t s);
 hipError_t launch_softmax_bwd(const float* A, float* dA, int64_t rows, int cols, float scale, hipStream_t s);
 hipError_t launch_sumpool2(const float* in, float* out, int B, int H, int W, int C, int accumulate, hipStream_t s);
@@ -199,8 +199,8 @@ hipError_t launch_nx_temb(const NxTembParams& p, hipStream_t s);
 
 // image boundary: NCHW image -> zero-padded NHWC-32 operand of the MFMA conv, and back (the first Cimg channels of the NHWC-32
 // output-skip pyramid, divided by sigma = t * t_scale when scale_by_sigma; ncsnpp.py:378-381)
-hipError_t launch_img_to_nhwc32(const float* img, float* out, int B, int Cimg, int H, int W, hipStream_t s);
+hipError_t launch_img_to_nhwc32(const float* img, float* out, int B, int Cimg, int H, int W, hipStream_t s, const float* div = nullptr /* [B]: image b is divided by div[b] */);
 hipError_t launch_nhwc32_to_img(const float* in, float* img, const float* t, float t_scale, int scale_by_sigma, int B, int Cimg, int H, int W,
-                                hipStream_t s);
+                                hipStream_t s, float* sigma_out = nullptr /* [B] <- the divisor used (kept for the VJP) */);
 
 }  // namespace pf

@@ -117,7 +117,7 @@ template <bool HAS_ADD, bool ACC>
 __global__ __launch_bounds__(256) void gn_bwd_post_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mu,
                                                           const float* __restrict__ rs, const float* __restrict__ m1, const float* __restrict__ m2,
                                                           const float* __restrict__ add, float* out, int HW, int C, int coff, int Ct,
-                                                          int pix_per_block) {
+                                                          int pix_per_block, float add_scale) {
     const int b = blockIdx.y, tid = threadIdx.x;
     const int cq = C / 4, lanes_p = 256 / cq;
     const int q = tid % cq, pr = tid / cq;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void gn_bwd_post_kernel(const float* __restric
                 r.y = r4.y * (dv[k].y - a4.y - (xv[k].y - m4.y) * r4.y * b4.y);
                 r.z = r4.z * (dv[k].z - a4.z - (xv[k].z - m4.z) * r4.z * b4.z);
                 r.w = r4.w * (dv[k].w - a4.w - (xv[k].w - m4.w) * r4.w * b4.w);
-                if constexpr (HAS_ADD) { r.x += av[k].x; r.y += av[k].y; r.z += av[k].z; r.w += av[k].w; }
+                if constexpr (HAS_ADD) { r.x = fmaf(av[k].x, add_scale, r.x); r.y = fmaf(av[k].y, add_scale, r.y); r.z = fmaf(av[k].z, add_scale, r.z); r.w = fmaf(av[k].w, add_scale, r.w); }
                 if constexpr (ACC) { r.x += ov[k].x; r.y += ov[k].y; r.z += ov[k].z; r.w += ov[k].w; }
                 *reinterpret_cast<float4*>(out + ((size_t)b * HW + pix + k * lanes_p) * C + q * 4) = r;
             }
@@ -174,14 +174,14 @@ hipError_t launch_gn_bwd_coeffs(const double* bsum, int Ct, int cpg, int HW, flo
     return hipGetLastError();
 }
 hipError_t launch_gn_bwd_post(const float* dy, const float* x, const float* mu, const float* rs, const float* m1, const float* m2,
-                              const float* add, float* out, int B, int HW, int C, int coff, int Ct, int accumulate, hipStream_t s) {
+                              const float* add, float* out, int B, int HW, int C, int coff, int Ct, int accumulate, hipStream_t s, float add_scale) {
     if (C % 4 || C / 4 > 256) return hipErrorInvalidValue;
     const int ppb = 1024;
     const dim3 grid((HW + ppb - 1) / ppb, B);
-    if (add != nullptr && accumulate) hipLaunchKernelGGL((gn_bwd_post_kernel<true, true>), grid, dim3(256), 0, s, dy, x, mu, rs, m1, m2, add, out, HW, C, coff, Ct, ppb);
-    else if (add != nullptr) hipLaunchKernelGGL((gn_bwd_post_kernel<true, false>), grid, dim3(256), 0, s, dy, x, mu, rs, m1, m2, add, out, HW, C, coff, Ct, ppb);
-    else if (accumulate) hipLaunchKernelGGL((gn_bwd_post_kernel<false, true>), grid, dim3(256), 0, s, dy, x, mu, rs, m1, m2, add, out, HW, C, coff, Ct, ppb);
-    else hipLaunchKernelGGL((gn_bwd_post_kernel<false, false>), grid, dim3(256), 0, s, dy, x, mu, rs, m1, m2, add, out, HW, C, coff, Ct, ppb);
+    if (add != nullptr && accumulate) hipLaunchKernelGGL((gn_bwd_post_kernel<true, true>), grid, dim3(256), 0, s, dy, x, mu, rs, m1, m2, add, out, HW, C, coff, Ct, ppb, add_scale);
+    else if (add != nullptr) hipLaunchKernelGGL((gn_bwd_post_kernel<true, false>), grid, dim3(256), 0, s, dy, x, mu, rs, m1, m2, add, out, HW, C, coff, Ct, ppb, add_scale);
+    else if (accumulate) hipLaunchKernelGGL((gn_bwd_post_kernel<false, true>), grid, dim3(256), 0, s, dy, x, mu, rs, m1, m2, add, out, HW, C, coff, Ct, ppb, add_scale);
+    else hipLaunchKernelGGL((gn_bwd_post_kernel<false, false>), grid, dim3(256), 0, s, dy, x, mu, rs, m1, m2, add, out, HW, C, coff, Ct, ppb, add_scale);
     return hipGetLastError();
 }
 

@@ -7,7 +7,7 @@ ncsnpp.py:34-383), executed by the HIP engine (csrc/engine_ncsnpp.inc, ncsnpp_op
 
 Built: the block list both rectified-flow configs of the reference select (BigGAN blocks, FIR resampling, input_skip / output_skip
 with `sum`, Fourier conditioning, skip_rescale, scale_by_sigma).  Any other value of those switches raises NotImplementedError.
-Forward only: the VJP entry points of the engine reject this net.
+`forward_retain` / `backward` / `vjp` give the input-gradient VJP OT_ODE needs (ot_ode.py:137-138).
 """
 from __future__ import annotations
 

@@ -66,8 +66,8 @@ class OT_ODE(object):
         iterations in `cb_iterations` (None = every iteration)."""
         args = self.args
         problem = args.problem
-        if args.model == "rectified":
-            raise NotImplementedError("ot_ode needs the VJP of the velocity net (ot_ode.py:137-138); the NCSN++ engine is forward-only")
+        if hasattr(self.model, "set_solver_time_scale"):
+            self.model.set_solver_time_scale(999.0 if args.model == "rectified" else 1.0)       # model_fn(x, t * 999), ot_ode.py:21-25
         if problem not in ("denoising", "inpainting", "random_inpainting", "paintbrush_inpainting", "superresolution", "gaussian_deblurring_FFT"):
             # the reference's remaining branch is a per-image GMRES on H H^T (ot_ode.py:118-128); none of its operators reach it
             raise NotImplementedError(f"ot_ode linear solve for '{problem}' is not implemented by this engine")

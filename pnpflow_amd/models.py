@@ -77,6 +77,29 @@ class _EngineNet:
                    self._h, "pf_unet_forward")
         return v
 
+    def forward_retain(self, x: torch.Tensor, temp: torch.Tensor) -> torch.Tensor:
+        """Forward that keeps every activation on the device, for a following `backward`."""
+        x = x.contiguous().float(); t = temp.contiguous().float().to(x.device)
+        B = x.shape[0]
+        v = torch.empty((B, self.output_channels, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
+        _lib.check(self._lib.pf_unet_forward_retain(self._h, x.data_ptr(), t.data_ptr(), v.data_ptr(), B, _lib.current_stream_ptr()),
+                   self._h, "pf_unet_forward_retain")
+        return v
+
+    def backward(self, vec: torch.Tensor) -> torch.Tensor:
+        """J^T vec (input gradient) at the last `forward_retain`."""
+        vec = vec.contiguous().float()
+        g = torch.empty((vec.shape[0], self.input_channels, vec.shape[2], vec.shape[3]), dtype=torch.float32, device=vec.device)
+        _lib.check(self._lib.pf_unet_backward(self._h, vec.data_ptr(), g.data_ptr(), vec.shape[0], _lib.current_stream_ptr()),
+                   self._h, "pf_unet_backward")
+        return g
+
+    def vjp(self, x: torch.Tensor, temp: torch.Tensor, vec: torch.Tensor):
+        """(v_theta(x,t), J^T vec) - what torch.autograd.functional.vjp(lambda z: model(z,t), x, vec) returns
+        (reference pnpflow/methods/ot_ode.py:137-138)."""
+        v = self.forward_retain(x, temp)
+        return v, self.backward(vec)
+
     # ---- debugging: named internal activations of the last forward (NCHW numpy) -----------
     def read_taps(self, B):
         """Internal activations of the last forward as {name: (B,C,H,W) numpy}.  Only
@@ -152,26 +175,3 @@ class UNet(_EngineNet):
         self._h = h
         self._loaded = False
         self.training = False
-
-    def forward_retain(self, x: torch.Tensor, temp: torch.Tensor) -> torch.Tensor:
-        """Forward that keeps every activation on the device, for a following `backward`."""
-        x = x.contiguous().float(); t = temp.contiguous().float().to(x.device)
-        B = x.shape[0]
-        v = torch.empty((B, self.output_channels, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device)
-        _lib.check(self._lib.pf_unet_forward_retain(self._h, x.data_ptr(), t.data_ptr(), v.data_ptr(), B, _lib.current_stream_ptr()),
-                   self._h, "pf_unet_forward_retain")
-        return v
-
-    def backward(self, vec: torch.Tensor) -> torch.Tensor:
-        """J^T vec (input gradient) at the last `forward_retain`."""
-        vec = vec.contiguous().float()
-        g = torch.empty((vec.shape[0], self.input_channels, vec.shape[2], vec.shape[3]), dtype=torch.float32, device=vec.device)
-        _lib.check(self._lib.pf_unet_backward(self._h, vec.data_ptr(), g.data_ptr(), vec.shape[0], _lib.current_stream_ptr()),
-                   self._h, "pf_unet_backward")
-        return g
-
-    def vjp(self, x: torch.Tensor, temp: torch.Tensor, vec: torch.Tensor):
-        """(v_theta(x,t), J^T vec) - what torch.autograd.functional.vjp(lambda z: model(z,t), x, vec) returns
-        (reference pnpflow/methods/ot_ode.py:137-138)."""
-        v = self.forward_retain(x, temp)
-        return v, self.backward(vec)

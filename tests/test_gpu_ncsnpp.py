@@ -126,11 +126,7 @@ def test_ncsnpp_checkpoint_key_forms_and_errors():
     bad = dict(sd); bad.pop("all_modules.4.Conv_0.weight")
     with pytest.raises(RuntimeError):
         m2.load_state_dict(bad)
-    # forward-only: the VJP entry points refuse this net
-    lib = _lib.load()
-    xx = x.cuda(); ll = lab.cuda(); v = torch.empty_like(xx)
-    rc = lib.pf_unet_forward_retain(m.handle, xx.data_ptr(), ll.data_ptr(), v.data_ptr(), 1, _lib.current_stream_ptr())
-    assert rc == -1 and b"VJP" in lib.pf_last_error(m.handle)
+    xx = x.cuda()
     # unsupported switches are rejected loudly
     cfg_bad = ref_config(c); cfg_bad.model.resblock_type = "ddpm"
     with pytest.raises(NotImplementedError):
@@ -179,3 +175,76 @@ def test_ncsnpp_in_the_pnp_flow_loop_time_scale():
     solver2 = PNP_FLOW(m, "cuda", args); solver2.noise = noise.cuda()
     with pytest.raises(_lib.PnpFlowHipError):
         solver2.restore_batch(y.cuda(), D.BoxInpainting(6), sigma, lr_eff)
+
+
+@pytest.mark.parametrize("precision", [1, 0])
+def test_ncsnpp_vjp_oracle_and_reference_autograd(precision):
+    """J^T vec w.r.t. the image (what OT_ODE takes, ot_ode.py:137-138): FIR adjoints, both pyramids, scaled skips, AttnBlockpp
+    adjoint - against autograd through the oracle and through the REAL reference module (golden)."""
+    m, cfg, sd = get_model("tiny")
+    g = np.load(os.path.join(GOLD, "ncsnpp_tiny.npz"))
+    x = det_normal((2, 3, 32, 32), 81); t = torch.from_numpy(g["t"]); vec = det_normal((2, 3, 32, 32), 87)
+    scale = float(g["g_absmax"])
+    m.set_precision(precision)
+    try:
+        v, gv = m.vjp(x.cuda(), (t * 999).cuda(), vec.cuda())
+        m.check_numerics()
+        # linearity in vec (a power of two: exact) and independence of the batch composition
+        g2 = m.backward((4.0 * vec).cuda()).cpu()
+        assert (g2 - 4.0 * gv.cpu()).abs().max().item() <= 1e-6 * 4 * scale
+        v1, g1 = m.vjp(x[1:].cuda(), (t[1:] * 999).cuda(), vec[1:].cuda())
+        assert (g1.cpu() - gv.cpu()[1:]).abs().max().item() <= 2 * NX_RTOL * scale
+    finally:
+        m.set_precision(1)
+    assert np.abs(v.cpu().numpy() - g["y"]).max() <= NX_RTOL * float(g["y_absmax"])       # the retained forward is the forward
+    ref = NO.ncsnpp_vjp(sd, cfg, x, t * 999, vec)
+    assert (gv.cpu() - ref).abs().max().item() <= 2 * NX_RTOL * scale                        # measured 3e-6
+    assert np.abs(gv.cpu().numpy() - g["g"]).max() <= 2 * NX_RTOL * scale
+
+
+def test_ncsnpp_vjp_reference_config_256_golden():
+    m, cfg, sd = get_model("afhq256")
+    g = np.load(os.path.join(GOLD, "ncsnpp_afhq256.npz"))
+    x = det_normal((1, 3, 256, 256), 81); t = torch.from_numpy(g["t"]); vec = det_normal((1, 3, 256, 256), 87)
+    v, gv = m.vjp(x.cuda(), (t * 999).cuda(), vec.cuda())
+    m.check_numerics()
+    gv = gv.cpu(); scale = float(g["g_absmax"])
+    assert np.abs(gv[:, :, 112:144, 112:144].numpy() - g["g_crop"]).max() <= 2 * NX_RTOL * scale      # measured 6e-6
+    assert np.abs(gv[:, :, :8, :8].numpy() - g["g_corner"]).max() <= 2 * NX_RTOL * scale
+    d = gv.double()
+    assert abs(d.abs().sum().item() - g["g_checksum"][1]) <= 2 * NX_RTOL * g["g_checksum"][1]
+    assert abs((d * d).sum().item() - g["g_checksum"][2]) <= 4 * NX_RTOL * g["g_checksum"][2]
+    # adjoint identity <J u, vec> = <u, J^T vec> with J u from a central difference of the (nonlinear) forward
+    u = det_normal((1, 3, 256, 256), 88); eps = 1e-2
+    lab = (t * 999).cuda()
+    jp = (m((x + eps * u).cuda(), lab).double() - m((x - eps * u).cuda(), lab).double()) / (2 * eps)
+    lhs = float((jp.cpu() * vec.double()).sum()); rhs = float((u.double() * d).sum())
+    assert abs(lhs - rhs) <= 2e-3 * max(abs(lhs), abs(rhs), 1e-3), (lhs, rhs)
+
+
+def test_ot_ode_with_the_rectified_net():
+    """OT_ODE.solve_ip's loop (ot_ode.py:63-147) with model='rectified': model_fn(x, t * 999) and its VJP inside pf_ot_ode_restore
+    (one hipGraph per Euler step), against the oracle's loop on the oracle's NCSN++ forward / autograd VJP."""
+    import pnpflow_amd.degradations as D
+    from pnpflow_amd.methods.ot_ode import OT_ODE
+    from pnpflow_amd.utils import CfgNode
+    m, cfg, sd = get_model("tiny")
+    B, S, steps, t0, sigma = 2, 32, 10, 0.3, 0.05
+    args = CfgNode(dict(method="ot_ode", model="rectified", problem="inpainting", steps_ode=steps, start_time=t0, gamma="constant", max_batch=1,
+                        compute_time=False, compute_memory=False, save_results=False, batch=0))
+    solver = OT_ODE(m, torch.device("cuda"), args)
+    clean = torch.tanh(det_normal((B, 3, S, S), 85))
+    deg_o = O.BoxInpainting(6)
+    y = O.make_measurement(clean, deg_o, sigma, 0, noise=det_normal((B, 3, S, S), 86))
+    init = det_normal((B, 3, S, S), 89)
+    solver.init_noise = init.cuda()
+    its = {}
+    x = solver.restore_batch(y.cuda(), D.BoxInpainting(6), sigma, iter_cb=lambda it, xx: its.__setitem__(it, xx.clone().cpu())).cpu()
+    ref_its = {}
+    ref = O.ot_ode_restore(lambda a, t: NO.ncsnpp_forward(sd, cfg, a, t * 999), lambda a, t, v: NO.ncsnpp_vjp(sd, cfg, a, t * 999, v), deg_o,
+                           "inpainting", y, sigma, steps=steps, start_time=t0, gamma="constant", init_noise=init,
+                           record=lambda it, xx: ref_its.__setitem__(it, xx.clone()))
+    first = int(steps * t0)
+    s0 = float(ref_its[first].abs().max())
+    assert (its[first] - ref_its[first]).abs().max().item() <= 1e-4 * s0
+    assert (x - ref).abs().max().item() <= 1e-3 * float(ref.abs().max())

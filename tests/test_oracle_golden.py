@@ -318,6 +318,12 @@ def test_ncsnpp_oracle_matches_reference_module(golden, name):
     taps = {}
     y = NO.ncsnpp_forward(sd, cfg, x, t * 999, taps)
     tol = 1e-6 * float(g["y_absmax"])          # same ops in the same order: observed 0
+    if "g" in g.files or "g_crop" in g.files:      # the VJP OT_ODE takes, by autograd through the real module
+        gv = NO.ncsnpp_vjp(sd, cfg, x, t * 999, det_normal((B, 3, c["image_size"], c["image_size"]), 87))
+        if name == "afhq256":
+            _check_crops(gv, g, "g", 1e-6 * float(g["g_absmax"]))
+        else:
+            np.testing.assert_allclose(gv.numpy(), g["g"], atol=1e-6 * float(g["g_absmax"]))
     if name == "afhq256":
         assert sum(int(np.prod(s)) for s in NO.ncsnpp_param_shapes(cfg).values()) == 65574549      # the reference prints it (models/utils.py:97-100); + 2000 sigmas
         _check_crops(y, g, "y", tol)

@@ -50,6 +50,13 @@ if __name__ == "__main__":
                 if k in taps:
                     r = taps[k].numpy()
                     print(f"   tap {k:14s} {tuple(r.shape)} err {np.abs(v - r).max():.3e} |ref| {np.abs(r).max():.3e}")
+    vec = torch.from_numpy(np.random.Generator(np.random.Philox(key=[87, 0])).standard_normal(size=tuple(x.shape), dtype=np.float32))
+    t0 = time.time(); gref = NO.ncsnpp_vjp(sd, cfg, x, t * 999, vec); print("oracle vjp %.2fs" % (time.time() - t0))
+    for prec in (1, 0):
+        m.set_precision(prec)
+        v, gg = m.vjp(x.cuda(), (t * 999).cuda(), vec.cuda()); torch.cuda.synchronize(); m.check_numerics()
+        e1 = (v.cpu() - ref).abs().max().item(); e2 = (gg.cpu() - gref).abs().max().item()
+        print(f"precision {prec}: retained forward err {e1:.3e}; vjp max|hip - oracle| = {e2:.3e} (|ref|max {gref.abs().max().item():.3e}, rel {e2 / gref.abs().max().item():.2e})")
     if name == "afhq256":
         m.set_precision(1)
         for bb in (1, 4, 8):

@@ -446,6 +446,17 @@ def gen_ncsnpp():
         for h in hooks:
             h.remove()
         rec = dict(t=t.numpy(), y_absmax=np.array(float(y.abs().max())))
+        if name != "wide":       # the VJP OT_ODE takes (ot_ode.py:137-138), by autograd through the real module
+            vec = det_normal((B, 3, S, S), 87)
+            for prm in m.parameters():
+                prm.requires_grad_(False)
+            gv = torch.autograd.functional.vjp(lambda z: m(z, t * 999), x, vec)[1]
+            rec["g_absmax"] = np.array(float(gv.abs().max()))
+            if name == "afhq256":
+                rec.update(crop_rec("g", gv))
+            else:
+                rec["g"] = gv.numpy()
+            print("   vjp", float(gv.abs().mean()), float(gv.abs().max()))
         if name == "afhq256":
             rec.update(crop_rec("y", y))
         else:

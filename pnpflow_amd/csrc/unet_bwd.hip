@@ -5,6 +5,7 @@
 // conv_mfma_kernel with transposed-flipped weight repacks; this file holds the GroupNorm(+SiLU)
 // backward, softmax backward, transposes and the 2x2 sum-pool (adjoint of nearest upsampling).
 #include <algorithm>
+#include <cstdlib>
 #include "pf_common.h"
 
 namespace pf {
@@ -165,7 +166,8 @@ hipError_t launch_gn_fwd_coeffs(const double* st0, int C0, const double* st1, in
 hipError_t launch_gn_bwd_pre(float* g, const float* x, const float* mu, const float* rs, const float* gamma, const float* beta, double* bsum,
                              int B, int HW, int C, int coff, int Ct, int silu, hipStream_t s) {
     if (C % 4 || C / 4 > 256) return hipErrorInvalidValue;
-    const int ppb = 1024;
+    int ppb = 256;
+    while (ppb > 64 && (long)((HW + ppb - 1) / ppb) * B < 2048) ppb >>= 1;
     hipLaunchKernelGGL(gn_bwd_pre_kernel, dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, s, g, x, mu, rs, gamma, beta, bsum, HW, C, coff, Ct, silu, ppb);
     return hipGetLastError();
 }
@@ -176,7 +178,12 @@ hipError_t launch_gn_bwd_coeffs(const double* bsum, int Ct, int cpg, int HW, flo
 hipError_t launch_gn_bwd_post(const float* dy, const float* x, const float* mu, const float* rs, const float* m1, const float* m2,
                               const float* add, float* out, int B, int HW, int C, int coff, int Ct, int accumulate, hipStream_t s, float add_scale) {
     if (C % 4 || C / 4 > 256) return hipErrorInvalidValue;
-    const int ppb = 1024;
+    static const int ppb_env = getenv("PNPFLOW_HIP_POST_PPB") ? atoi(getenv("PNPFLOW_HIP_POST_PPB")) : 0;
+    // pixels per workgroup: >= 8 workgroups per CU where the tensor allows it (1024 left the second wave of workgroups 60 % full at
+    // 256^2: C5 5.27 -> 5.54 images/s with 256, profiles/r02_ab_variants_same_box.txt)
+    int ppb = 256;
+    while (ppb > 64 && (long)((HW + ppb - 1) / ppb) * B < 2048) ppb >>= 1;
+    if (ppb_env > 0) ppb = ppb_env;
     const dim3 grid((HW + ppb - 1) / ppb, B);
     if (add != nullptr && accumulate) hipLaunchKernelGGL((gn_bwd_post_kernel<true, true>), grid, dim3(256), 0, s, dy, x, mu, rs, m1, m2, add, out, HW, C, coff, Ct, ppb, add_scale);
     else if (add != nullptr) hipLaunchKernelGGL((gn_bwd_post_kernel<true, false>), grid, dim3(256), 0, s, dy, x, mu, rs, m1, m2, add, out, HW, C, coff, Ct, ppb, add_scale);

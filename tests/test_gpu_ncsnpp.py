@@ -248,3 +248,22 @@ def test_ot_ode_with_the_rectified_net():
     s0 = float(ref_its[first].abs().max())
     assert (its[first] - ref_its[first]).abs().max().item() <= 1e-4 * s0
     assert (x - ref).abs().max().item() <= 1e-3 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("c", [dict(image_size=16, nf=96, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=(8,), num_channels=1),
+                               dict(image_size=32, nf=64, ch_mult=(2, 1, 3), num_res_blocks=3, attn_resolutions=(32, 8), num_channels=3)])
+def test_ncsnpp_other_configurations_forward_and_vjp(c):
+    """Widths that are not powers of two (96 channels: 24 GroupNorm groups, FIR lanes that do not fill a workgroup), a single image
+    channel, a narrowing level, three blocks per level, attention at the full resolution (T = 1024) - engine vs oracle."""
+    from pnpflow_amd.image_generation.models.ncsnpp import NCSNpp
+    cfg = NO.ncsnpp_config(**c)
+    sd = NO.synthetic_state_dict(cfg, 3)
+    rc = ref_config(c); rc.data.num_channels = c["num_channels"]
+    m = NCSNpp(rc); m.load_state_dict(sd)
+    S, ch = c["image_size"], c["num_channels"]
+    x = det_normal((2, ch, S, S), 91); lab = torch.tensor([77.0, 640.0]); vec = det_normal((2, ch, S, S), 92)
+    v, gv = m.vjp(x.cuda(), lab.cuda(), vec.cuda())
+    m.check_numerics()
+    ref = NO.ncsnpp_forward(sd, cfg, x, lab); gref = NO.ncsnpp_vjp(sd, cfg, x, lab, vec)
+    assert (v.cpu() - ref).abs().max().item() <= NX_RTOL * ref.abs().max().item()
+    assert (gv.cpu() - gref).abs().max().item() <= 2 * NX_RTOL * gref.abs().max().item()

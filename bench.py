@@ -234,6 +234,10 @@ def conv_roofline(r, precision, workload):
         peak = 157.3   # TFLOP/s, fp32 MFMA dense peak (MI355X_MICROARCH.md)
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=None,
                     kernel="conv_mfma_kernel (fp32 32x32x2 MFMA implicit GEMM)")
+    elif precision == 2:
+        peak = 2500.0  # TFLOP/s, f16 MFMA dense peak; one f16 MFMA product per algorithmic product
+        roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=None,
+                    kernel="conv_mfma16_kernel, TERMS = 1 (one f16 32x32x16 MFMA per product: fp16 operands, f32 accumulate)")
     else:
         peak = 2500.0  # TFLOP/s, f16 MFMA dense peak; every algorithmic product is executed as 3 f16 MFMA products
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=traffic,
@@ -363,7 +367,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary BASELINE configs and the pointwise block (N=1 default runs include them)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="override the workload's batch per GPU (tests)")
-    ap.add_argument("--precision", type=int, default=1, choices=[0, 1],
+    ap.add_argument("--precision", type=int, default=1, choices=[0, 1, 2],
                     help="1 (default): fp32-equivalent split-fp16 MFMA (3 x f16 MFMA per product); 0: exact fp32 MFMA")
     a = ap.parse_args()
     if a.batch > 0:
@@ -428,7 +432,8 @@ def main():
             "metric": "restored images/sec", "value": round(total_images / dt, 4), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {0: "f32", 1: "f32-equivalent (f16 hi+lo split operands, 3 x f16 MFMA per product, f32 accumulate)"}[a.precision],
+            "dtype": {0: "f32", 1: "f32-equivalent (f16 hi+lo split operands, 3 x f16 MFMA per product, f32 accumulate)",
+                      2: "f16 operands (power-of-two scaled), f32 accumulate - TF32-class, not fp32-equivalent"}[a.precision],
             "data": "synthetic",
             "config": {"workload": wl["label"], "image": f"{dim}x{dim}x3", "batch_per_gpu": B, "global_batch": world * B,
                        "steps_pnp": wl["steps"], "num_samples": wl["ns"], "weights": "synthetic seed 0 (no checkpoint offline)",
@@ -464,6 +469,19 @@ def main():
                 elif not a.no_cpu_baseline:
                     rec["cpu_baseline"] = cpu_baseline_ot_ode(w2, budget_s=12.0)
                 extra[name] = rec
+                del rr
+            if a.precision == 1:
+                # the headline workload in precision mode 2 (one fp16 MFMA per product: NOT fp32-equivalent, ~7e-4 relative on the U-Net
+                # output; within the BASELINE tolerance of +-0.05 dB PSNR, tests/test_gpu_parity.py::test_fp16_mode_*).  Reported
+                # beside the headline, never as `value`.
+                rr = Runner("c2", 0, 1, dev, 2, not a.no_graph, models)
+                rr.step(0, steps=2); torch.cuda.synchronize()
+                t1 = time.perf_counter(); xx = rr.step(1); torch.cuda.synchronize(); d1 = time.perf_counter() - t1
+                extra["c2_fp16_mode"] = {"workload": rr.wl["label"] + ", precision mode 2", "dtype": "f16 operands, f32 accumulate (TF32-class)",
+                                         "images_per_s": round(rr.wl["B"] / d1, 4), "ms_per_step": round(d1 * 1e3, 1), "steps": 1,
+                                         "psnr_db": round(float(psnr_per_image(xx, rr.clean).mean()), 4), "psnr_db_headline_mode": out["psnr_db"],
+                                         "roofline": conv_roofline(rr, 2, "c2")}
+                rr.model.set_precision(1)
                 del rr
             extra["n4_ncsnpp_forward"] = ncsnpp_forward_block(dev)
             out["configs"] = extra

@@ -112,7 +112,11 @@ int pf_engine_weight_shape(const pf_engine* e, int i, int64_t shape[4]);
  *     the matrix-pipe time.  Applies to the packed-weight convs of the forward and of the backward (the VJP input is
  *     normalised by a power of two first) and selects the fused attention core (q k^T, softmax, P v in one launch)
  *     where its shapes apply; the unfused attention matmuls and their adjoints run on the fp32 MFMA.
- * 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere. */
+ * 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere.
+ * 2 = single fp16 MFMA per product: the packed-weight convs round both operands to fp16 (11-bit significands; the per-image
+ *     power-of-two operand scales keep them in range) and accumulate in fp32 - the precision class of the TF32 convolutions the
+ *     reference's CUDA runs use by PyTorch default (torch.backends.cudnn.allow_tf32), NOT fp32-equivalent: U-Net outputs
+ *     agree with the fp32 reference to ~1e-3 relative, restored images to the +-0.05 dB PSNR the BASELINE tolerance asks. */
 int pf_engine_set_precision(pf_engine* e, int mode);
 
 /* ---- velocity field ---------------------------------------------------------------- */

@@ -46,7 +46,10 @@ __device__ __forceinline__ float silu_fast16(float x) { return x * __builtin_amd
 #define PF_LB3(MT, WM, KC) (((MT) == 4 && (WM) == 2 && (KC) == 16) || ((KC) != 64 && (((MT) == 4 && (WM) == 1) || ((MT) == 2 && (WM) == 4))))
 #endif
 
-template <int MT, int NT, int WM, int WN, int S, int UP, int KC, bool GNB = false>
+// TERMS = 3: every product as a_lo*w_hi + a_hi*w_lo + a_hi*w_hi (fp32-equivalent).  TERMS = 1: a_hi*w_hi only - operands rounded to
+// fp16 (11-bit significands, the power-of-two operand scales keep them in range), fp32 accumulate: the precision class of the
+// TF32 convolutions the reference's own CUDA runs use by PyTorch default; one third of the matrix-pipe work, no low halves staged.
+template <int MT, int NT, int WM, int WN, int S, int UP, int KC, bool GNB = false, int TERMS = 3>
 __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16_kernel(const ConvParams p) {
     constexpr int ROW = KC + 4;                  // dwords per LDS row: KC/2 (hi) + KC/2 (lo) + 4 (pad)
     constexpr int KQ = KC / 4, KH = KC / 2, KS = KC / 16;
@@ -140,10 +143,12 @@ __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16
                 asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
                 f16x4 h, l;
                 h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-                l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
-                l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
                 *reinterpret_cast<f16x4*>(s_patch + a_lds) = h;
-                *reinterpret_cast<f16x4*>(s_patch + a_lds + KH) = l;
+                if constexpr (TERMS == 3) {
+                    l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
+                    l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
+                    *reinterpret_cast<f16x4*>(s_patch + a_lds + KH) = l;
+                }
             }
         }
     };
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16
         const size_t kidx = ((size_t)ch * KS + j) * sg.taps + tap;     // global 16-channel slice index x taps + tap
         const uint4* wp = reinterpret_cast<const uint4*>(sg.w16) + kidx * ((size_t)p.Cout * 4) + hi;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { dh[nt] = wp[(size_t)nclamp[nt] * 4]; dl[nt] = wp[(size_t)nclamp[nt] * 4 + 2]; }
+        for (int nt = 0; nt < NT; ++nt) { dh[nt] = wp[(size_t)nclamp[nt] * 4]; if constexpr (TERMS == 3) dl[nt] = wp[(size_t)nclamp[nt] * 4 + 2]; else dl[nt] = dh[nt]; }
     };
 
     int si = 0, ch = 0;
@@ -291,7 +296,7 @@ __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16
                 const int poff = (((wm * MT + mt) * 2 + prow) * S + ky) * RS + (pcol * S + kx) * ROW;
                 if (PF_DBG(4)) { ah[mt] = *reinterpret_cast<const f16x8*>(&ch_[0]); al[mt] = *reinterpret_cast<const f16x8*>(&cl_[0]); continue; }
                 ah[mt] = *reinterpret_cast<const f16x8*>(s_patch + poff + j * 8 + hi * 4);
-                al[mt] = *reinterpret_cast<const f16x8*>(s_patch + poff + KH + j * 8 + hi * 4);
+                if constexpr (TERMS == 3) al[mt] = *reinterpret_cast<const f16x8*>(s_patch + poff + KH + j * 8 + hi * 4); else al[mt] = ah[mt];
             }
 #ifndef PF_AB_NO_A_FIRST
             // every A fragment of the k-step is requested before its first MFMA (the MFMAs then wait with counted lgkmcnt):
@@ -306,6 +311,7 @@ __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16
                 for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(ch_[nt].x), "v"(ch_[nt].y), "v"(ch_[nt].z), "v"(ch_[nt].w), "v"(cl_[nt].x), "v"(cl_[nt].y), "v"(cl_[nt].z), "v"(cl_[nt].w));
                 return;
             }
+            if constexpr (TERMS == 3) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -316,6 +322,7 @@ __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], *reinterpret_cast<const f16x8*>(&cl_[nt]), acc[mt][nt], 0, 0, 0);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -483,7 +490,7 @@ __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16
 #endif
 }
 
-template <int MT, int NT, int WM, int WN, int S, int UP, int KC>
+template <int MT, int NT, int WM, int WN, int S, int UP, int KC, int TERMS>
 static hipError_t launch_cfg16(const ConvParams& p, hipStream_t stream) {
     constexpr int ROW = KC + 4;
     constexpr int TH = 2 * MT * WM, TW = 16;
@@ -498,7 +505,7 @@ static hipError_t launch_cfg16(const ConvParams& p, hipStream_t stream) {
     if constexpr (S == 1 && UP == 0) {
         if (p.gnb_x != nullptr) {        // adjoint conv with the fused GroupNorm-backward first stage
             static bool attr_set_g = false;
-            auto kg = conv_mfma16_kernel<MT, NT, WM, WN, S, UP, KC, true>;
+            auto kg = conv_mfma16_kernel<MT, NT, WM, WN, S, UP, KC, true, TERMS>;
             if (!attr_set_g) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (e != hipSuccess) return e;
@@ -510,7 +517,7 @@ static hipError_t launch_cfg16(const ConvParams& p, hipStream_t stream) {
     }
     if (p.gnb_x != nullptr) return hipErrorInvalidValue;
     static bool attr_set = false;
-    auto kern = conv_mfma16_kernel<MT, NT, WM, WN, S, UP, KC>;
+    auto kern = conv_mfma16_kernel<MT, NT, WM, WN, S, UP, KC, false, TERMS>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -524,31 +531,32 @@ static long wg_count16(const ConvParams& p, int TH, int BN) {
     return (long)p.B * ((p.H + TH - 1) / TH) * ((p.W + 15) / 16) * ((p.Cout + BN - 1) / BN);
 }
 
-template <int S, int UP, int KC>
+template <int S, int UP, int KC, int TERMS>
 static hipError_t launch_sel16(const ConvParams& p, hipStream_t stream) {
     static const long MIN_WGS = getenv("PNPFLOW_HIP_MIN_WGS") ? atol(getenv("PNPFLOW_HIP_MIN_WGS")) : 512;
     if constexpr (S == 1) {
         if (p.Cout <= 32) {
-            return launch_cfg16<2, 1, 4, 1, S, UP, KC>(p, stream);                                                        // 16x16 px x 32
+            return launch_cfg16<2, 1, 4, 1, S, UP, KC, TERMS>(p, stream);                                                        // 16x16 px x 32
         }
         if (p.Cout <= 64) {
-            if (wg_count16(p, 16, 64) >= MIN_WGS) return launch_cfg16<4, 1, 2, 2, S, UP, KC>(p, stream);                  // 16x16 px x 64
-            if (wg_count16(p, 8, 64) >= MIN_WGS) return launch_cfg16<2, 1, 2, 2, S, UP, KC>(p, stream);                   // 8x16 px x 64
-            return launch_cfg16<1, 1, 2, 2, S, UP, KC>(p, stream);                                                        // 4x16 px x 64
+            if (wg_count16(p, 16, 64) >= MIN_WGS) return launch_cfg16<4, 1, 2, 2, S, UP, KC, TERMS>(p, stream);                  // 16x16 px x 64
+            if (wg_count16(p, 8, 64) >= MIN_WGS) return launch_cfg16<2, 1, 2, 2, S, UP, KC, TERMS>(p, stream);                   // 8x16 px x 64
+            return launch_cfg16<1, 1, 2, 2, S, UP, KC, TERMS>(p, stream);                                                        // 4x16 px x 64
         }
-        if (wg_count16(p, 8, 128) >= MIN_WGS) return launch_cfg16<4, 1, 1, 4, S, UP, KC>(p, stream);                      // 8x16 px x 128
-        if (wg_count16(p, 4, 128) >= MIN_WGS) return launch_cfg16<2, 1, 1, 4, S, UP, KC>(p, stream);                      // 4x16 px x 128
-        return launch_cfg16<1, 1, 2, 2, S, UP, KC>(p, stream);                                                            // 4x16 px x 64
+        if (wg_count16(p, 8, 128) >= MIN_WGS) return launch_cfg16<4, 1, 1, 4, S, UP, KC, TERMS>(p, stream);                      // 8x16 px x 128
+        if (wg_count16(p, 4, 128) >= MIN_WGS) return launch_cfg16<2, 1, 1, 4, S, UP, KC, TERMS>(p, stream);                      // 4x16 px x 128
+        return launch_cfg16<1, 1, 2, 2, S, UP, KC, TERMS>(p, stream);                                                            // 4x16 px x 64
     } else {
-        if (p.Cout <= 32) return launch_cfg16<1, 1, 4, 1, S, UP, KC>(p, stream);
-        if (p.Cout <= 64) return launch_cfg16<2, 1, 2, 2, S, UP, KC>(p, stream);
-        return launch_cfg16<1, 1, 2, 2, S, UP, KC>(p, stream);
+        if (p.Cout <= 32) return launch_cfg16<1, 1, 4, 1, S, UP, KC, TERMS>(p, stream);
+        if (p.Cout <= 64) return launch_cfg16<2, 1, 2, 2, S, UP, KC, TERMS>(p, stream);
+        return launch_cfg16<1, 1, 2, 2, S, UP, KC, TERMS>(p, stream);
     }
 }
 
 // Only fragment-major packed weights (w_mode 0) with a 16-bit repack are supported; the caller keeps the
 // fp32 kernel (launch_conv) for the generic strided operands of attention.
-hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t stream) {
+template <int TERMS>
+static hipError_t launch_conv16_t(const ConvParams& p, int stride, int up, hipStream_t stream) {
 #ifdef PF_AB_GN_INKERNEL
     if (p.gn_C > 1024) return hipErrorInvalidValue;
 #else
@@ -564,11 +572,15 @@ hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t st
     static const int kc_l1 = getenv("PNPFLOW_HIP_KC_L1") ? atoi(getenv("PNPFLOW_HIP_KC_L1")) : 32;
     bool all32 = (p.Cout <= 32 ? kc_l0 : p.Cout <= 64 ? kc_l1 : kc_pref) == 32;
     for (int i = 0; i < p.nseg; ++i) all32 &= p.seg[i].C % 32 == 0;
-    if (all_1tap && stride == 1 && !up) return launch_sel16<1, 0, 64>(p, stream);
-    if (stride == 2) return launch_sel16<2, 0, 16>(p, stream);
-    if (up == 2) return launch_sel16<1, 2, 16>(p, stream);
-    if (up) return all32 ? launch_sel16<1, 1, 32>(p, stream) : launch_sel16<1, 1, 16>(p, stream);
-    return all32 ? launch_sel16<1, 0, 32>(p, stream) : launch_sel16<1, 0, 16>(p, stream);
+    if (all_1tap && stride == 1 && !up) return launch_sel16<1, 0, 64, TERMS>(p, stream);
+    if (stride == 2) return launch_sel16<2, 0, 16, TERMS>(p, stream);
+    if (up == 2) return launch_sel16<1, 2, 16, TERMS>(p, stream);
+    if (up) return all32 ? launch_sel16<1, 1, 32, TERMS>(p, stream) : launch_sel16<1, 1, 16, TERMS>(p, stream);
+    return all32 ? launch_sel16<1, 0, 32, TERMS>(p, stream) : launch_sel16<1, 0, 16, TERMS>(p, stream);
+}
+
+hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t stream, int terms) {
+    return terms == 1 ? launch_conv16_t<1>(p, stride, up, stream) : launch_conv16_t<3>(p, stride, up, stream);
 }
 
 }  // namespace pf

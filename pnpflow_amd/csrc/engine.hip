@@ -150,7 +150,8 @@ struct pf_engine {
     struct GraphKey { const void* plan; int kind, half, sf, ntaps; const void* mask; const void* taps; const void* noise;
                       int num_samples, batch_samples, noise_model, B; };
     GraphKey gkey{}; hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
-    int precision = 1;   // 1 (default): split-fp16 (3 x f16 MFMA, fp32-equivalent) for the packed-weight convs; 0: exact fp32 MFMA
+    int precision = 1;   // 1 (default): split-fp16 (3 x f16 MFMA, fp32-equivalent) for the packed-weight convs; 0: exact fp32 MFMA;
+                         // 2: single fp16 MFMA per product (fp16 operands, fp32 accumulate - TF32-class, include/pnpflow_hip.h)
     SolverBufs sb;
     // OT-ODE loop (pf_ot_ode_restore): iterate, velocity, solve output, J^T vec, per-iteration schedule tables, cached graph
     struct OdeBufs { int B = 0; size_t n = 0, ny = 0; int steps = 0; bool blur = false;
@@ -728,7 +729,7 @@ static int unet_walk(pf_engine* e, Builder& bd, Plan* plan) {
 #include "engine_ncsnpp.inc"
 
 static int build_plan(pf_engine* e, int B, bool retain, Plan** out_plan) {
-    const int key = (B * 2 + (retain ? 1 : 0)) * 2 + (e->precision ? 1 : 0);      // the precision mode selects kernels at build time
+    const int key = (B * 2 + (retain ? 1 : 0)) * 2 + (e->precision ? 1 : 0);      // the precision mode selects kernels at build time (modes 1 and 2 share plans: same launches, the term count is a run-time argument)
     auto it = e->plans.find(key);
     if (it != e->plans.end()) { *out_plan = e->last_plan = it->second.get(); it->second->last_used = ++e->plan_clock; return PF_OK; }
     // bounded cache: a plan owns its activation buffers (GBs at the BASELINE sizes), so the least recently used one is
@@ -1119,8 +1120,8 @@ static hipError_t dispatch_conv(pf_engine* e, const Op& op, hipStream_t s) {
     if (e->precision != 0) {
         bool ok16 = true;
         for (int i = 0; i < op.cp.nseg; ++i) ok16 &= op.cp.seg[i].w_mode == 0 && op.cp.seg[i].w16 != nullptr;
-        if (ok16 && conv_ws_supported(op.cp, op.stride, op.up)) return launch_conv_ws(op.cp, s);
-        if (ok16) return launch_conv16(op.cp, op.stride, op.up, s);
+        if (ok16 && e->precision == 1 && conv_ws_supported(op.cp, op.stride, op.up)) return launch_conv_ws(op.cp, s);
+        if (ok16) return launch_conv16(op.cp, op.stride, op.up, s, e->precision == 2 ? 1 : 3);
     }
     return launch_conv(op.cp, op.stride, op.up, s);
 }
@@ -1350,7 +1351,8 @@ int pf_engine_finalize_weights(pf_engine* e) {
 
 int pf_engine_set_precision(pf_engine* e, int mode) {
     if (!e) return PF_ERR_INVALID;
-    if (mode < 0 || mode > 1) { e->err = "precision mode must be 0 (fp32 MFMA) or 1 (split-fp16 MFMA)"; return PF_ERR_INVALID; }
+    if (mode < 0 || mode > 2) { e->err = "precision mode must be 0 (fp32 MFMA), 1 (split-fp16 MFMA, fp32-equivalent) or 2 (single fp16 MFMA)"; return PF_ERR_INVALID; }
+    if (mode != e->precision) { drop_graph(e); drop_ode_graph(e); }       // captured graphs bake the kernel choice in
     e->precision = mode;
     return PF_OK;
 }

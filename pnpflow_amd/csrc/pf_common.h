@@ -112,7 +112,7 @@ struct GnCoefParams {
 hipError_t launch_gn_coef(const GnCoefParams& p, int B, hipStream_t s);
 
 hipError_t launch_conv(const ConvParams& p, int stride, int up, hipStream_t s);
-hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t s);   // split-fp16 MFMA variant
+hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t s, int terms = 3);   // split-fp16 MFMA variant (terms 3) / single fp16 MFMA (terms 1)
 bool conv_ws_supported(const ConvParams& p, int stride, int up);
 hipError_t launch_conv_ws(const ConvParams& p, hipStream_t s);                     // wave-specialised persistent split-fp16 variant (conv_ws.hip)
 size_t conv_flops(const ConvParams& p);

@@ -117,7 +117,8 @@ class _EngineNet:
         return out
 
     def set_precision(self, mode: int):
-        """1 (default): split-fp16 MFMA (fp32-equivalent, 3 x f16 MFMA per product); 0: exact fp32 MFMA."""
+        """1 (default): split-fp16 MFMA (fp32-equivalent, 3 x f16 MFMA per product); 0: exact fp32 MFMA; 2: single fp16 MFMA per
+        product (fp16 operands, fp32 accumulate: TF32-class, ~1e-3 relative on the U-Net output)."""
         _lib.check(self._lib.pf_engine_set_precision(self._h, int(mode)), self._h, "pf_engine_set_precision")
         return self
 

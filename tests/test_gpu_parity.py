@@ -321,6 +321,60 @@ def test_pnp_flow_trajectory_matches_reference(hip, golden, idx, use_graph, prec
     assert float((p_hip - p_ref).abs().max()) <= 0.05      # north_star: PSNR within +-0.05 dB of the reference
 
 
+# ---------------------------------------------------------------------------------------------
+# precision mode 2: single fp16 MFMA per product (fp16 operands, fp32 accumulate) - NOT fp32-equivalent; held to the
+# BASELINE tolerance (restored-image PSNR within +-0.05 dB of the reference) and to a stated bound on the U-Net output
+# ---------------------------------------------------------------------------------------------
+FP16_REL_L2 = 2e-3        # relative L2 error of the U-Net output vs the fp32 oracle (measured 6.6e-4 at 128^2 and 256^2)
+
+
+@pytest.mark.parametrize("net", ["tiny4", "celeba128"])
+def test_fp16_mode_unet_forward_error_bound(hip, net):
+    m, cfg, sd = model_for(net)
+    S, Cc = cfg["input_height"], cfg["input_channels"]
+    x = det_normal((2, Cc, S, S), 11); t = torch.tensor([0.25, 0.75])
+    ref = O.unet_forward(sd, cfg, x, t)
+    m.set_precision(2)
+    try:
+        y = m(x.cuda(), t.cuda()).cpu()
+        m.check_numerics()
+    finally:
+        m.set_precision(1)
+    rel = float((y - ref).norm() / ref.norm())
+    assert 1e-5 < rel <= FP16_REL_L2, rel            # really the single-term kernel (the split mode is at 7e-7), within the bound
+    assert float((y - ref).abs().max()) <= 5 * FP16_REL_L2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("idx", range(6))
+def test_fp16_mode_pnp_flow_psnr_within_baseline_tolerance(hip, golden, idx):
+    """Same seeded restoration as test_pnp_flow_trajectory_matches_reference, in precision mode 2: final PSNR within +-0.05 dB of
+    the real reference's (north_star), iterates within 2e-2 of its iterates."""
+    from pnpflow_amd.methods.pnp_flow import PNP_FLOW
+    from pnpflow_amd.utils import CfgNode, psnr_per_image
+    tag, net, problem, mk, sigma = traj_cases()[idx]
+    g = golden("pnp_traj_" + tag)
+    m, cfg, sd = model_for(net)
+    S, Cc = cfg["input_height"], cfg["input_channels"]
+    steps, ns = int(g["steps"]), int(g["num_samples"])
+    B = 2
+    args = CfgNode(dict(method="pnp_flow", model="ot", problem=problem, noise_type="gaussian", num_samples=ns, steps_pnp=steps,
+                        lr_pnp=1.0, gamma_style="alpha_1_minus_t", alpha=float(g["alpha"]), max_batch=1, compute_time=False,
+                        compute_memory=False, save_results=False, batch=0))
+    solver = PNP_FLOW(m, torch.device("cuda"), args)
+    solver.noise = torch.stack([det_normal((B, Cc, S, S), 41, 1 + i) for i in range(steps * ns)]).cuda()
+    args.sigma_noise = sigma
+    m.set_precision(2)
+    try:
+        x = solver.restore_batch(torch.from_numpy(g["noisy"]).cuda(), mk(S), sigma, lr=sigma ** 2 * 1.0)
+    finally:
+        m.set_precision(1)
+    assert np.abs(x.cpu().numpy() - g["x_it9"]).max() <= 2e-2
+    clean = det_image((B, Cc, S, S), 31)
+    p_hip = psnr_per_image(x, clean.cuda()).cpu()
+    p_ref = O.psnr_per_image(torch.from_numpy(g["x_it9"]), clean)
+    assert float((p_hip - p_ref).abs().max()) <= 0.05, (p_hip, p_ref)
+
+
 @pytest.mark.parametrize("idx", range(3))
 def test_pnp_flow_laplace_trajectory_matches_reference(hip, golden, idx):
     """Laplace noise model (pnp_flow.py:42-43).  The data-fit gradient is a sign function, so a residual within

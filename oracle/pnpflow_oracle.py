@@ -615,7 +615,48 @@ def ot_ode_solution(problem: str, d: torch.Tensor, degradation: Degradation, x_l
         fft_kernel = torch.fft.fft2(degradation.filter)
         inv = rt_squared * fft_kernel * torch.conj(fft_kernel) + sigma_noise ** 2
         return torch.fft.ifft2(torch.fft.fft2(d) / inv)
-    raise NotImplementedError(problem)
+    # generic operator (ot_ode.py:118-128): per image, GMRES(max_iter=100) on C z = r_t^2 H(H_adj(z)) + sigma^2 z
+    sol = torch.zeros_like(d)
+    for i in range(d.shape[0]):
+        def c_ope(z, i=i):
+            zz = z.reshape(d.shape[1:]).unsqueeze(0)
+            return (rt_squared[i].unsqueeze(0) * degradation.H(degradation.H_adj(zz)) + sigma_noise ** 2 * zz).reshape(-1)
+        sol[i] = gmres(c_ope, d[i].reshape(-1), max_iter=100).reshape(d[i].shape)
+    return sol
+
+
+def gmres(avp: Callable, b: torch.Tensor, max_iter: int, tol: float = 1e-6, atol: float = 1e-6) -> torch.Tensor:
+    """pnpflow/utils.py:972-1109 `GMRES` with x0 = 0: Arnoldi by modified Gram-Schmidt, the Hessenberg matrix reduced by Givens
+    rotations as it grows, stop when |residual| < tol*|b| or < atol, then the triangular solve and x = V y.  (The reference returns
+    `b` itself when |b| < 1e-8 or max_iter == 0, :996-997.)"""
+    bnorm = torch.norm(b)
+    if max_iter == 0 or bnorm < 1e-8:
+        return b
+    eps = torch.finfo(b.dtype).eps
+    unit = lambda v: ((v / torch.norm(v)) if torch.norm(v) > eps else torch.zeros_like(v), torch.norm(v))     # _safe_normalize (:1055)
+    v0, rnorm = unit(b)
+    beta = torch.zeros(max_iter + 1); beta[0] = rnorm
+    V = [v0]
+    Hm = torch.zeros((max_iter + 1, max_iter + 1)); cs = torch.zeros(max_iter); ss = torch.zeros(max_iter)
+    j = 0
+    for j in range(max_iter):
+        w = avp(V[j])
+        for i in range(j + 1):                                           # arnoldi (:1067-1082)
+            Hm[i, j] = torch.dot(w, V[i]); w = w - Hm[i, j] * V[i]
+        vn, wn = unit(w); Hm[j + 1, j] = wn; V.append(vn)
+        for i in range(j):                                               # apply_given_rotation (:1098-1109)
+            tmp = cs[i] * Hm[i, j] - ss[i] * Hm[i + 1, j]
+            Hm[i + 1, j] = cs[i] * Hm[i + 1, j] + ss[i] * Hm[i, j]
+            Hm[i, j] = tmp
+        r = torch.sqrt(Hm[j, j] * Hm[j, j] + Hm[j + 1, j] * Hm[j + 1, j])
+        cs[j], ss[j] = Hm[j, j] / r, -Hm[j + 1, j] / r                    # cal_rotation (:1085-1095)
+        Hm[j, j] = cs[j] * Hm[j, j] - ss[j] * Hm[j + 1, j]; Hm[j + 1, j] = 0
+        beta[j + 1] = ss[j] * beta[j]; beta[j] = cs[j] * beta[j]
+        res = torch.abs(beta[j + 1])
+        if res < tol * bnorm or res < atol:
+            break
+    y = torch.linalg.solve_triangular(Hm[0:j + 1, 0:j + 1], beta[0:j + 1].unsqueeze(-1), upper=True)
+    return torch.stack(V[:-1], dim=0).T @ y.squeeze(-1)
 
 
 def ot_ode_restore(model: Callable, vjp: Callable, degradation: Degradation, problem: str, noisy_img: torch.Tensor,

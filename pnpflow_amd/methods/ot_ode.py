@@ -69,8 +69,9 @@ class OT_ODE(object):
         if hasattr(self.model, "set_solver_time_scale"):
             self.model.set_solver_time_scale(999.0 if args.model == "rectified" else 1.0)       # model_fn(x, t * 999), ot_ode.py:21-25
         if problem not in ("denoising", "inpainting", "random_inpainting", "paintbrush_inpainting", "superresolution", "gaussian_deblurring_FFT"):
-            # the reference's remaining branch is a per-image GMRES on H H^T (ot_ode.py:118-128); none of its operators reach it
-            raise NotImplementedError(f"ot_ode linear solve for '{problem}' is not implemented by this engine")
+            # any other problem name: the reference's generic branch, a per-image GMRES on r_t^2 H H^T + sigma^2 I (ot_ode.py:118-128).
+            # No entry of main.py's problem table reaches it; it runs as a host-orchestrated loop (not the device loop below).
+            return self._restore_batch_generic(noisy_img, degradation, sigma_noise, iter_cb, cb_iterations)
         steps, delta = int(args.steps_ode), 1 / args.steps_ode
         first = int(steps * args.start_time)
         B = noisy_img.shape[0]
@@ -115,6 +116,71 @@ class OT_ODE(object):
                                                   _lib.current_stream_ptr(), cb, None), self.model.handle, "pf_ot_ode_restore")
         if holder["err"] is not None:
             raise holder["err"]
+        return x
+
+    # ---- generic operator: Krylov solve of (r_t^2 H H^T + sigma^2 I) sol = d per image --------------------------------------
+    @staticmethod
+    def _gmres(apply_c, rhs, max_iter=100, tol=1e-6, atol=1e-6):
+        """GMRES from a zero initial guess with the stopping rule of pnpflow/utils.py:972-1040 (|residual| < tol |rhs| or < atol,
+        at most max_iter Krylov vectors).  Operator applications run on the engine's H / H_adj kernels; the Krylov bookkeeping
+        (modified Gram-Schmidt, Givens-rotated Hessenberg least squares) is small host-driven tensor arithmetic."""
+        nb = torch.linalg.vector_norm(rhs)
+        if max_iter == 0 or float(nb) < 1e-8:
+            return rhs                                           # utils.py:996-997 returns the right-hand side itself
+        tiny = torch.finfo(rhs.dtype).eps
+        basis = [rhs / nb if float(nb) > tiny else torch.zeros_like(rhs)]
+        hess = np.zeros((max_iter + 1, max_iter), dtype=np.float64)
+        cos_, sin_ = np.zeros(max_iter), np.zeros(max_iter)
+        rhs_ls = np.zeros(max_iter + 1); rhs_ls[0] = float(nb)
+        k = 0
+        for k in range(max_iter):
+            w = apply_c(basis[k])
+            for i in range(k + 1):
+                hik = torch.dot(w, basis[i]); w = w - hik * basis[i]; hess[i, k] = float(hik)
+            wn = torch.linalg.vector_norm(w)
+            hess[k + 1, k] = float(wn)
+            basis.append(w / wn if float(wn) > tiny else torch.zeros_like(w))
+            for i in range(k):                                   # earlier rotations on the new column
+                a, b = hess[i, k], hess[i + 1, k]
+                hess[i, k], hess[i + 1, k] = cos_[i] * a - sin_[i] * b, cos_[i] * b + sin_[i] * a
+            r = float(np.hypot(hess[k, k], hess[k + 1, k]))
+            cos_[k], sin_[k] = hess[k, k] / r, -hess[k + 1, k] / r
+            hess[k, k] = cos_[k] * hess[k, k] - sin_[k] * hess[k + 1, k]; hess[k + 1, k] = 0.0
+            rhs_ls[k + 1] = sin_[k] * rhs_ls[k]; rhs_ls[k] = cos_[k] * rhs_ls[k]
+            if abs(rhs_ls[k + 1]) < tol * float(nb) or abs(rhs_ls[k + 1]) < atol:
+                break
+        import scipy.linalg
+        yk = scipy.linalg.solve_triangular(hess[:k + 1, :k + 1], rhs_ls[:k + 1], lower=False)
+        coeffs = torch.from_numpy(yk.astype(np.float32)).to(rhs.device)
+        return torch.stack(basis[:k + 1], dim=0).T @ coeffs
+
+    def _restore_batch_generic(self, noisy_img, degradation, sigma_noise, iter_cb=None, cb_iterations=None):
+        args = self.args
+        steps, delta = int(args.steps_ode), 1 / args.steps_ode
+        first = int(steps * args.start_time)
+        B = noisy_img.shape[0]
+        dev = noisy_img.device
+        Hop, Hadj = degradation.H, degradation.H_adj
+        y = noisy_img.contiguous().float()
+        x = self.initialization(Hadj(y.clone()), args.start_time).contiguous().float()
+        label = 999.0 if args.model == "rectified" else 1.0
+        self.last_callback_seconds = 0.0
+        for it in range(first, steps):
+            t1, omt, rt2, coef = self._scalars(it, delta, args.problem, B, dev)
+            t1, omt, rt2, coef = (v.to(dev).float() for v in (t1, omt, rt2, coef))
+            vt = self.model.forward_retain(x, t1 * label if label != 1.0 else t1)                 # v_theta(x, t), activations kept
+            dres = y - Hop(x + omt.view(-1, 1, 1, 1) * vt)                                        # ot_ode.py:74-77
+            sol = torch.zeros_like(dres)
+            for i in range(B):
+                def apply_c(z, i=i):
+                    zz = z.reshape(dres.shape[1:]).unsqueeze(0)
+                    return (rt2[i] * Hop(Hadj(zz)) + sigma_noise ** 2 * zz).reshape(-1)
+                sol[i] = self._gmres(apply_c, dres[i].reshape(-1), 100).reshape(dres[i].shape)
+            vec = Hadj(sol).contiguous()
+            g = self.model.backward(vec)                                                          # J^T vec (ot_ode.py:137-138)
+            x = x + delta * (vt + coef.view(-1, 1, 1, 1) * (vec + omt.view(-1, 1, 1, 1) * g))    # :141-147
+            if iter_cb is not None and (cb_iterations is None or it in cb_iterations):
+                t_cb = perf_counter(); iter_cb(it, x); self.last_callback_seconds += perf_counter() - t_cb
         return x
 
     def solve_ip(self, test_loader, degradation, sigma_noise, H_funcs=None):

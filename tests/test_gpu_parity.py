@@ -610,6 +610,33 @@ def test_ot_ode_trajectory_matches_reference(hip, golden, idx):
     assert float((p_hip - p_ref).abs().max()) <= 0.05, (p_hip, p_ref)
 
 
+def test_ot_ode_generic_operator_gmres_branch(hip, golden):
+    """A problem name outside the closed-form list takes the reference's generic branch (ot_ode.py:118-128): per-image GMRES on
+    r_t^2 H H^T + sigma^2 I.  Golden: the real reference's iterates with problem='gaussian_deblurring' on the circular blur."""
+    import pnpflow_amd.degradations as D
+    from pnpflow_amd.methods.ot_ode import OT_ODE
+    from pnpflow_amd.utils import CfgNode, psnr_per_image
+    g = golden("ot_ode_traj_tiny4_deblurring_gmres")
+    m, cfg, sd = model_for("tiny4")
+    S, steps, t0, sigma = cfg["input_height"], int(g["steps"]), float(g["start_time"]), float(g["sigma"])
+    args = CfgNode(dict(method="ot_ode", model="ot", problem="gaussian_deblurring", steps_ode=steps, start_time=t0, gamma="constant", max_batch=1,
+                        compute_time=False, compute_memory=False, save_results=False, batch=0))
+    solver = OT_ODE(m, torch.device("cuda"), args)
+    degradation = D.GaussianDeblurring(1.0, 61, "fft", 3, S)
+    y = torch.from_numpy(g["noisy"]).cuda()
+    solver.init_noise = det_normal((2, 3, S, S), 61, 1).cuda()
+    its = {}
+    x = solver.restore_batch(y, degradation, sigma, iter_cb=lambda it, xx: its.__setitem__(it, xx.clone().cpu()))
+    first = int(g["first"])
+    for it in (first, first + 1):
+        ref = g[f"x_it{it}"]
+        np.testing.assert_allclose(its[it].numpy(), ref, atol=1e-3 * float(np.abs(ref).max()), err_msg=f"iterate {it}")
+    clean = det_image((2, 3, S, S), 31)
+    p_hip = psnr_per_image(x, clean.cuda()).cpu()
+    p_ref = O.psnr_per_image(torch.from_numpy(g[f"x_it{steps - 1}"]), clean)
+    assert float((p_hip - p_ref).abs().max()) <= 0.05, (p_hip, p_ref)
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE configs C4 / C5 at their own sizes: the 256^2 net at the solver's U-Net batches (VERDICT r1, item 1)
 # ---------------------------------------------------------------------------------------------

@@ -332,3 +332,17 @@ def test_ncsnpp_oracle_matches_reference_module(golden, name):
         for k in g.files:
             if k.startswith("tap_"):
                 np.testing.assert_allclose(taps[k[4:]].numpy(), g[k], atol=1e-6)
+
+
+def test_oracle_ot_ode_generic_gmres_branch_matches_reference(golden):
+    """ot_ode.py:118-128 + utils.py:972-1109 (GMRES): the real reference's iterates for a problem name outside the closed forms."""
+    g = golden("ot_ode_traj_tiny4_deblurring_gmres")
+    cfg = O.unet_config(**CFGS["tiny4"]); sd = O.synthetic_state_dict(cfg, 0)
+    S = cfg["input_height"]; steps = int(g["steps"])
+    its = {}
+    O.ot_ode_restore(lambda a, t: O.unet_forward(sd, cfg, a, t), lambda a, t, v: O.unet_vjp(sd, cfg, a, t, v),
+                     O.GaussianDeblurring(1.0, 61, "fft", 3, S), "gaussian_deblurring", torch.from_numpy(g["noisy"]), float(g["sigma"]),
+                     steps=steps, start_time=float(g["start_time"]), gamma="constant", init_noise=det_normal((2, 3, S, S), 61, 1),
+                     record=lambda it, xx: its.__setitem__(it, xx.clone()))
+    for it in (int(g["first"]), int(g["first"]) + 1, steps - 1):
+        np.testing.assert_allclose(its[it].numpy(), g[f"x_it{it}"], atol=1e-5)

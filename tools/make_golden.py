@@ -225,11 +225,11 @@ def gen_traj(models, degr, utils, pnp):
         print("traj", tag, iterates[9].abs().mean().item())
 
 
-def gen_ot_ode(models, degr, utils):
+def gen_ot_ode(models, degr, utils, only=None):
     """Real OT_ODE.solve_ip (pnpflow/methods/ot_ode.py) iterates + a stand-alone VJP."""
     import pnpflow.methods.ot_ode as ot
     # stand-alone J^T vec on the MNIST net and the tiny4 net
-    for net, B in (("mnist", 2), ("tiny4", 2)):
+    for net, B in ((("mnist", 2), ("tiny4", 2)) if only is None else ()):
         m, cfg, sd = build_ref_unet(models, net)
         c = CFGS[net]; S = c["input_height"]
         x = det_normal((B, c["input_channels"], S, S), 51); vec = det_normal((B, c["input_channels"], S, S), 52)
@@ -242,7 +242,12 @@ def gen_ot_ode(models, degr, utils):
              ("tiny4_superresolution", "tiny4", "superresolution", lambda S: (degr.Superresolution(2, S, device="cpu"), 0.05), 0.1, "constant"),
              ("mnist_denoising", "mnist", "denoising", lambda S: (degr.Denoising(), 0.2), 0.3, "gamma_t"),
              ("tiny4_gaussian_deblurring_FFT", "tiny4", "gaussian_deblurring_FFT",
-              lambda S: (degr.GaussianDeblurring(1.0, 61, "fft", 3, S, device="cpu"), 0.05), 0.1, "constant")]
+              lambda S: (degr.GaussianDeblurring(1.0, 61, "fft", 3, S, device="cpu"), 0.05), 0.1, "constant"),
+             # any other problem name takes the reference's generic branch: per-image GMRES on r_t^2 H H^T + sigma^2 I (ot_ode.py:118-128)
+             ("tiny4_deblurring_gmres", "tiny4", "gaussian_deblurring",
+              lambda S: (degr.GaussianDeblurring(1.0, 61, "fft", 3, S, device="cpu"), 0.2), 0.3, "constant")]
+    if only is not None:
+        cases = [c for c in cases if c[0] in only]
     steps, B = 10, 2
     for tag, net, problem, mk, t0, gamma in cases:
         m, cfg, sd = build_ref_unet(models, net)
@@ -485,3 +490,5 @@ if __name__ == "__main__":
         gen_ops()
     if "ncsnpp" in which:
         gen_ncsnpp()
+    if "gmres" in which:
+        gen_ot_ode(models, degr, utils, only=("tiny4_deblurring_gmres",))

@@ -729,7 +729,7 @@ static int unet_walk(pf_engine* e, Builder& bd, Plan* plan) {
 #include "engine_ncsnpp.inc"
 
 static int build_plan(pf_engine* e, int B, bool retain, Plan** out_plan) {
-    const int key = (B * 2 + (retain ? 1 : 0)) * 2 + (e->precision ? 1 : 0);      // the precision mode selects kernels at build time (modes 1 and 2 share plans: same launches, the term count is a run-time argument)
+    const int key = (B * 2 + (retain ? 1 : 0)) * 3 + e->precision;      // the precision mode selects kernels at build time (one plan per mode: pf_unet_backward must meet the mode of its retained forward)
     auto it = e->plans.find(key);
     if (it != e->plans.end()) { *out_plan = e->last_plan = it->second.get(); it->second->last_used = ++e->plan_clock; return PF_OK; }
     // bounded cache: a plan owns its activation buffers (GBs at the BASELINE sizes), so the least recently used one is

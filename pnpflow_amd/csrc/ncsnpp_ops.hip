@@ -7,6 +7,7 @@
 //   nx_temb_kernel         Gaussian Fourier features of log(sigma) -> 2-layer MLP -> every block's Dense_0 (ncsnpp.py:223-246)
 //   img_to_nhwc32 / back   image boundary of the net
 #include <algorithm>
+#include <cstdlib>
 #include "pf_common.h"
 
 namespace pf {
@@ -78,10 +79,100 @@ __global__ __launch_bounds__(256) void fir_nhwc_kernel(const FirParams p) {
     }
 }
 
+// The two shapes the net uses - 4 x 4 taps with (up 2, pad0 2) or (down 2, pad0 1), which are also each other's adjoints - with
+// compile-time tap loops and no divisions: a workgroup walks whole output rows (row validity is uniform), a thread one (pixel,
+// channel quad) per step.  Per output: 2 x 2 taps (up) / 4 x 4 taps (down), all requested before the first use.
+template <bool ACT, bool RAW, int UP>
+__global__ __launch_bounds__(256) void fir4_nhwc_kernel(const FirParams p) {
+    constexpr int DOWN = UP == 2 ? 1 : 2, PAD0 = UP == 2 ? 2 : 1, NT = UP == 2 ? 2 : 4, SH = UP == 2 ? 1 : 0;
+    __shared__ float s_k[16];
+    __shared__ float s_sum[2 * 512];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int cq = p.C / 4, lanes_p = 256 / cq;
+    if (tid < 16) s_k[tid] = p.k2d[(3 - tid / 4) * 4 + (3 - tid % 4)];       // flipped taps (op/upfirdn2d.py:170-171)
+    if (RAW && p.stats_raw != nullptr) for (int i = tid; i < 2 * p.C; i += 256) s_sum[i] = 0.f;
+    __syncthreads();
+    const int q = tid % cq, pr = tid / cq;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ACT && pr < lanes_p) {
+        sc = *reinterpret_cast<const float4*>(p.coef + ((size_t)b * 2 + 0) * p.coef_stride + q * 4);
+        sh = *reinterpret_cast<const float4*>(p.coef + ((size_t)b * 2 + 1) * p.coef_stride + q * 4);
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int rows = max(1, FIR_PPB / p.W);
+    const int oy_lo = blockIdx.x * rows, oy_hi = min(p.H, oy_lo + rows);
+    if (pr < lanes_p) {
+        const float* src = p.src + (size_t)b * p.Hs * p.Ws * p.C + q * 4;
+        for (int oy = oy_lo; oy < oy_hi; ++oy) {
+            const int by = oy * DOWN - PAD0, ky0 = UP == 2 ? (by & 1) : 0;
+            for (int ox = pr; ox < p.W; ox += lanes_p) {
+                const int bx = ox * DOWN - PAD0, kx0 = UP == 2 ? (bx & 1) : 0;
+                float4 v[NT][NT];
+                unsigned inside = 0u;                      // bit a * NT + c: tap (a, c) lies inside the image
+#pragma unroll
+                for (int a = 0; a < NT; ++a) {
+                    const int iy = (by + ky0 + a * UP) >> SH;
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) {
+                        const int ix = (bx + kx0 + c * UP) >> SH;
+                        const bool ok = iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
+                        v[a][c] = ok ? *reinterpret_cast<const float4*>(src + ((size_t)iy * p.Ws + ix) * p.C) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (ok) inside |= 1u << (a * NT + c);
+                    }
+                }
+                float4 aa = make_float4(0.f, 0.f, 0.f, 0.f), ar = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) {
+                        const float w = s_k[(ky0 + a * UP) * 4 + kx0 + c * UP];
+                        const float4 x = v[a][c];
+                        if (ACT) {
+                            if (inside & (1u << (a * NT + c))) {         // a tap outside the image contributes nothing (SiLU(sh) would)
+                                aa.x = fmaf(nx_silu(fmaf(x.x, sc.x, sh.x)), w, aa.x); aa.y = fmaf(nx_silu(fmaf(x.y, sc.y, sh.y)), w, aa.y);
+                                aa.z = fmaf(nx_silu(fmaf(x.z, sc.z, sh.z)), w, aa.z); aa.w = fmaf(nx_silu(fmaf(x.w, sc.w, sh.w)), w, aa.w);
+                                if (RAW) { ar.x = fmaf(x.x, w, ar.x); ar.y = fmaf(x.y, w, ar.y); ar.z = fmaf(x.z, w, ar.z); ar.w = fmaf(x.w, w, ar.w); }
+                            }
+                        } else if (RAW) {
+                            ar.x = fmaf(x.x, w, ar.x); ar.y = fmaf(x.y, w, ar.y); ar.z = fmaf(x.z, w, ar.z); ar.w = fmaf(x.w, w, ar.w);
+                        }
+                    }
+                const size_t o = (((size_t)b * p.H + oy) * p.W + ox) * p.C + q * 4;
+                if (ACT) *reinterpret_cast<float4*>(p.out_act + o) = aa;
+                if (RAW) {
+                    *reinterpret_cast<float4*>(p.out_raw + o) = ar;
+                    s1[0] += ar.x; s1[1] += ar.y; s1[2] += ar.z; s1[3] += ar.w;
+                    s2[0] += ar.x * ar.x; s2[1] += ar.y * ar.y; s2[2] += ar.z * ar.z; s2[3] += ar.w * ar.w;
+                }
+            }
+        }
+    }
+    if (RAW && p.stats_raw != nullptr) {
+        if (pr < lanes_p) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { atomicAdd(&s_sum[(q * 4 + j) * 2], s1[j]); atomicAdd(&s_sum[(q * 4 + j) * 2 + 1], s2[j]); }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * p.C; i += 256) unsafeAtomicAdd(p.stats_raw + (size_t)b * p.C * 2 + i, (double)s_sum[i]);
+    }
+}
+
+template <int UP>
+static void launch_fir4(const FirParams& p, hipStream_t s) {
+    const int rows = std::max(1, FIR_PPB / p.W);
+    const dim3 grid((p.H + rows - 1) / rows, p.B);
+    if (p.out_act && p.out_raw) hipLaunchKernelGGL((fir4_nhwc_kernel<true, true, UP>), grid, dim3(256), 0, s, p);
+    else if (p.out_act) hipLaunchKernelGGL((fir4_nhwc_kernel<true, false, UP>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((fir4_nhwc_kernel<false, true, UP>), grid, dim3(256), 0, s, p);
+}
+
 hipError_t launch_fir_nhwc(const FirParams& p, hipStream_t s) {
     if (p.C % 4 || p.C / 4 > 128 || p.C < 4 || p.K < 1 || p.K > 8 || p.up < 1 || p.down < 1 || (p.out_act == nullptr && p.out_raw == nullptr) ||
         (p.out_act != nullptr && p.coef == nullptr))
         return hipErrorInvalidValue;
+    static const bool generic_only = getenv("PNPFLOW_HIP_FIR_GENERIC") != nullptr;
+    if (!generic_only && p.K == 4 && p.up == 2 && p.down == 1 && p.pad0 == 2) { launch_fir4<2>(p, s); return hipGetLastError(); }
+    if (!generic_only && p.K == 4 && p.up == 1 && p.down == 2 && p.pad0 == 1) { launch_fir4<1>(p, s); return hipGetLastError(); }
     const dim3 grid((p.H * p.W + FIR_PPB - 1) / FIR_PPB, p.B);
     if (p.out_act && p.out_raw) hipLaunchKernelGGL((fir_nhwc_kernel<true, true>), grid, dim3(256), 0, s, p);
     else if (p.out_act) hipLaunchKernelGGL((fir_nhwc_kernel<true, false>), grid, dim3(256), 0, s, p);

@@ -143,6 +143,7 @@ FWD_FLOPS = {128: 49.78e9, 256: 189.44e9}      # algorithmic FLOP per image per 
 # MI355X_MICROARCH.md prescribes for gfx950): {workload: (bytes per launch, committed summary it comes from)}
 TRAFFIC = {
     "c2": (473.5e6, "profiles/r02_pmc_fwd_c2_{FETCH,WRITE}_SIZE.md (142 conv launches per forward of 160 images)"),
+    "c3": (984.4e6, "profiles/r02_pmc_fwd_c3_{FETCH,WRITE}_SIZE.md (142 conv launches per forward of 320 images)"),
     "c4": (1082.9e6, "profiles/r02_pmc_fwd_c4_{FETCH,WRITE}_SIZE.md (116 conv launches per forward of 80 images at 256^2)"),
 }
 

@@ -142,9 +142,9 @@ FWD_FLOPS = {128: 49.78e9, 256: 189.44e9}      # algorithmic FLOP per image per 
 # HBM bytes per conv-GEMM launch measured with rocprofv3 --pmc (FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled as
 # MI355X_MICROARCH.md prescribes for gfx950): {workload: (bytes per launch, committed summary it comes from)}
 TRAFFIC = {
-    "c2": (473.5e6, "profiles/r02_pmc_fwd_c2_{FETCH,WRITE}_SIZE.md (142 conv launches per forward of 160 images)"),
-    "c3": (984.4e6, "profiles/r02_pmc_fwd_c3_{FETCH,WRITE}_SIZE.md (142 conv launches per forward of 320 images)"),
-    "c4": (1082.9e6, "profiles/r02_pmc_fwd_c4_{FETCH,WRITE}_SIZE.md (116 conv launches per forward of 80 images at 256^2)"),
+    "c2": (419.3e6, "profiles/r02_pmc_fwd_c2_xcd_{FETCH,WRITE}_SIZE.md (142 conv launches per forward of 160 images; 473.5 MB before the XCD-aware workgroup mapping)"),
+    "c3": (836.2e6, "profiles/r02_pmc_fwd_c3_xcd_{FETCH,WRITE}_SIZE.md (142 conv launches per forward of 320 images; 984.4 MB before)"),
+    "c4": (954.0e6, "profiles/r02_pmc_fwd_c4_xcd_{FETCH,WRITE}_SIZE.md (116 conv launches per forward of 80 images at 256^2; 1082.9 MB before)"),
 }
 
 

@@ -73,11 +73,22 @@ __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16
     float* s_sh = s_sc + ((p.gn_C + 3) & ~3);
 
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
-    int bid = blockIdx.x;
+    // Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2).  With the XCD-aware mapping workgroup L works on
+    // item (L % 8) * (total / 8) + L / 8 of the (tile-major, N-block-minor) list: an XCD walks a contiguous band of tiles - halo
+    // rows / columns and the second N-block of a tile are L2 hits instead of another trip to the memory side.
+    int bid, nb;
+    if (p.xcd_map) {
+        const int NBk = gridDim.y == 1 ? (p.Cout + BN - 1) / BN : 1;
+        const int total = gridDim.x;
+        const int work = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
+        bid = work / NBk; nb = work % NBk;
+    } else {
+        bid = blockIdx.x; nb = blockIdx.y;
+    }
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
-    const int oy0 = ty * TH, ox0 = tx * TW, n0 = blockIdx.y * BN;
+    const int oy0 = ty * TH, ox0 = tx * TW, n0 = nb * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     const int wm = wave % WM, wn = wave / WM;
     const int Hv = UP ? 2 * p.Hs : p.Hs, Wv = UP ? 2 * p.Ws : p.Ws;
@@ -502,6 +513,9 @@ static hipError_t launch_cfg16(const ConvParams& p, hipStream_t stream) {
     const size_t lds = (size_t)((PH * RS > EPI ? PH * RS : EPI) + 2 * ((p.gn_C + 3) & ~3)) * 4;
     const int tiles = p.B * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
     dim3 grid(tiles, (p.Cout + BN - 1) / BN);
+    static const bool xcd_env = !(getenv("PNPFLOW_HIP_XCD") && atoi(getenv("PNPFLOW_HIP_XCD")) == 0);
+    ConvParams pp = p; pp.xcd_map = 0;
+    if (xcd_env && ((long)grid.x * grid.y) % 8 == 0) { pp.xcd_map = 1; grid = dim3(grid.x * grid.y, 1); }
     if constexpr (S == 1 && UP == 0) {
         if (p.gnb_x != nullptr) {        // adjoint conv with the fused GroupNorm-backward first stage
             static bool attr_set_g = false;
@@ -511,7 +525,7 @@ static hipError_t launch_cfg16(const ConvParams& p, hipStream_t stream) {
                 if (e != hipSuccess) return e;
                 attr_set_g = true;
             }
-            hipLaunchKernelGGL(kg, grid, dim3(256), lds, stream, p);
+            hipLaunchKernelGGL(kg, grid, dim3(256), lds, stream, pp);
             return hipGetLastError();
         }
     }
@@ -523,7 +537,7 @@ static hipError_t launch_cfg16(const ConvParams& p, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, pp);
     return hipGetLastError();
 }
 

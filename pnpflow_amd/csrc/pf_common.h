@@ -65,6 +65,7 @@ struct ConvParams {
     int gnb_Ct, gnb_coff, gnb_silu;
     double* gnb_sum;             // [B][gnb_Ct][2] += (sum dyhat, sum dyhat*yhat)
     unsigned long long* trace;   // profiling only: per-launch phase cycle sums [prologue, staging, k-loop, epilogue, stats, workgroups], or nullptr
+    int xcd_map;          // split-fp16 kernel, set by its launcher: 1 = workgroup -> (tile, N-block) mapping that keeps neighbouring tiles and the N-blocks of a tile on one XCD
     int dbg;              // ablation switches for profiling (0 in production): 1 skip MFMAs, 2 skip re-staging, 4 skip LDS A reads, 8 skip B loads, 16 skip epilogue global traffic
 };
 

@@ -172,6 +172,12 @@ struct pf_engine {
 
 static thread_local std::string g_create_err;
 
+// PNPFLOW_HIP_POISON=1 (tests): every fresh device allocation of the engine is filled with 0xFF bytes (NaNs as fp32 / fp64), so that a
+// read of memory the engine never wrote shows up as a numeric-health error or a parity failure instead of depending on what
+// the allocation happened to hold (a fresh box hands out zeroed HBM; the second process on a box does not)
+static bool poison_enabled() { static const bool on = getenv("PNPFLOW_HIP_POISON") && atoi(getenv("PNPFLOW_HIP_POISON")) != 0; return on; }
+static void poison(void* p, size_t bytes) { if (poison_enabled() && p) hipMemset(p, 0xFF, bytes); }
+
 // selects the engine's device for the duration of an ABI call and restores the caller's current device afterwards
 struct DeviceGuard {
     int prev = -1; hipError_t err = hipSuccess;
@@ -372,6 +378,7 @@ struct Builder {
         if (it != free_list.end()) { void* p = it->second; free_list.erase(it); return (float*)p; }
         void* p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) { ok = false; e->err = "hipMalloc failed (activations)"; return nullptr; }
+        poison(p, bytes);
         plan->allocs.push_back(p); sizes[p] = bytes; plan->bytes += (int64_t)bytes; e->bytes += (int64_t)bytes;
         return (float*)p;
     }
@@ -765,6 +772,7 @@ static int build_plan(pf_engine* e, int B, bool retain, Plan** out_plan) {
     // statistics slab
     void* slab = nullptr;
     if (hipMalloc(&slab, std::max<size_t>(bd.stats_bytes, 256)) != hipSuccess) { e->err = "hipMalloc failed (stats)"; return PF_ERR_HIP; }
+    poison(slab, std::max<size_t>(bd.stats_bytes, 256));
     plan->allocs.push_back(slab); plan->bytes += (int64_t)std::max<size_t>(bd.stats_bytes, 256); e->bytes += (int64_t)std::max<size_t>(bd.stats_bytes, 256);
     for (auto& op : plan->ops) fix_stats(op, (double*)slab);
     for (auto& op : plan->bops) fix_stats(op, (double*)slab);
@@ -1072,6 +1080,23 @@ static int build_backward(pf_engine* e, Plan* plan, Builder& bd) {
     return PF_OK;
 }
 
+// zero fill as a KERNEL: inside the captured per-step graphs a hipMemsetAsync becomes a memset node; the OT-ODE graph (three of them
+// per Euler step) produced non-finite statistics in ~1 of 3 runs of 270 steps while the same launches issued eagerly never did
+// (profiles/r02_ab_variants_same_box.txt) - with kernels for the fills every node of the graph is a kernel node on one queue
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint4* p, size_t n16, unsigned char* tail, size_t ntail) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = z;
+    if (blockIdx.x == 0) for (size_t i = threadIdx.x; i < ntail; i += 256) tail[i] = 0;
+}
+static hipError_t zero_fill(void* ptr, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    if (((uintptr_t)ptr & 15) != 0) return hipMemsetAsync(ptr, 0, bytes, s);      // (allocations are 256-B aligned: not taken)
+    const size_t n16 = bytes / 16, ntail = bytes % 16;
+    const unsigned g = (unsigned)std::min<size_t>((n16 + 255) / 256 + 1, 2048);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(g), dim3(256), 0, s, (uint4*)ptr, n16, (unsigned char*)ptr + n16 * 16, ntail);
+    return hipGetLastError();
+}
+
 #include "engine_ncsnpp_bwd.inc"
 
 static hipError_t dispatch_conv(pf_engine* e, const Op& op, hipStream_t s);
@@ -1086,7 +1111,7 @@ static int run_backward(pf_engine* e, Plan* plan, const float* vec, float* g, hi
     for (auto& op : plan->bops) {
         hipError_t r = hipSuccess;
         switch (op.kind) {
-            case OP_MEMSET: if (op.bytes) r = hipMemsetAsync(op.ptr, 0, op.bytes, s); break;
+            case OP_MEMSET: if (op.bytes) r = zero_fill(op.ptr, op.bytes, s); break;
             case OP_BEGIN: { EdgeConvParams ep = op.ep; ep.in = vec; r = launch_begin_conv(ep, s); break; }
             case OP_END: { EdgeConvParams ep = op.ep; ep.out = g; r = launch_end_conv(ep, s); break; }
             case OP_CONV: r = dispatch_conv(e, op, s); break;
@@ -1130,7 +1155,7 @@ static int run_plan(pf_engine* e, Plan* plan, const float* x, const float* t, fl
     for (auto& op : plan->ops) {
         hipError_t r = hipSuccess;
         switch (op.kind) {
-            case OP_MEMSET: r = hipMemsetAsync(op.ptr, 0, op.bytes, s); break;
+            case OP_MEMSET: r = zero_fill(op.ptr, op.bytes, s); break;
             case OP_TEMB: { TembParams tp = op.tp; tp.t = t; r = launch_temb(tp, s); break; }
             case OP_BEGIN: { EdgeConvParams ep = op.ep; ep.in = x; r = launch_begin_conv(ep, s); break; }
             case OP_CONV:
@@ -1532,6 +1557,8 @@ static int ensure_solver(pf_engine* e, int B, size_t n, size_t ny, int steps, in
     HIPCHK(e, hipMalloc(&b.t_cur, (size_t)ns * B * 4)); HIPCHK(e, hipMalloc(&b.coef_cur, (size_t)ns * B * 4));
     HIPCHK(e, hipMalloc(&b.iter, 64));
     HIPCHK(e, hipMalloc(&b.y, (size_t)B * ny * 4)); HIPCHK(e, hipMalloc(&b.rng, 64));
+    if (poison_enabled()) { poison(b.x, tot * 4); poison(b.z, tot * 4); poison(b.zt, ns * tot * 4); poison(b.v, ns * tot * 4); poison(b.scratch, 2 * tot * 4); poison(b.y, (size_t)B * ny * 4);
+                            poison(b.t_cur, (size_t)ns * B * 4); poison(b.coef_cur, (size_t)ns * B * 4); }
     b.B = B; b.n = n; b.ny = ny; b.steps = steps; b.ns = ns;
     b.bytes = (int64_t)((1 + 1 + 2 * (size_t)ns + 2) * tot * 4 + (size_t)B * ny * 4 + 2 * (size_t)steps * 4 + 2 * (size_t)ns * B * 4 + 128);
     e->bytes += b.bytes;
@@ -1697,6 +1724,7 @@ static int ensure_ode(pf_engine* e, int B, size_t n, size_t ny, int steps, bool 
     const size_t scr = blur ? 4 * tot + 2 * (size_t)H : 0;
     if (scr) HIPCHK(e, hipMalloc(&b.scratch, scr * 4));
     HIPCHK(e, hipMalloc(&b.tab, (size_t)4 * steps * 4)); HIPCHK(e, hipMalloc(&b.cur, (size_t)4 * B * 4)); HIPCHK(e, hipMalloc(&b.iter, 64));
+    if (poison_enabled()) { for (float* q : {b.x, b.vt, b.vec, b.g}) poison(q, tot * 4); poison(b.y, (size_t)B * ny * 4); poison(b.scratch, scr * 4); poison(b.tab, (size_t)4 * steps * 4); poison(b.cur, (size_t)4 * B * 4); }
     b.B = B; b.n = n; b.ny = ny; b.steps = steps; b.blur = blur;
     b.bytes = (int64_t)(4 * tot * 4 + (size_t)B * ny * 4 + scr * 4 + (size_t)4 * steps * 4 + (size_t)4 * B * 4 + 64);
     e->bytes += b.bytes;

@@ -645,6 +645,7 @@ hipError_t launch_ot_ode_update(float* x, const float* vt, const float* vec, con
 }
 
 // ---- power-of-two normalisation of the VJP input (keeps the backward's fp16-split operands in range) -----
+__global__ void zero_u32_kernel(unsigned int* p) { *p = 0u; }
 __global__ __launch_bounds__(256) void absmax_kernel(const float* x, int64_t n, unsigned int* amax_bits) {
     float m = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
@@ -664,7 +665,8 @@ __global__ __launch_bounds__(256) void scale_kernel(const float* in, float* out,
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = in[i] * s;
 }
 hipError_t launch_vjp_normalise(const float* vec, float* vec_scaled, int64_t n, unsigned int* amax_bits, float* scale, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(amax_bits, 0, sizeof(unsigned int), s);
+    hipLaunchKernelGGL(zero_u32_kernel, dim3(1), dim3(1), 0, s, amax_bits);      // a kernel, not a memset node (see engine.hip zero_fill)
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const unsigned g = (unsigned)std::min<int64_t>((n + 255) / 256, 1024);
     hipLaunchKernelGGL(absmax_kernel, dim3(g), dim3(256), 0, s, vec, n, amax_bits);

@@ -610,6 +610,30 @@ def test_ot_ode_trajectory_matches_reference(hip, golden, idx):
     assert float((p_hip - p_ref).abs().max()) <= 0.05, (p_hip, p_ref)
 
 
+def test_ot_ode_graph_replays_are_reproducible_at_size(hip):
+    """Three full OT-ODE restorations (90 captured-graph replays each) of the 256^2 net must agree and stay finite.  With the
+    zero fills of the statistics slabs as hipMemset NODES inside the per-step graph, ~1 in 3 such runs produced non-finite
+    statistics (the same launches issued eagerly never did); the fills are kernels now (engine.hip `zero_fill`)."""
+    import pnpflow_amd.degradations as D
+    from pnpflow_amd.methods.ot_ode import OT_ODE
+    from pnpflow_amd.utils import CfgNode
+    m, cfg, sd = model_for("afhq256")
+    B, S = 8, 256
+    args = CfgNode(dict(method="ot_ode", model="ot", problem="random_inpainting", steps_ode=100, start_time=0.1, gamma="constant", max_batch=1,
+                        compute_time=False, compute_memory=False, save_results=False, batch=0))
+    solver = OT_ODE(m, torch.device("cuda"), args)
+    degradation = D.RandomInpainting(0.7)
+    clean = det_image((B, 3, S, S), 33)
+    y = (degradation.H(clean.cuda()) + 0.01 * det_normal((B, 3, S, S), 34).cuda()).contiguous()
+    solver.init_noise = det_normal((B, 3, S, S), 35).cuda()
+    outs = [solver.restore_batch(y, degradation, 0.01).cpu() for _ in range(3)]
+    for o in outs:
+        assert bool(torch.isfinite(o).all())
+    scale = float(outs[0].abs().max())
+    for o in outs[1:]:
+        assert float((o - outs[0]).abs().max()) <= 1e-3 * scale        # only the order of the fp64 statistics atomics differs
+
+
 def test_ot_ode_generic_operator_gmres_branch(hip, golden):
     """A problem name outside the closed-form list takes the reference's generic branch (ot_ode.py:118-128): per-image GMRES on
     r_t^2 H H^T + sigma^2 I.  Golden: the real reference's iterates with problem='gaussian_deblurring' on the circular blur."""

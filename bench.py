@@ -22,7 +22,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # HBM bytes per conv-GEMM launch from the PMC passes in profiles/ (2 x FETCH_SIZE + WRITE_SIZE, one c2 forward at 160 images)
-TRAFFIC_C2_F16X3 = 478.7e6
 
 WORKLOADS = {
     # name: (dim, batch per GPU, problem, alpha, steps_pnp, num_samples, net config, GFLOP per image per forward)

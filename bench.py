@@ -21,8 +21,6 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# HBM bytes per conv-GEMM launch from the PMC passes in profiles/ (2 x FETCH_SIZE + WRITE_SIZE, one c2 forward at 160 images)
-
 WORKLOADS = {
     # name: (dim, batch per GPU, problem, alpha, steps_pnp, num_samples, net config, GFLOP per image per forward)
     "c2": dict(dim=128, B=32, problem="inpainting", alpha=0.5, steps=100, ns=5, nres=6, label="CelebA-128 box-inpainting pnp_flow B=32/GPU 100x5 (BASELINE configs[1])"),

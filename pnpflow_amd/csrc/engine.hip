@@ -175,8 +175,13 @@ static thread_local std::string g_create_err;
 // PNPFLOW_HIP_POISON=1 (tests): every fresh device allocation of the engine is filled with 0xFF bytes (NaNs as fp32 / fp64), so that a
 // read of memory the engine never wrote shows up as a numeric-health error or a parity failure instead of depending on what
 // the allocation happened to hold (a fresh box hands out zeroed HBM; the second process on a box does not)
-static bool poison_enabled() { static const bool on = getenv("PNPFLOW_HIP_POISON") && atoi(getenv("PNPFLOW_HIP_POISON")) != 0; return on; }
-static void poison(void* p, size_t bytes) { if (poison_enabled() && p) hipMemset(p, 0xFF, bytes); }
+static int poison_mask() { static const int m = getenv("PNPFLOW_HIP_POISON") ? atoi(getenv("PNPFLOW_HIP_POISON")) : 0; return m == 1 ? 7 : m; }      // 1 = everything; else bit 0 plans, bit 1 PnP-Flow buffers, bit 2 OT-ODE buffers
+static bool poison_enabled() { return poison_mask() != 0; }
+static void poison(void* p, size_t bytes, int group = 1) {
+    // (device-wide synchronisation on both sides: the fill runs on the NULL stream, which does not order with the non-blocking streams
+    //  the solvers hand over - without it the fill can land AFTER the first kernels that write the buffer)
+    if ((poison_mask() & group) && p) { hipDeviceSynchronize(); hipMemset(p, 0xFF, bytes); hipDeviceSynchronize(); }
+}
 
 // selects the engine's device for the duration of an ABI call and restores the caller's current device afterwards
 struct DeviceGuard {
@@ -413,7 +418,7 @@ static void ensure_coef(Builder& bd) {
     plan->coef = bd.acquire((size_t)bd.B * 2 * Plan::COEF_STRIDE);
     plan->scale = bd.acquire((size_t)bd.B * 8);
     plan->flags = reinterpret_cast<unsigned int*>(bd.acquire(64));
-    if (plan->flags) hipMemset(plan->flags, 0, 64);
+    if (plan->flags) { hipMemset(plan->flags, 0, 64); hipDeviceSynchronize(); }      // (NULL-stream fill: not ordered with the non-blocking streams the launches use)
 }
 
 static ConvParams with_coef(Builder& bd, ConvParams p, std::vector<Op>& ops) {
@@ -1284,7 +1289,7 @@ static int check_flags(pf_engine* e) {
         unsigned int f[2] = {0, 0};
         HIPCHK(e, hipMemcpy(f, pl->flags, sizeof f, hipMemcpyDeviceToHost));
         if (f[0]) {
-            bad = true; HIPCHK(e, hipMemset(pl->flags, 0, sizeof f));
+            bad = true; HIPCHK(e, hipMemset(pl->flags, 0, sizeof f)); HIPCHK(e, hipDeviceSynchronize());
             char buf[160] = "";
             const int id = (int)f[1];                 // the op that follows the flagging finalisation is the consuming conv
             if (id >= 1 && id < (int)pl->ops.size() && pl->ops[id].kind == OP_CONV)
@@ -1557,8 +1562,8 @@ static int ensure_solver(pf_engine* e, int B, size_t n, size_t ny, int steps, in
     HIPCHK(e, hipMalloc(&b.t_cur, (size_t)ns * B * 4)); HIPCHK(e, hipMalloc(&b.coef_cur, (size_t)ns * B * 4));
     HIPCHK(e, hipMalloc(&b.iter, 64));
     HIPCHK(e, hipMalloc(&b.y, (size_t)B * ny * 4)); HIPCHK(e, hipMalloc(&b.rng, 64));
-    if (poison_enabled()) { poison(b.x, tot * 4); poison(b.z, tot * 4); poison(b.zt, ns * tot * 4); poison(b.v, ns * tot * 4); poison(b.scratch, 2 * tot * 4); poison(b.y, (size_t)B * ny * 4);
-                            poison(b.t_cur, (size_t)ns * B * 4); poison(b.coef_cur, (size_t)ns * B * 4); }
+    if (poison_enabled()) { poison(b.x, tot * 4, 2); poison(b.z, tot * 4, 2); poison(b.zt, ns * tot * 4, 2); poison(b.v, ns * tot * 4, 2); poison(b.scratch, 2 * tot * 4, 2); poison(b.y, (size_t)B * ny * 4, 2);
+                            poison(b.t_cur, (size_t)ns * B * 4, 2); poison(b.coef_cur, (size_t)ns * B * 4, 2); }
     b.B = B; b.n = n; b.ny = ny; b.steps = steps; b.ns = ns;
     b.bytes = (int64_t)((1 + 1 + 2 * (size_t)ns + 2) * tot * 4 + (size_t)B * ny * 4 + 2 * (size_t)steps * 4 + 2 * (size_t)ns * B * 4 + 128);
     e->bytes += b.bytes;
@@ -1724,7 +1729,7 @@ static int ensure_ode(pf_engine* e, int B, size_t n, size_t ny, int steps, bool 
     const size_t scr = blur ? 4 * tot + 2 * (size_t)H : 0;
     if (scr) HIPCHK(e, hipMalloc(&b.scratch, scr * 4));
     HIPCHK(e, hipMalloc(&b.tab, (size_t)4 * steps * 4)); HIPCHK(e, hipMalloc(&b.cur, (size_t)4 * B * 4)); HIPCHK(e, hipMalloc(&b.iter, 64));
-    if (poison_enabled()) { for (float* q : {b.x, b.vt, b.vec, b.g}) poison(q, tot * 4); poison(b.y, (size_t)B * ny * 4); poison(b.scratch, scr * 4); poison(b.tab, (size_t)4 * steps * 4); poison(b.cur, (size_t)4 * B * 4); }
+    if (poison_enabled()) { for (float* q : {b.x, b.vt, b.vec, b.g}) poison(q, tot * 4, 4); poison(b.y, (size_t)B * ny * 4, 4); poison(b.scratch, scr * 4, 4); poison(b.tab, (size_t)4 * steps * 4, 4); poison(b.cur, (size_t)4 * B * 4, 4); }
     b.B = B; b.n = n; b.ny = ny; b.steps = steps; b.blur = blur;
     b.bytes = (int64_t)(4 * tot * 4 + (size_t)B * ny * 4 + scr * 4 + (size_t)4 * steps * 4 + (size_t)4 * B * 4 + 64);
     e->bytes += b.bytes;

@@ -301,3 +301,31 @@ def test_rectified_model_surface():
     from oracle import ncsnpp_oracle as NO
     shapes = NO.ncsnpp_param_shapes(NO.ncsnpp_config())
     assert len(shapes) == 645 and shapes["all_modules.0.W"] == (128,) and shapes["all_modules.3.weight"] == (128, 3, 3, 3)
+
+
+def test_ncsnpp_create_rejects_unsupported_configurations_before_touching_a_device():
+    """pf_ncsnpp_create validates the hyper-parameters first (works without a GPU): widths that are not multiples of 32, too wide
+    levels, odd FIR lengths, un-centred data, sizes the level count does not divide."""
+    import ctypes as C
+    import pnpflow_amd._lib as L
+    lib = L.load()
+
+    def cfg(**kw):
+        c = L.PfNcsnppCfg()
+        base = dict(image_size=32, num_channels=3, nf=32, num_levels=2, num_res_blocks=1, num_attn_resolutions=1, fir_taps=4,
+                    skip_rescale=1, scale_by_sigma=1, centered=1)
+        base.update(kw)
+        for k, v in base.items():
+            setattr(c, k, v)
+        c.ch_mult[0], c.ch_mult[1] = 1, kw.get("mult1", 2)
+        c.attn_resolutions[0] = 16
+        for i, v in enumerate([1, 3, 3, 1]):
+            c.fir_kernel[i] = float(v)
+        return c
+
+    for bad in (dict(nf=48), dict(nf=160), dict(mult1=16), dict(fir_taps=3), dict(centered=0), dict(image_size=33), dict(num_channels=4)):
+        h = C.c_void_p()
+        c = cfg(**{k: v for k, v in bad.items() if k != "mult1"}, **({"mult1": bad["mult1"]} if "mult1" in bad else {}))
+        assert lib.pf_ncsnpp_create(0, C.byref(c), C.byref(h)) == -1, bad
+        assert b"unsupported NCSN++ configuration" in lib.pf_last_error(None)
+    assert lib.pf_engine_set_solver_time_scale(None, 999.0) == -1

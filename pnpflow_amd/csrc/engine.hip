@@ -36,7 +36,7 @@ struct LevelDesc { std::vector<ResDesc> blocks; std::string resample; int res_ch
 
 struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; double* stats = nullptr; };
 
-enum OpKind { OP_MEMSET, OP_TEMB, OP_BEGIN, OP_CONV, OP_SOFTMAX, OP_ATTN, OP_END, OP_GN_COEF,
+enum OpKind { OP_MEMSET, OP_TEMB, OP_BEGIN, OP_CONV, OP_SOFTMAX, OP_ATTN, OP_END, OP_GN_COEF, OP_PREP,
               // NCSN++ net (engine_ncsnpp.inc)
               OP_NX_TEMB, OP_NX_IMG_IN, OP_NX_FIR, OP_NX_IMG_OUT,
               // backward-only
@@ -44,6 +44,8 @@ enum OpKind { OP_MEMSET, OP_TEMB, OP_BEGIN, OP_CONV, OP_SOFTMAX, OP_ATTN, OP_END
 struct Op {
     OpKind kind;
     ConvParams cp; int stride = 1, up = 0;
+    int dma = 0;                                    // OP_CONV: 1 = conv_dma.hip (its operands were written by the OP_PREP in front of it)
+    PrepParams pp{};
     EdgeConvParams ep;
     TembParams tp;
     void* ptr = nullptr; size_t bytes = 0;          // memset
@@ -137,6 +139,8 @@ struct pf_engine {
     std::vector<std::pair<std::string, int>> res_order;   // every ResidualBlock prefix (+cout), in forward order
     // device weights
     std::map<std::string, float*> dev;     // cache of uploaded / packed arrays
+    struct W16Src { std::string name; int lo, hi; };
+    std::map<const void*, W16Src> w16_src;  // split-fp16 repack -> the host tensor slice it was made from (for the hi-only repack of the single-term mode)
     std::vector<void*> weight_allocs;
     int temb_total = 0;
     std::map<std::string, int> temb_off;   // ResBlock prefix -> offset in the stacked temb projection
@@ -359,6 +363,31 @@ static const void* packed_conv16(pf_engine* e, const std::string& wname, int lo,
                 }
     std::vector<float> raw(out.size() / 2);
     memcpy(raw.data(), out.data(), out.size() * sizeof(_Float16));
+    const void* d = upload(e, key, raw);
+    if (d) e->w16_src[d] = {wname, lo, hi};
+    return d;
+}
+
+// hi-only repack of the same slice for the single-term (precision mode 2) LDS-DMA kernel: [slice16][tap][Cout][16 halfs], values
+// pre-scaled by 2^8 like the split repack (so that the epilogue's 2^-8 is shared) - no low halves are stored, fetched or multiplied
+static const void* packed_conv16h(pf_engine* e, const std::string& wname, int lo, int hi) {
+    const std::string key = wname + "#h1_" + std::to_string(lo) + ":" + std::to_string(hi);
+    auto it = e->dev.find(key);
+    if (it != e->dev.end()) return it->second;
+    const HostTensor& t = W(e, wname);
+    const int O = (int)t.shape[0], I = (int)t.shape[1], kk = (int)(t.shape[2] * t.shape[3]);
+    const int C = hi - lo, nchunk = (C + CONV_KC - 1) / CONV_KC;
+    std::vector<_Float16> out((size_t)nchunk * kk * O * 16, (_Float16)0.f);
+    for (int chn = 0; chn < nchunk; ++chn)
+        for (int tap = 0; tap < kk; ++tap)
+            for (int n = 0; n < O; ++n)
+                for (int k = 0; k < CONV_KC; ++k) {
+                    const int c = chn * CONV_KC + k;
+                    if (c >= C) continue;
+                    out[(((size_t)chn * kk + tap) * O + n) * 16 + k] = (_Float16)(t.data[((size_t)n * I + lo + c) * kk + tap] * 256.0f);
+                }
+    std::vector<float> raw((out.size() + 1) / 2);
+    memcpy(raw.data(), out.data(), out.size() * sizeof(_Float16));
     return upload(e, key, raw);
 }
 
@@ -443,9 +472,43 @@ static ConvParams with_coef(Builder& bd, ConvParams p, std::vector<Op>& ops) {
     return p;
 }
 
+// LDS-DMA path (conv_dma.hip): if the launch qualifies, the operands of its K-segments are pre-transformed by one OP_PREP in front of it
+// (after the OP_GN_COEF that finalises its GroupNorm coefficients / operand scales).  The a16 buffers are launch-local temporaries.
+static bool attach_dma(Builder& bd, ConvParams& p, int stride, int up, std::vector<Op>& ops) {
+    pf_engine* e = bd.e;
+    if (e->precision == 0) return false;
+    const int terms = e->precision == 2 ? 1 : 3;
+    if (terms == 1)
+        for (int i = 0; i < p.nseg; ++i) {
+            auto it = e->w16_src.find(p.seg[i].w16);
+            if (p.seg[i].w_mode != 0 || it == e->w16_src.end()) return false;
+            if ((it->second.hi - it->second.lo) % 64 != 0) return false;
+            p.seg[i].w16h = packed_conv16h(e, it->second.name, it->second.lo, it->second.hi);
+        }
+    if (!conv_dma_supported(p, stride, up, terms)) return false;
+    Op op{}; op.kind = OP_PREP;
+    PrepParams& q = op.pp;
+    q.nseg = p.nseg; q.B = p.B; q.Hs = p.Hs; q.Ws = p.Ws; q.terms = terms;
+    q.coef = p.coef; q.coef_stride = p.coef_stride; q.scale = p.scale;
+    std::vector<float*> tmp;
+    for (int i = 0; i < p.nseg; ++i) {
+        ConvSeg& sg = p.seg[i];
+        float* a = bd.acquire(conv_dma_a16_bytes(p.B, sg.C, p.Hs, p.Ws, terms) / sizeof(float));
+        if (!a) return false;
+        tmp.push_back(a);
+        sg.a16 = a;
+        q.src[i] = sg.src; q.dst[i] = a; q.C[i] = sg.C; q.cstride[i] = sg.cstride; q.coff[i] = sg.coff; q.xform[i] = sg.xform; q.gn_off[i] = sg.gn_off;
+    }
+    ops.push_back(op);
+    for (float* a : tmp) bd.recycle(a);      // stream order: the next launch that may get these bytes starts after this conv has finished
+    return true;
+}
+
 static void push_conv(Builder& bd, const ConvParams& p0, int stride = 1, int up = 0) {
-    const ConvParams p = with_coef(bd, p0, bd.plan->ops);
-    Op op{}; op.kind = OP_CONV; op.cp = p; op.stride = stride; op.up = up; op.flops = conv_flops(p);
+    ConvParams p = with_coef(bd, p0, bd.plan->ops);
+    Op op{}; op.kind = OP_CONV;
+    op.dma = attach_dma(bd, p, stride, up, bd.plan->ops) ? 1 : 0;
+    op.cp = p; op.stride = stride; op.up = up; op.flops = conv_flops(p);
     bd.plan->gemm_flops += op.flops;
     bd.plan->ops.push_back(op);
 }
@@ -1120,6 +1183,7 @@ static int run_backward(pf_engine* e, Plan* plan, const float* vec, float* g, hi
             case OP_BEGIN: { EdgeConvParams ep = op.ep; ep.in = vec; r = launch_begin_conv(ep, s); break; }
             case OP_END: { EdgeConvParams ep = op.ep; ep.out = g; r = launch_end_conv(ep, s); break; }
             case OP_CONV: r = dispatch_conv(e, op, s); break;
+            case OP_PREP: r = launch_prep_split(op.pp, s); break;
             case OP_GN_FWD_COEF:
                 r = launch_gn_fwd_coeffs((const double*)op.P[0], op.I[0], (const double*)op.P[1], op.I[1], op.I[2], op.I[3], 1e-6f, (float*)op.P[2],
                                          (float*)op.P[3], B, s); break;
@@ -1147,22 +1211,37 @@ static int run_backward(pf_engine* e, Plan* plan, const float* vec, float* g, hi
 }
 
 static hipError_t dispatch_conv(pf_engine* e, const Op& op, hipStream_t s) {
+    if (op.dma) return launch_conv_dma(op.cp, op.up, s, e->precision == 2 ? 1 : 3);
     if (e->precision != 0) {
         bool ok16 = true;
         for (int i = 0; i < op.cp.nseg; ++i) ok16 &= op.cp.seg[i].w_mode == 0 && op.cp.seg[i].w16 != nullptr;
+#ifdef PF_WITH_CONV_WS      // the wave-specialised persistent variant (conv_ws.hip): measured slower on every layer class, debug builds only
         if (ok16 && e->precision == 1 && conv_ws_supported(op.cp, op.stride, op.up)) return launch_conv_ws(op.cp, s);
+#endif
         if (ok16) return launch_conv16(op.cp, op.stride, op.up, s, e->precision == 2 ? 1 : 3);
     }
     return launch_conv(op.cp, op.stride, op.up, s);
 }
 
 static int run_plan(pf_engine* e, Plan* plan, const float* x, const float* t, float* v, hipStream_t s, float t_scale = 1.0f) {
+    bool prep_open = false;
     for (auto& op : plan->ops) {
         hipError_t r = hipSuccess;
         switch (op.kind) {
             case OP_MEMSET: r = zero_fill(op.ptr, op.bytes, s); break;
             case OP_TEMB: { TembParams tp = op.tp; tp.t = t; r = launch_temb(tp, s); break; }
             case OP_BEGIN: { EdgeConvParams ep = op.ep; ep.in = x; r = launch_begin_conv(ep, s); break; }
+            case OP_PREP:
+                // profiling: the prep pass is part of its conv's cost - the event pair of the following OP_CONV opens here
+                if (e->profile) {
+                    if (e->ev_used == e->ev_pool.size()) {
+                        hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); e->ev_pool.emplace_back(a, b);
+                    }
+                    hipEventRecord(e->ev_pool[e->ev_used].first, s);
+                    prep_open = true;
+                }
+                r = launch_prep_split(op.pp, s);
+                break;
             case OP_CONV:
                 if (e->profile) {
                     if (e->ev_used == e->ev_pool.size()) {
@@ -1171,7 +1250,8 @@ static int run_plan(pf_engine* e, Plan* plan, const float* x, const float* t, fl
                     auto& ev = e->ev_pool[e->ev_used++];
                     if (e->ev_ops.size() < e->ev_used) e->ev_ops.resize(e->ev_used);
                     e->ev_ops[e->ev_used - 1] = &op;
-                    hipEventRecord(ev.first, s);
+                    if (!prep_open) hipEventRecord(ev.first, s);
+                    prep_open = false;
                     if (getenv("PNPFLOW_HIP_TRACE") && e->ev_used <= pf_engine::TRACE_MAX) {
                         const size_t tb = pf_engine::TRACE_MAX * pf_engine::TRACE_SLOTS * 64;
                         if (!e->trace_buf) { hipMalloc(&e->trace_buf, tb); hipMemsetAsync(e->trace_buf, 0, tb, s); }

@@ -21,6 +21,8 @@ struct ConvSeg {
                           // 1: generic strided operand: element (n,k) at b*w_bs + n*w_ns + k*w_ks
     int64_t w_bs, w_cs, w_ts, w_ns, w_ks;
     const void* w16;      // optional split-fp16 repack [chunk][tap][Cout][16 hi | 16 lo] (x256), see conv_mfma16.hip
+    const void* w16h;     // optional hi-only repack [slice16][tap][Cout][16 hi] (x256) of the single-term mode's LDS-DMA kernel (conv_dma.hip)
+    const void* a16;      // conv_dma.hip only: the pre-transformed fp16 operand of this segment (prep_split_kernel), or nullptr
 };
 
 struct ConvParams {
@@ -111,6 +113,20 @@ struct GnCoefParams {
     int id;                          // index of the consuming conv in the plan (diagnostics)
 };
 hipError_t launch_gn_coef(const GnCoefParams& p, int B, hipStream_t s);
+
+// conv_dma.hip: prep pass (GroupNorm-apply + SiLU + operand scale + fp16 hi/lo split into the padded record layout) and the conv whose
+// A operand arrives by LDS-DMA from it
+struct PrepParams {
+    const float* src[3]; void* dst[3];
+    int C[3], cstride[3], coff[3], xform[3], gn_off[3];
+    int nseg, B, Hs, Ws, terms;
+    const float* coef; int coef_stride;      // ConvParams::coef of the consuming launch (gn_coef_kernel ran before)
+    const float* scale;                      // ConvParams::scale, or nullptr
+};
+hipError_t launch_prep_split(const PrepParams& p, hipStream_t s);
+bool conv_dma_supported(const ConvParams& p, int stride, int up, int terms);
+hipError_t launch_conv_dma(const ConvParams& p, int up, hipStream_t s, int terms);
+size_t conv_dma_a16_bytes(int B, int C, int Hs, int Ws, int terms);
 
 hipError_t launch_conv(const ConvParams& p, int stride, int up, hipStream_t s);
 hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t s, int terms = 3);   // split-fp16 MFMA variant (terms 3) / single fp16 MFMA (terms 1)

@@ -1,13 +1,19 @@
 """Benchmark of the PnP-Flow restoration hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2|c3|c4|tiny]
+    python bench.py --gpus N --steps K --warmup W [--workload c2_256|c2|c3|c4|c5|tiny]
 
 A "step" = one full PnP-Flow restoration (steps_pnp=100 outer iterations x num_samples=5
 U-Net evaluations + data-fidelity / interpolation / averaging kernels) of ONE batch of
-synthetic degraded images that already resides in HBM.  Default workload = BASELINE.json
-configs[1]: CelebA-shaped 128x128 box inpainting, pnp_flow, batch 32 per GPU.  Each rank
-restores its own batch (independent units, weak scaling); the only collective is the final
-all_gather of per-image PSNR.  Rank 0 prints ONE JSON line.
+synthetic degraded images that already resides in HBM.  Default workload = the configuration
+BASELINE.json's `metric` is quoted on: CelebA-shaped 256x256 box inpainting (half-size 40,
+sigma 0.05, alpha 0.5 - the reference's main.py:132-136 at 256^2), pnp_flow, batch 32 per GPU,
+100 x 5; BASELINE configs[1] (the 128x128 case) and the other configs are timed beside it in
+`configs`.  Each rank restores its own batch (independent units, weak scaling); the only
+collective is the final all_gather of per-image PSNR.  Rank 0 prints ONE JSON line.
+
+`--gpus N` IS the job size: with N > 1 and no torchrun environment the script re-executes itself
+under `python -m torch.distributed.run --nproc-per-node N` (one process per GPU, backend "nccl" =
+RCCL); launched under torchrun (as the driver does) it requires WORLD_SIZE == N and aborts otherwise.
 """
 import argparse
 import json
@@ -23,6 +29,8 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: (dim, batch per GPU, problem, alpha, steps_pnp, num_samples, net config, GFLOP per image per forward)
+    "c2_256": dict(dim=256, B=32, problem="inpainting", alpha=0.5, steps=100, ns=5, nres=6,
+                   label="CelebA-shaped 256x256 box-inpainting (half-size 40, sigma 0.05) pnp_flow B=32/GPU 100x5 (the configuration BASELINE.json's metric is quoted on; main.py:132-136 at 256^2)"),
     "c2": dict(dim=128, B=32, problem="inpainting", alpha=0.5, steps=100, ns=5, nres=6, label="CelebA-128 box-inpainting pnp_flow B=32/GPU 100x5 (BASELINE configs[1])"),
     "c3": dict(dim=128, B=64, problem="gaussian_deblurring_FFT", alpha=0.01, steps=100, ns=5, nres=6, label="CelebA-128 Gaussian deblurring pnp_flow B=64/GPU 100x5 (BASELINE configs[2])"),
     "c4": dict(dim=256, B=16, problem="superresolution", alpha=0.3, steps=100, ns=5, nres=6, label="AFHQ-256 superresolution x4 pnp_flow B=16/GPU 100x5 (BASELINE configs[3])"),
@@ -136,13 +144,17 @@ def cpu_baseline(wl, budget_s=20.0):
 
 FWD_FLOPS = {128: 49.78e9, 256: 189.44e9}      # algorithmic FLOP per image per U-Net forward
 
-# HBM bytes per conv-GEMM launch measured with rocprofv3 --pmc (FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled as
-# MI355X_MICROARCH.md prescribes for gfx950): {workload: (bytes per launch, committed summary it comes from)}
-TRAFFIC = {
-    "c2": (419.3e6, "profiles/r02_pmc_fwd_c2_xcd_{FETCH,WRITE}_SIZE.md (142 conv launches per forward of 160 images; 473.5 MB before the XCD-aware workgroup mapping)"),
-    "c3": (836.2e6, "profiles/r02_pmc_fwd_c3_xcd_{FETCH,WRITE}_SIZE.md (142 conv launches per forward of 320 images; 984.4 MB before)"),
-    "c4": (954.0e6, "profiles/r02_pmc_fwd_c4_xcd_{FETCH,WRITE}_SIZE.md (116 conv launches per forward of 80 images at 256^2; 1082.9 MB before)"),
-}
+def measured_traffic(workload):
+    """HBM bytes per conv-family launch of `workload`, measured with rocprofv3 --pmc in separate FETCH_SIZE / WRITE_SIZE passes
+    (FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950) by tools/pmc_traffic.sh, which writes profiles/traffic.json:
+    {workload: {"bytes_per_launch": ..., "launches": ..., "source": ..., "commit": ...}}.  The bench line carries what that
+    committed file holds (null when the workload has no entry) - never a constant of this script."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            rec = json.load(fh).get(workload)
+        return (float(rec["bytes_per_launch"]), rec.get("source")) if rec else (None, None)
+    except Exception:           # noqa: BLE001
+        return None, None
 
 
 class Runner:
@@ -227,7 +239,7 @@ def conv_roofline(r, precision, workload):
     launches, ms, flops = model.profile_read()
     model.profile(False)
     ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0      # ALGORITHMIC (fp32-equivalent) TFLOP/s of the conv-GEMM launches
-    traffic, src = TRAFFIC.get(workload, (None, None)) if (precision == 1 and rep == 5) else (None, None)
+    traffic, src = measured_traffic(workload) if (precision == 1 and rep == 5) else (None, None)
     if precision == 0:
         peak = 157.3   # TFLOP/s, fp32 MFMA dense peak (MI355X_MICROARCH.md)
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=None,
@@ -235,12 +247,12 @@ def conv_roofline(r, precision, workload):
     elif precision == 2:
         peak = 2500.0  # TFLOP/s, f16 MFMA dense peak; one f16 MFMA product per algorithmic product
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=None,
-                    kernel="conv_mfma16_kernel, TERMS = 1 (one f16 32x32x16 MFMA per product: fp16 operands, f32 accumulate)")
+                    kernel="conv_dma_kernel / conv_mfma16_kernel, TERMS = 1 (one f16 32x32x16 MFMA per product: fp16 operands, f32 accumulate, hi-only operand layouts)")
     else:
         peak = 2500.0  # TFLOP/s, f16 MFMA dense peak; every algorithmic product is executed as 3 f16 MFMA products
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=traffic,
                     traffic_source=src,
-                    kernel="conv_mfma16_kernel (f16 32x32x16 MFMA x3 split, implicit GEMM; every 3x3/1x1 conv of the U-Net; the fused attention core is a separate launch and not in this family)",
+                    kernel="conv family: conv_dma_kernel (LDS-DMA A operand from the prep_split pass, 128/256-channel levels; its prep pass is inside the timed launches) + conv_mfma16_kernel (register-staged, 32/64-channel levels) - f16 32x32x16 MFMA x3 split implicit GEMM; every 3x3/1x1 conv of the U-Net; the fused attention core is a separate launch and not in this family",
                     mfma_tflops_executed=round(3 * ach, 2), frac_executed=round(3 * ach / peak, 4))
     roof.update(launches=int(launches // n_fw), avg_launch_us=round(ms * 1e3 / max(1, launches), 2),
                 algorithmic_gflop_per_launch=round(flops / max(1, launches) / 1e9, 4), unet_batch=r.wl["B"] * rep)
@@ -332,8 +344,9 @@ def cpu_baseline_ot_ode(wl, budget_s=15.0):
 
 def ncsnpp_forward_block(dev, B=32, reps=3):
     """Velocity evaluations of the NCSN++ ("rectified") net at the reference's 256^2 config, synthetic weights.
-    Forward only: the reference's PnP-Flow schedule starts at t = 0 where this net's log-sigma conditioning is singular, and its
-    OT-ODE use needs the VJP, which is not built - so the measured unit is model(x, t * 999) itself."""
+    The measured unit is the velocity evaluation model(x, t * 999) itself: the reference's PnP-Flow schedule starts at t = 0 where
+    this net's log-sigma conditioning is singular (its own output is NaN from the first iteration on); OT_ODE (start_time > 0)
+    is the solver that runs with it, on the forward + the hand-written VJP (tests/test_gpu_ncsnpp.py)."""
     from pnpflow_amd.image_generation.configs.rectified_flow.afhq_cat_pytorch_rf_gaussian import get_config
     from pnpflow_amd.image_generation.models.ncsnpp import NCSNpp
     from tools.synthetic_weights import synthetic_state_dict
@@ -355,27 +368,77 @@ def ncsnpp_forward_block(dev, B=32, reps=3):
     return rec
 
 
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def resolve_job(gpus):
+    """Makes `--gpus N` the job size.  No torchrun environment and N > 1: re-execute under torch.distributed.run with N ranks on
+    127.0.0.1 (never returns).  Torchrun environment present: WORLD_SIZE must equal N."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None:
+        if gpus > 1:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+                   "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+            sys.stdout.flush(); sys.stderr.flush()
+            os.execv(sys.executable, cmd)
+        return 0, 1
+    world = int(env_world)
+    if world != gpus:
+        sys.exit(f"bench.py: --gpus {gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a mislabelled line "
+                 f"(launch with --nproc-per-node {gpus}, or pass --gpus {world})")
+    return int(os.environ.get("RANK", "0")), world
+
+
+def dry_run(a, rank, world, backend):
+    """PNPFLOW_BENCH_DRY=1: the launch / rendezvous / reduction path of the bench without any GPU work (CPU containers: the
+    `--gpus N` contract is testable where there is no device).  Prints the same line shape with "dry_run": true."""
+    import torch.distributed as dist
+    dt = 0.001 * (rank + 1)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if backend != "nccl" or not torch.cuda.is_available() else "nccl", rank=rank, world_size=world)
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+        ranks = dist.get_world_size()
+    else:
+        ranks = 1
+    if rank == 0:
+        wl = WORKLOADS[a.workload]
+        print(json.dumps({"metric": "restored images/sec", "value": 0.0, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dry_run": True,
+                          "data": "none (dry run)", "ranks_in_job": ranks, "config": {"workload": wl["label"], "global_batch": world * wl["B"]}}), flush=True)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default="c2_256", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary BASELINE configs and the pointwise block (N=1 default runs include them)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="override the workload's batch per GPU (tests)")
     ap.add_argument("--precision", type=int, default=1, choices=[0, 1, 2],
-                    help="1 (default): fp32-equivalent split-fp16 MFMA (3 x f16 MFMA per product); 0: exact fp32 MFMA")
+                    help="1 (default): fp32-equivalent split-fp16 MFMA (3 x f16 MFMA per product); 0: exact fp32 MFMA; 2: one f16 MFMA per product")
     a = ap.parse_args()
+    if a.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    rank, world = resolve_job(a.gpus)
     if a.batch > 0:
         WORKLOADS[a.workload] = dict(WORKLOADS[a.workload], B=a.batch)
     wl = WORKLOADS[a.workload]
 
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     # one process per GPU over RCCL ("nccl" on ROCm).  Functional tests on a 1-GPU box run the SAME rank logic with every rank
     # on device PNPFLOW_FORCE_DEVICE and the collectives on gloo (PNPFLOW_DIST_BACKEND=gloo; tensors staged through the host)
     backend = os.environ.get("PNPFLOW_DIST_BACKEND", "nccl")
+    if os.environ.get("PNPFLOW_BENCH_DRY") == "1":
+        return dry_run(a, rank, world, backend)
     local = int(os.environ.get("PNPFLOW_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -386,6 +449,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        if dist.get_world_size() != a.gpus:
+            sys.exit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {a.gpus}")
     comm = (lambda t: t) if backend == "nccl" else (lambda t: t.cpu())
 
     import pnpflow_amd.degradations as D
@@ -429,6 +494,8 @@ def main():
         out = {
             "metric": "restored images/sec", "value": round(total_images / dt, 4), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
+            "collective_backend": (("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else None),
+            "ranks_in_job": (dist.get_world_size() if world > 1 else 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {0: "f32", 1: "f32-equivalent (f16 hi+lo split operands, 3 x f16 MFMA per product, f32 accumulate)",
                       2: "f16 operands (power-of-two scaled), f32 accumulate - TF32-class, not fp32-equivalent"}[a.precision],
@@ -449,10 +516,12 @@ def main():
                 out["cpu_baseline"] = cpu_baseline_ot_ode(wl) if r.is_ode else cpu_baseline(wl)
             except Exception as exc:          # noqa: BLE001   (the reported baseline must not take the measured line with it)
                 out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
-        if world == 1 and not a.no_extra and a.workload == "c2":
-            # the other BASELINE configs under the same clock (one full restoration each after a short warm-up that builds the
-            # plans / graph), and the HBM-side numbers of the pointwise prox kernels
+        if world == 1 and not a.no_extra and a.workload in ("c2_256", "c2"):
+            # the other BASELINE configs under the same clock (EXTRA_STEPS full restorations each after a short warm-up that
+            # builds the plans / graph), the headline workload in precision mode 2, and the HBM-side numbers of the pointwise
+            # prox kernels
             extra = {}
+            EXTRA_STEPS = 3
 
             def guarded(key, fn):
                 # a failure of a secondary measurement must not take the headline line with it: it is recorded in place
@@ -465,16 +534,21 @@ def main():
                     except Exception:          # noqa: BLE001
                         pass
 
-            def run_config(name):
-                rr = Runner(name, 0, 1, dev, a.precision, not a.no_graph, models)
+            def timed_steps(rr, n):
                 rr.step(0, steps=12 if rr.is_ode else 2)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                xx = rr.step(1)
+                xx = None
+                for k in range(n):
+                    xx = rr.step(1 + k)
                 torch.cuda.synchronize()
-                d1 = time.perf_counter() - t1
+                return (time.perf_counter() - t1) / n, xx
+
+            def run_config(name):
+                rr = Runner(name, 0, 1, dev, a.precision, not a.no_graph, models)
+                d1, xx = timed_steps(rr, EXTRA_STEPS)
                 w2 = rr.wl
-                rec = {"workload": w2["label"], "images_per_s": round(w2["B"] / d1, 4), "ms_per_step": round(d1 * 1e3, 1), "steps": 1,
+                rec = {"workload": w2["label"], "images_per_s": round(w2["B"] / d1, 4), "ms_per_step": round(d1 * 1e3, 1), "steps": EXTRA_STEPS,
                        "unet_batch": rr.unet_batch(), "psnr_db": round(float(psnr_per_image(xx, rr.clean).mean()), 4),
                        "unet_tflops_end_to_end": round(w2["B"] * rr.flops_per_image() / d1 / 1e12, 2)}
                 if not rr.is_ode:
@@ -487,21 +561,21 @@ def main():
                 # the headline workload in precision mode 2 (one fp16 MFMA per product: NOT fp32-equivalent, ~7e-4 relative on the U-Net
                 # output; within the BASELINE tolerance of +-0.05 dB PSNR, tests/test_gpu_parity.py::test_fp16_mode_*).  Reported
                 # beside the headline, never as `value`.
-                rr = Runner("c2", 0, 1, dev, 2, not a.no_graph, models)
+                rr = Runner(a.workload, 0, 1, dev, 2, not a.no_graph, models)
                 try:
-                    rr.step(0, steps=2); torch.cuda.synchronize()
-                    t1 = time.perf_counter(); xx = rr.step(1); torch.cuda.synchronize(); d1 = time.perf_counter() - t1
+                    d1, xx = timed_steps(rr, EXTRA_STEPS)
                     return {"workload": rr.wl["label"] + ", precision mode 2", "dtype": "f16 operands, f32 accumulate (TF32-class)",
-                            "images_per_s": round(rr.wl["B"] / d1, 4), "ms_per_step": round(d1 * 1e3, 1), "steps": 1,
+                            "images_per_s": round(rr.wl["B"] / d1, 4), "ms_per_step": round(d1 * 1e3, 1), "steps": EXTRA_STEPS,
                             "psnr_db": round(float(psnr_per_image(xx, rr.clean).mean()), 4), "psnr_db_headline_mode": out["psnr_db"],
-                            "roofline": conv_roofline(rr, 2, "c2")}
+                            "roofline": conv_roofline(rr, 2, a.workload)}
                 finally:
                     rr.model.set_precision(1)
 
-            for name in ("c3", "c4", "c5"):
-                guarded(name, lambda name=name: run_config(name))
+            for name in ("c2", "c3", "c4", "c5"):
+                if name != a.workload:
+                    guarded(name, lambda name=name: run_config(name))
             if a.precision == 1:
-                guarded("c2_fp16_mode", run_mode2)
+                guarded("headline_fp16_mode", run_mode2)
             guarded("n4_ncsnpp_forward", lambda: ncsnpp_forward_block(dev))
             out["configs"] = extra
             try:

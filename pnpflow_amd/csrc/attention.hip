@@ -379,13 +379,9 @@ hipError_t launch_attn_long_cfg(const AttnParams& p, hipStream_t s) {
     constexpr int C = 128 * TC;
     constexpr int AROW = (C > 256 ? C : 256) + 4;
     const size_t lds = (size_t)(32 * AROW + 256 * 36 + 32) * 4;
-    static bool attr_set = false;
+    static unsigned long long attr_set = 0ull;
     auto kern = attn_fused_long_kernel<TC>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    { hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(kern), attr_set, 160 * 1024); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(kern, dim3((p.T / 32) * ((p.B + 7) / 8) * 8), dim3(256), lds, s, p);
     return hipGetLastError();
 }
@@ -396,13 +392,9 @@ hipError_t launch_attn_cfg(const AttnParams& p, hipStream_t s) {
     constexpr int AROW = (C > T ? C : T) + 4;
     constexpr int KBUF = T * 36, SBUF = 32 * (T + 4);
     const size_t lds = (size_t)(32 * AROW + (KBUF > SBUF ? KBUF : SBUF)) * 4;
-    static bool attr_set = false;
+    static unsigned long long attr_set = 0ull;
     auto kern = attn_fused_kernel<TK, TC>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    { hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(kern), attr_set, 160 * 1024); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(kern, dim3((T / 32) * ((p.B + 7) / 8) * 8), dim3(256), lds, s, p);
     return hipGetLastError();
 }

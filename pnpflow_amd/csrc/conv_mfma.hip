@@ -315,13 +315,9 @@ static hipError_t launch_cfg(const ConvParams& p, hipStream_t stream) {
     constexpr int BN = WN * NT * 32;
     constexpr int EPI = 4 * 32 * 36 + WM * BN * 2;
     const size_t lds = (size_t)((PP * KCP > EPI ? PP * KCP : EPI) + 2 * ((p.gn_C + 3) & ~3)) * sizeof(float);
-    static bool attr_set = false;
+    static unsigned long long attr_set = 0ull;
     auto kern = conv_mfma_kernel<MT, NT, WM, WN, S, UP, BM, KC>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    { hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(kern), attr_set, 160 * 1024); if (e != hipSuccess) return e; }
     const int tiles = p.B * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
     dim3 grid(tiles, (p.Cout + BN - 1) / BN);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);

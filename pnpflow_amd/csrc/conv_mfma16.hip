@@ -518,25 +518,17 @@ static hipError_t launch_cfg16(const ConvParams& p, hipStream_t stream) {
     if (xcd_env && ((long)grid.x * grid.y) % 8 == 0) { pp.xcd_map = 1; grid = dim3(grid.x * grid.y, 1); }
     if constexpr (S == 1 && UP == 0) {
         if (p.gnb_x != nullptr) {        // adjoint conv with the fused GroupNorm-backward first stage
-            static bool attr_set_g = false;
+            static unsigned long long attr_set_g = 0ull;
             auto kg = conv_mfma16_kernel<MT, NT, WM, WN, S, UP, KC, true, TERMS>;
-            if (!attr_set_g) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) return e;
-                attr_set_g = true;
-            }
+            { hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(kg), attr_set_g, 160 * 1024); if (e != hipSuccess) return e; }
             hipLaunchKernelGGL(kg, grid, dim3(256), lds, stream, pp);
             return hipGetLastError();
         }
     }
     if (p.gnb_x != nullptr) return hipErrorInvalidValue;
-    static bool attr_set = false;
+    static unsigned long long attr_set = 0ull;
     auto kern = conv_mfma16_kernel<MT, NT, WM, WN, S, UP, KC, false, TERMS>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    { hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(kern), attr_set, 160 * 1024); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, pp);
     return hipGetLastError();
 }

@@ -406,13 +406,9 @@ template <int MT, int NT, int WM, int WN, int KC>
 static hipError_t launch_ws_cfg(const ConvParams& p, hipStream_t stream) {
     constexpr int ROW = KC + 4, TH = 2 * MT * WM, PP = (TH + 2) * 18, BN = WN * NT * 32;
     const size_t lds = ((size_t)2 * PP * ROW + 4 * 32 * 36 + 2 * WM * BN * 2) * 4;
-    static bool attr_set = false;
+    static unsigned long long attr_set = 0ull;
     auto kern = conv_ws_kernel<MT, NT, WM, WN, KC>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    { hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(kern), attr_set, 160 * 1024); if (e != hipSuccess) return e; }
     const int PT = p.B * ((p.H + TH - 1) / TH) * ((p.W + 15) / 16), NB = (p.Cout + BN - 1) / BN;
     static const int cus = [] { hipDeviceProp_t pr; int d = 0; return (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) ? pr.multiProcessorCount : 256; }();
     const long tiles = (long)PT * NB;

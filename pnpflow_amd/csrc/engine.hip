@@ -161,7 +161,7 @@ struct pf_engine {
     struct OdeBufs { int B = 0; size_t n = 0, ny = 0; int steps = 0; bool blur = false;
                      float *x = nullptr, *vt = nullptr, *vec = nullptr, *g = nullptr, *y = nullptr, *scratch = nullptr;
                      float *tab = nullptr /* [4][steps]: t, 1-t, r_t^2, coef */, *cur = nullptr /* [4][B] */; int* iter = nullptr; int64_t bytes = 0; } ob;
-    struct OdeKey { const void* plan; int kind, half, sf, ntaps; const void* mask; const void* taps; int B; float sigma2, delta; };
+    struct OdeKey { const void* plan; int kind, half, sf, ntaps; const void* mask; const void* taps; int B; float sigma2, delta; int pad_; };   // compared with memcmp: no implicit padding (static_assert below)
     OdeKey okey{}; hipGraph_t ograph = nullptr; hipGraphExec_t ogexec = nullptr;
     hipStream_t work_stream = nullptr;   // used when the caller passes the NULL stream and asks for graph replay
     // profiling
@@ -827,19 +827,22 @@ static int build_plan(pf_engine* e, int B, bool retain, Plan** out_plan) {
     if (retain) bd.keep = true;
     // op 0: zero the statistics slab (filled in below)
     { Op op{}; op.kind = OP_MEMSET; plan->ops.push_back(op); }
+    // a plan that fails to build gives its device memory back (at the BASELINE sizes a half-built plan strands GBs, and
+    // pf_engine_memory_bytes would keep counting them)
+    auto fail = [&](int rc) { for (void* q : plan->allocs) hipFree(q); e->bytes -= plan->bytes; plan->allocs.clear(); plan->bytes = 0; return rc; };
     if (e->arch == 1) {
         int rc = nx_walk(e, bd, plan.get());
-        if (rc != PF_OK) return rc;
+        if (rc != PF_OK) return fail(rc);
     } else {
         int rc = unet_walk(e, bd, plan.get());
-        if (rc != PF_OK) return rc;
+        if (rc != PF_OK) return fail(rc);
     }
-    if (retain) { int rc = e->arch == 1 ? nx_build_backward(e, plan.get(), bd) : build_backward(e, plan.get(), bd); if (rc != PF_OK) return rc; }
-    if (!bd.ok) return PF_ERR_HIP;
-    for (auto& kv : e->dev) if (kv.second == nullptr) { e->err = "weight upload failed: " + kv.first; return PF_ERR_HIP; }
+    if (retain) { int rc = e->arch == 1 ? nx_build_backward(e, plan.get(), bd) : build_backward(e, plan.get(), bd); if (rc != PF_OK) return fail(rc); }
+    if (!bd.ok) return fail(PF_ERR_HIP);
+    for (auto& kv : e->dev) if (kv.second == nullptr) { e->err = "weight upload failed: " + kv.first; return fail(PF_ERR_HIP); }
     // statistics slab
     void* slab = nullptr;
-    if (hipMalloc(&slab, std::max<size_t>(bd.stats_bytes, 256)) != hipSuccess) { e->err = "hipMalloc failed (stats)"; return PF_ERR_HIP; }
+    if (hipMalloc(&slab, std::max<size_t>(bd.stats_bytes, 256)) != hipSuccess) { e->err = "hipMalloc failed (stats)"; return fail(PF_ERR_HIP); }
     poison(slab, std::max<size_t>(bd.stats_bytes, 256));
     plan->allocs.push_back(slab); plan->bytes += (int64_t)std::max<size_t>(bd.stats_bytes, 256); e->bytes += (int64_t)std::max<size_t>(bd.stats_bytes, 256);
     for (auto& op : plan->ops) fix_stats(op, (double*)slab);
@@ -1876,7 +1879,8 @@ int pf_ot_ode_restore(pf_engine* e, const pf_degradation* d, const pf_ot_ode_par
     HIPCHK(e, hipMemcpyAsync(b.x, x_inout, (size_t)B * n * 4, hipMemcpyDeviceToDevice, s));
     HIPCHK(e, hipStreamSynchronize(s));      // the host tables may go away after return
 
-    const pf_engine::OdeKey key{plan, dv.kind, dv.half, dv.sf, dv.ntaps, dv.mask, dv.taps, B, prm->sigma2, prm->delta};
+    static_assert(sizeof(pf_engine::OdeKey) == 3 * sizeof(void*) + 8 * sizeof(int), "OdeKey is compared with memcmp: it must have no padding bytes");
+    const pf_engine::OdeKey key{plan, dv.kind, dv.half, dv.sf, dv.ntaps, dv.mask, dv.taps, B, prm->sigma2, prm->delta, 0};
     if (e->ogexec && memcmp(&key, &e->okey, sizeof key) != 0) drop_ode_graph(e);
     const bool can_graph = prm->use_graph && !e->profile;
     for (int it = first; it < prm->steps; ++it) {

@@ -5,6 +5,19 @@
 
 namespace pf {
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: a process may hold engines on several devices
+// (pf_engine_create's device_index), so "set once" is tracked per device, not per process.  `done` is the call site's
+// own static mask; devices past 63 simply set the attribute on every launch.
+inline hipError_t set_max_dynamic_lds_once(const void* kernel, unsigned long long& done, int bytes = 160 * 1024) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && ((done >> dev) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev >= 0 && dev < 64) done |= 1ull << dev;
+    return e;
+}
+
 // One K-segment of the implicit GEMM: a source activation tensor (NHWC) plus the
 // slice of the weights that multiplies it.
 struct ConvSeg {

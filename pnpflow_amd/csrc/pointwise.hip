@@ -253,12 +253,8 @@ static hipError_t blur2(const DegView& d, const float* in, float* tmp, float* ou
     hipLaunchKernelGGL(blur_rows_kernel, dim3((rows + ty - 1) / ty), dim3(tx, ty), lds_r, s, in, tmp, d.taps, d.ntaps, rows, W, sign, 0,
                        (const float*)nullptr, (const float*)nullptr, C * H);
     const size_t lds_c = ((size_t)(H + 2 * r + 4) * BL_COLS + 128) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(blur_cols_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned long long attr_set = 0ull;
+    { hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(blur_cols_kernel), attr_set, 160 * 1024); if (e != hipSuccess) return e; }
     if (lds_c > 160 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(blur_cols_kernel, dim3((W + BL_COLS - 1) / BL_COLS, B * C), dim3(256), lds_c, s, (const float*)tmp, out, d.taps, d.ntaps,
                        H, W, sign, mode, aux, coef, C);

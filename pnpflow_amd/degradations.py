@@ -43,6 +43,8 @@ class Degradation:
         else:
             sf = getattr(self, "sf", 1) if self.kind in (_lib.PF_DEG_SUPERRESOLUTION, _lib.PF_DEG_SR_FILTERED) else 1
             out = torch.empty((B, Cc, Hf // sf, Wf // sf), dtype=torch.float32, device=x.device)
+        if B == 0:
+            return out          # an empty shard (global batch smaller than the number of ranks): nothing to launch
         n_scr = {_lib.PF_DEG_GAUSSIAN_BLUR: 1, _lib.PF_DEG_SR_FILTERED: 2}.get(self.kind, 0)
         scratch = torch.empty((n_scr, B, Cc, Hf, Wf), dtype=torch.float32, device=x.device) if n_scr else None
         fn = lib.pf_degradation_H_adj if adjoint else lib.pf_degradation_H

@@ -76,6 +76,8 @@ class OT_ODE(object):
         first = int(steps * args.start_time)
         B = noisy_img.shape[0]
         Hh = self.model.input_height
+        if B == 0:      # empty shard: join the logging collectives, restore nothing (see PNP_FLOW.restore_batch)
+            return parallel.empty_shard_result(noisy_img, (0, self.model.input_channels, Hh, Hh), steps, iter_cb, cb_iterations, first=first)
         dev = noisy_img.device
         d = degradation.descriptor(B, Hh, Hh, dev)
         y = noisy_img.contiguous().float()

@@ -104,6 +104,10 @@ class PNP_FLOW(object):
         steps, ns = int(args.steps_pnp), int(args.num_samples)
         B = noisy_img.shape[0]
         Cc, Hh = self.model.input_channels, self.model.input_height
+        if B == 0:
+            # empty shard (a batch with fewer images than ranks, e.g. the last partial batch): nothing to restore, but the
+            # logging callbacks hold the job's collectives (per-image metric all_gather) and must be joined in the same order
+            return parallel.empty_shard_result(noisy_img, (0, Cc, Hh, Hh), steps, iter_cb, cb_iterations)
         t_vals, coef = self._schedule(steps, lr, sigma_noise)
         if hasattr(self.model, "set_solver_time_scale"):
             # the engine's loop evaluates model(x, t * 999) for the rectified coupling (model_forward above).  NB the reference's

@@ -93,3 +93,15 @@ def gather_in_image_order(local: torch.Tensor, group=None) -> torch.Tensor:
 def mean_psnr(local_psnr: torch.Tensor, group=None) -> float:
     """Mean over the global batch, summed in global image order."""
     return float(gather_in_image_order(local_psnr, group).double().mean())
+
+
+def empty_shard_result(like: torch.Tensor, shape, steps: int, iter_cb=None, cb_iterations=None, first: int = 0) -> torch.Tensor:
+    """What a rank whose shard of the batch is empty returns from `restore_batch`: a 0-image tensor - after calling the
+    logging callback for the same iterations, in the same order, as the ranks that do restore images (the callbacks
+    all_gather per-image metrics: a rank that skipped them would leave the others blocked in the collective)."""
+    x = torch.empty(tuple(shape), dtype=torch.float32, device=like.device)
+    if iter_cb is not None:
+        its = range(first, int(steps)) if cb_iterations is None else sorted(i for i in set(cb_iterations) if first <= i < int(steps))
+        for it in its:
+            iter_cb(it, x)
+    return x

@@ -131,6 +131,8 @@ def psnr_per_image(rec: torch.Tensor, clean: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     rec = rec.contiguous().float(); clean = clean.to(rec.device).contiguous().float()
     out = torch.empty(rec.shape[0], dtype=torch.float32, device=rec.device)
+    if rec.shape[0] == 0:
+        return out              # an empty shard contributes a 0-length vector to the gather (parallel.gather_in_image_order)
     _lib.check(lib.pf_psnr(rec.data_ptr(), clean.data_ptr(), out.data_ptr(), rec.shape[0], rec[0].numel(), _lib.current_stream_ptr()),
                None, "pf_psnr")
     return out
@@ -144,6 +146,8 @@ def ssim_per_image(rec: torch.Tensor, clean: torch.Tensor) -> torch.Tensor:
     rec = rec.contiguous().float(); clean = clean.to(rec.device).contiguous().float()
     B, Cc, H, W = rec.shape
     out = torch.empty(B, dtype=torch.float64, device=rec.device)
+    if B == 0:
+        return out
     _lib.check(lib.pf_ssim(rec.data_ptr(), clean.data_ptr(), out.data_ptr(), B, Cc, H, W, _lib.current_stream_ptr()), None, "pf_ssim")
     return out
 

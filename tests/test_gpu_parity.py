@@ -1053,3 +1053,24 @@ def test_main_two_ranks_write_the_single_process_result_files(hip, tmp_path):
         a = [l.split() for l in outs[1][f].strip().splitlines()]; b = [l.split() for l in outs[2][f].strip().splitlines()]
         assert [x[0] for x in a] == [x[0] for x in b], f
         assert max(abs(float(x[1]) - float(y[1])) for x, y in zip(a, b)) < 1e-3, (f, a, b)
+
+
+def test_main_two_ranks_with_an_empty_shard(hip, tmp_path):
+    """batch_size_ip = 1 under two ranks: rank 1 owns an empty shard of every batch (the default config's batch of 4 under 8 ranks
+    is the same situation).  The job must finish and rank 0's files must equal the single-process run's."""
+    import os
+    outs = {}
+    for n in (1, 2):
+        root = str(tmp_path / f"n{n}") + "/"
+        os.makedirs(root)
+        opts = ["main.py", "--opts", "dataset", "celeba", "problem", "inpainting", "method", "pnp_flow", "synthetic", "True", "max_batch", "2",
+                "batch_size_ip", "1", "steps_pnp", "10", "num_samples", "2", "output_root", root]
+        _torchrun(opts, n)
+        base = os.path.join(root, "results_synthetic", "celeba", "ot", "inpainting", "pnp_flow", "test")
+        sub = [d for d, _, f in os.walk(base) if "psnr_rec_batch1.txt" in f]
+        assert len(sub) == 1, list(os.walk(base))
+        outs[n] = {f: open(os.path.join(sub[0], f)).read() for f in ("psnr_rec_batch0.txt", "psnr_rec_batch1.txt", "ssim_rec_batch0.txt")}
+    for f in outs[1]:
+        a = [l.split() for l in outs[1][f].strip().splitlines()]; b = [l.split() for l in outs[2][f].strip().splitlines()]
+        assert [x[0] for x in a] == [x[0] for x in b], f
+        assert max(abs(float(x[1]) - float(y[1])) for x, y in zip(a, b)) < 1e-3, (f, a, b)

@@ -329,3 +329,32 @@ def test_ncsnpp_create_rejects_unsupported_configurations_before_touching_a_devi
         assert lib.pf_ncsnpp_create(0, C.byref(c), C.byref(h)) == -1, bad
         assert b"unsupported NCSN++ configuration" in lib.pf_last_error(None)
     assert lib.pf_engine_set_solver_time_scale(None, 999.0) == -1
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py: `--gpus N` is the job size
+# ---------------------------------------------------------------------------------------------
+def _bench(args, env_extra):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PNPFLOW_BENCH_DRY="1", PNPFLOW_DIST_BACKEND="gloo", **env_extra)
+    return subprocess.run([sys.executable, "bench.py"] + args, cwd=root, env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` with NO torchrun wrapper must run a 2-rank job (it re-executes itself under
+    torch.distributed.run) and report n_gpus = 2.  PNPFLOW_BENCH_DRY=1: rendezvous + reduction only, no device work (this
+    container has no GPU); the rank / world logic is the same code the measured run goes through."""
+    import json
+    out = _bench(["--gpus", "2", "--workload", "tiny", "--steps", "1", "--warmup", "0"], {})
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["ranks_in_job"] == 2 and rec["config"]["global_batch"] == 8 and rec["dry_run"] is True
+    one = _bench(["--gpus", "1", "--workload", "tiny"], {})
+    assert one.returncode == 0 and json.loads(one.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    out = _bench(["--gpus", "8", "--workload", "tiny"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)

@@ -27,6 +27,17 @@
 #include <type_traits>
 #include "pf_common.h"
 
+// A/B switches (tools/build_variant.py; the defaults are the production configuration)
+#ifndef PF_DMA_APIPE
+#define PF_DMA_APIPE 0       // 1: A fragments software-pipelined one k16-step ahead (second register set)
+#endif
+#ifndef PF_DMA_CARRY
+#define PF_DMA_CARRY 0       // 1: the weight ring of the 9-tap loop runs across chunk boundaries (no cold start per chunk)
+#endif
+#ifndef PF_DMA_LB
+#define PF_DMA_LB 3          // waves per SIMD the register allocation is bounded for
+#endif
+
 namespace pf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -138,7 +149,7 @@ __device__ __forceinline__ void glds16(unsigned voff, const char* sbase, unsigne
 }
 
 template <int MT, int NT, int WM, int WN, int UP, int TERMS, bool GNB>
-__global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, PF_DMA_LB) void conv_dma_kernel(const ConvParams p) {
     static_assert(NT == 1, "one 32-channel N-tile per wave (the weight ring is sized for it)");
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int KC = TERMS == 3 ? 32 : 64;     // channels per chunk = one 128-byte record per pixel
@@ -226,16 +237,18 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvParams p) {
 
     // one k16-step: A fragments of every M-tile from the patch buffer, then the MFMAs of this wave's 32 output channels
     // (lbc = lb + byte offset of the current buffer: the XOR below touches bits 4-6 only, the buffer offset bits >= 10)
-    auto mma_step = [&](const unsigned (&lbc)[3], int ky, int kx, int j, const BFrag& f) __attribute__((always_inline)) {
-        f16x8 ah[MT], al[MT];
+    auto load_a = [&](const unsigned (&lbc)[3], int ky, int kx, int j, f16x8 (&ah)[MT], f16x8 (&al)[MT]) __attribute__((always_inline)) {
         const unsigned base_h = lbc[kx] ^ (unsigned)((j * 2) << 4);
         const unsigned base_l = lbc[kx] ^ (unsigned)((4 + j * 2) << 4);
+        // (in the order the MFMAs consume them: the low halves first)
+        if constexpr (TERMS == 3) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int coff = (mt * 2 + ky) * PW * 128;
-            ah[mt] = *reinterpret_cast<const f16x8*>(s_buf + base_h + coff);
-            if constexpr (TERMS == 3) al[mt] = *reinterpret_cast<const f16x8*>(s_buf + base_l + coff);
+            for (int mt = 0; mt < MT; ++mt) al[mt] = *reinterpret_cast<const f16x8*>(s_buf + base_l + (mt * 2 + ky) * PW * 128);
         }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ah[mt] = *reinterpret_cast<const f16x8*>(s_buf + base_h + (mt * 2 + ky) * PW * 128);
+    };
+    auto mma = [&](const f16x8 (&ah)[MT], const f16x8 (&al)[MT], const BFrag& f) __attribute__((always_inline)) {
         if constexpr (TERMS == 3) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], __builtin_bit_cast(f16x8, f.h), acc[mt], 0, 0, 0);
@@ -247,39 +260,79 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvParams p) {
     };
 
     // ---- main loop -----------------------------------------------------------------------------------------------------------------
-    // A requested weight fragment lives only inside ONE straight-line chunk body (request -> counted wait -> MFMAs): its loads are
-    // invisible to the compiler, so it must never cross a control-flow merge, where the register allocator may copy or spill it
-    // before the data has landed.  Per chunk:   request B(0), B(1)  ->  wait for this chunk's patch  ->  barrier  ->  request the
-    // next chunk's patch  ->  steps (step s requests B(s + 2)).  Queue (oldest first) and the wait of every step:
+    // A requested weight fragment's loads are invisible to the compiler, so between its request and its counted wait the registers
+    // must not be copied, spilled or renamed (tools/isa_audit_asm_loads.py replays the compiled ISA and checks exactly that).
+    // Per chunk:   [request B(0), B(1)]  ->  wait for this chunk's patch  ->  barrier  ->  request the next chunk's patch  ->  steps
+    // (step s requests B(s + 2)).  Queue (oldest first) and the wait of every step:
     //     [B0][B1][DMA x IPW] + [B2] at step 0:  B0 needs vmcnt(2 NB + IPW);  step 1 the same;  steps >= 2: vmcnt(2 NB) (B(s+1), B(s+2));
-    //     the last two steps request nothing: vmcnt(NB), vmcnt(0).
+    //     without the carry the last two steps request nothing: vmcnt(NB), vmcnt(0).
+    // CARRY (9-tap loop only): the last two steps request steps 0 / 1 of the NEXT chunk instead, into the registers the next
+    // iteration expects them in (18 / 36 steps are a multiple of the ring length 3), so a chunk does not start with a cold L2 round trip.
     // The last chunk requests its own patch again into the free buffer (never read), which keeps the counts static.
-    auto chunk_body = [&](auto taps_c, const char* wcur, int cur, int nsi, int nch) __attribute__((always_inline)) {
+    BFrag f0, f1, f2;
+    f0.h = u32x4{0u, 0u, 0u, 0u}; f0.l = f0.h; f1 = f0; f2 = f0;
+    auto chunk_body = [&](auto taps_c, auto carry_c, const char* wcur, const char* wnext, int ntaps, int cur, int nsi, int nch) __attribute__((always_inline)) {
         constexpr int TAPS = decltype(taps_c)::value;
+        constexpr bool CARRY = decltype(carry_c)::value;
         constexpr int NS = TAPS * KS;
-        static_assert(NS >= 2 && NS <= 36, "unrolled steps");
-        auto wstep = [&](int s2) -> const char* { return wcur + (size_t)((s2 % KS) * TAPS + s2 / KS) * wblk; };      // (tap, slice) = (s2 / KS, s2 % KS)
-        BFrag f0, f1, f2;
-        f2.h = u32x4{0u, 0u, 0u, 0u}; f2.l = f2.h;
-        bload<TERMS>(f0, b_voff, wstep(0));
-        bload<TERMS>(f1, b_voff, wstep(1));
+        static_assert(NS >= 2 && NS <= 36 && (!CARRY || NS % 3 == 0), "unrolled steps / ring phase");
+        // weight block of fragment step s2 of this chunk ((tap, slice) = (s2 / KS, s2 % KS)), or of step s2 - NS in {0, 1} of the next
+        auto wstep = [&](int s2) -> const char* {
+            if (s2 < NS) return wcur + (size_t)((s2 % KS) * TAPS + s2 / KS) * wblk;
+            return wnext + (size_t)((s2 - NS) * ntaps) * wblk;
+        };
+        if constexpr (!CARRY) {
+            bload<TERMS>(f0, b_voff, wstep(0));
+            bload<TERMS>(f1, b_voff, wstep(1));
+        }
         PF_WAITV(2 * NB);                                 // in-order return: everything older than B0 / B1 - this chunk's patch - has landed
         __builtin_amdgcn_s_barrier();                     // raw barrier (no vmcnt(0) drain); every wave has finished reading the other buffer
         dma(nsi, nch, cur ^ 1);
         unsigned lbc[3];
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) lbc[kx] = lb[kx] + (unsigned)(cur * BUF);
+#define PF_KY(S) (TAPS == 9 ? ((S) / KS) / 3 : 1)
+#define PF_KX(S) (TAPS == 9 ? ((S) / KS) % 3 : 1)
+#if PF_DMA_APIPE
+        f16x8 ahA[MT], alA[MT], ahB[MT], alB[MT];
+        load_a(lbc, PF_KY(0), PF_KX(0), 0, ahA, alA);
+#define PF_STEP(S, FC, FN, ACUR_H, ACUR_L, ANXT_H, ANXT_L)                                                                     \
+        if constexpr ((S) < NS) {                                                                                              \
+            constexpr bool REQ_ = CARRY || (S) + 2 < NS;                                                                       \
+            if constexpr (REQ_) bload<TERMS>(FN, b_voff, wstep((S) + 2));                                                      \
+            constexpr int W_ = REQ_ ? ((S) < 2 ? 2 * NB + IPW : 2 * NB) : ((S) + 1 < NS ? ((S) < 2 ? NB + IPW : NB) : ((S) < 2 ? IPW : 0)); \
+            bwait<TERMS, W_>(FC);                                                                                              \
+            if constexpr ((S) + 1 < NS) load_a(lbc, PF_KY((S) + 1), PF_KX((S) + 1), ((S) + 1) % KS, ANXT_H, ANXT_L);            \
+            if constexpr (PF_DMA_APIPE == 1) __builtin_amdgcn_sched_barrier(0);      /* reads of step S+1 issue before the MFMAs of step S */ \
+            mma(ACUR_H, ACUR_L, FC);                                                                                           \
+            if constexpr (PF_DMA_APIPE == 2 && (S) + 1 < NS) {                       /* ... or interleaved with them, one read behind each of the first MFMAs */ \
+                _Pragma("unroll") for (int q_ = 0; q_ < (TERMS == 3 ? 2 : 1) * MT; ++q_) {                                      \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }     \
+                __builtin_amdgcn_sched_group_barrier(0x008, (TERMS == 3 ? 3 : 1) * MT - (TERMS == 3 ? 2 : 1) * MT, 0);          \
+            }                                                                                                                  \
+        }
+#define PF_STEP6(S) PF_STEP((S), f0, f2, ahA, alA, ahB, alB) PF_STEP((S) + 1, f1, f0, ahB, alB, ahA, alA) PF_STEP((S) + 2, f2, f1, ahA, alA, ahB, alB) \
+                    PF_STEP((S) + 3, f0, f2, ahB, alB, ahA, alA) PF_STEP((S) + 4, f1, f0, ahA, alA, ahB, alB) PF_STEP((S) + 5, f2, f1, ahB, alB, ahA, alA)
+        PF_STEP6(0) PF_STEP6(6) PF_STEP6(12) PF_STEP6(18) PF_STEP6(24) PF_STEP6(30)
+#undef PF_STEP6
+#else
 #define PF_STEP(S, FC, FN)                                                                                                     \
         if constexpr ((S) < NS) {                                                                                              \
-            if constexpr ((S) + 2 < NS) bload<TERMS>(FN, b_voff, wstep((S) + 2));                                              \
-            constexpr int W_ = (S) + 2 < NS ? ((S) < 2 ? 2 * NB + IPW : 2 * NB) : ((S) + 1 < NS ? ((S) < 2 ? NB + IPW : NB) : ((S) < 2 ? IPW : 0)); \
+            constexpr bool REQ_ = CARRY || (S) + 2 < NS;                                                                       \
+            if constexpr (REQ_) bload<TERMS>(FN, b_voff, wstep((S) + 2));                                                      \
+            constexpr int W_ = REQ_ ? ((S) < 2 ? 2 * NB + IPW : 2 * NB) : ((S) + 1 < NS ? ((S) < 2 ? NB + IPW : NB) : ((S) < 2 ? IPW : 0)); \
             bwait<TERMS, W_>(FC);                                                                                              \
-            mma_step(lbc, TAPS == 9 ? ((S) / KS) / 3 : 1, TAPS == 9 ? ((S) / KS) % 3 : 1, (S) % KS, FC);                       \
+            f16x8 ah_[MT], al_[MT];                                                                                            \
+            load_a(lbc, PF_KY(S), PF_KX(S), (S) % KS, ah_, al_);                                                               \
+            mma(ah_, al_, FC);                                                                                                 \
         }
 #define PF_STEP3(S) PF_STEP((S), f0, f2) PF_STEP((S) + 1, f1, f0) PF_STEP((S) + 2, f2, f1)
         PF_STEP3(0) PF_STEP3(3) PF_STEP3(6) PF_STEP3(9) PF_STEP3(12) PF_STEP3(15) PF_STEP3(18) PF_STEP3(21) PF_STEP3(24) PF_STEP3(27) PF_STEP3(30) PF_STEP3(33)
 #undef PF_STEP3
+#endif
 #undef PF_STEP
+#undef PF_KY
+#undef PF_KX
     };
     auto rescale = [&](int rsi) __attribute__((always_inline)) {
         // the accumulator changes units: from segment rsi-1's operand scale to segment rsi's (both powers of two: exact)
@@ -295,24 +348,37 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvParams p) {
     dma(0, 0, 0);
     int si = 0, ch = 0, cur = 0;
     bool more = true;
+    constexpr bool CARRY9 = PF_DMA_CARRY != 0;
+    if (CARRY9 && p.seg[0].taps == 9) {
+        const char* w0 = wchunk(0, 0);
+        bload<TERMS>(f0, b_voff, w0);
+        bload<TERMS>(f1, b_voff, w0 + (size_t)9 * wblk);      // step 1 = (tap 0, slice 1)
+    }
     // 9-tap segments first (conv_dma_supported orders them so), then the 1-tap ones: two loops, one body each
     while (more && p.seg[si].taps == 9) {
         if (ch == 0 && si > 0) rescale(si);
         int nsi = si, nch = ch + 1;
         if (nch * KC >= p.seg[si].C) { nsi = si + 1; nch = 0; }
         more = nsi < p.nseg;
-        chunk_body(std::integral_constant<int, 9>{}, wchunk(si, ch), cur, more ? nsi : si, more ? nch : ch);
+        const int dsi = more ? nsi : si, dch = more ? nch : ch;
+        // the carried requests at the end of this chunk are for the next 9-tap chunk; past the last one they re-read this chunk's
+        // first two blocks (never used: the 1-tap loop below starts its own ring)
+        const bool next9 = more && p.seg[nsi].taps == 9;
+        chunk_body(std::integral_constant<int, 9>{}, std::integral_constant<bool, CARRY9>{}, wchunk(si, ch), next9 ? wchunk(nsi, nch) : wchunk(si, ch), 9, cur, dsi, dch);
         si = nsi; ch = nch; cur ^= 1;
     }
+    // the carried overrun requests of the last 9-tap chunk are still in flight in (f0, f1): nothing below may reuse those registers
+    // before they have landed (the compiler considers them dead - the ISA audit caught it handing one to the rescale factor)
+    if constexpr (CARRY9) PF_WAITV(0);
     while (more) {
         if (ch == 0 && si > 0) rescale(si);
         int nsi = si, nch = ch + 1;
         if (nch * KC >= p.seg[si].C) { nsi = si + 1; nch = 0; }
         more = nsi < p.nseg;
-        chunk_body(std::integral_constant<int, 1>{}, wchunk(si, ch), cur, more ? nsi : si, more ? nch : ch);
+        chunk_body(std::integral_constant<int, 1>{}, std::false_type{}, wchunk(si, ch), nullptr, 1, cur, more ? nsi : si, more ? nch : ch);
         si = nsi; ch = nch; cur ^= 1;
     }
-    PF_WAITV(0);                                          // the last chunk's overrun patch request must land before the scratch below reuses LDS
+    PF_WAITV(0);                                          // the last chunk's overrun requests must land before the scratch below reuses LDS
 
     // ---- epilogue (conv_mfma16.hip's) ----------------------------------------------------------------------------------------------
     __syncthreads();                                   // every wave is done reading the patch

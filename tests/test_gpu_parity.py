@@ -1074,3 +1074,153 @@ def test_main_two_ranks_with_an_empty_shard(hip, tmp_path):
         a = [l.split() for l in outs[1][f].strip().splitlines()]; b = [l.split() for l in outs[2][f].strip().splitlines()]
         assert [x[0] for x in a] == [x[0] for x in b], f
         assert max(abs(float(x[1]) - float(y[1])) for x, y in zip(a, b)) < 1e-3, (f, a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+# full-length recursions against the real reference
+# ---------------------------------------------------------------------------------------------
+def _pnp_solver(m, problem, steps, ns, alpha, precision, B, Cc, S):
+    from pnpflow_amd.methods.pnp_flow import PNP_FLOW
+    from pnpflow_amd.utils import CfgNode
+    m.set_precision(precision)
+    args = CfgNode(dict(method="pnp_flow", model="ot", problem=problem, noise_type="gaussian", num_samples=ns, steps_pnp=steps, lr_pnp=1.0,
+                        gamma_style="alpha_1_minus_t", alpha=alpha, max_batch=1, compute_time=False, compute_memory=False, save_results=False,
+                        batch=0))
+    solver = PNP_FLOW(m, torch.device("cuda"), args)
+    solver.noise = torch.stack([det_normal((B, Cc, S, S), 41, 1 + i) for i in range(steps * ns)]).cuda()
+    return solver, args
+
+
+def long_cases():
+    import pnpflow_amd.degradations as D
+    return [("tiny4_inpainting", "inpainting", lambda S: D.BoxInpainting(10), 0.05),
+            ("tiny4_superresolution", "superresolution", lambda S: D.Superresolution(2, S), 0.05),
+            ("tiny4_deblurring", "gaussian_deblurring_FFT", lambda S: D.GaussianDeblurring(1.0, 61, "fft", 3, S), 0.05)]
+
+
+@pytest.mark.parametrize("idx", range(3))
+@pytest.mark.parametrize("precision", [1, 2])
+def test_pnp_flow_100x5_matches_reference(hip, golden, idx, precision):
+    """The shipped recursion length - 100 outer iterations x 5 samples (pnp_flow.py:103-121) - against the real reference's iterates,
+    in the default fp32-equivalent mode AND in precision mode 2: final PSNR within the north_star's +-0.05 dB; the default mode
+    also follows the iterates themselves (1e-3 absolute at iteration 99, 500 sequential U-Net evaluations deep)."""
+    from pnpflow_amd.utils import psnr_per_image
+    tag, problem, mk, sigma = long_cases()[idx]
+    g = golden("pnp_long_" + tag)
+    m, cfg, sd = model_for("tiny4")
+    S, Cc, B = 64, 3, 2
+    steps, ns = int(g["steps"]), int(g["num_samples"])
+    assert (steps, ns) == (100, 5)
+    try:
+        solver, args = _pnp_solver(m, problem, steps, ns, float(g["alpha"]), precision, B, Cc, S)
+        args.sigma_noise = sigma
+        its = {}
+        x = solver.restore_batch(torch.from_numpy(g["noisy"]).cuda(), mk(S), sigma, lr=sigma ** 2 * 1.0,
+                                 iter_cb=lambda it, xx: its.__setitem__(it, xx.clone().cpu()), cb_iterations=[0, 10, 50, 90, 99])
+    finally:
+        m.set_precision(1)
+    clean = det_image((B, Cc, S, S), 31)
+    p_hip = psnr_per_image(x, clean.cuda()).cpu()
+    p_ref = O.psnr_per_image(torch.from_numpy(g["x_it99"]), clean)
+    assert float((p_hip - p_ref).abs().max()) <= 0.05, (tag, precision, p_hip, p_ref)
+    if precision == 1:
+        for it in (0, 10, 50, 90, 99):
+            np.testing.assert_allclose(its[it].numpy(), g[f"x_it{it}"], atol=1e-3, err_msg=f"{tag} iterate {it}")
+
+
+def test_c1_mnist_denoising_at_its_own_size(hip, golden):
+    """BASELINE configs[0]: MNIST-shaped denoising, B = 8, 50 x 5; iterates 0, 5, ..., 45, 49 of the real reference."""
+    import pnpflow_amd.degradations as D
+    from pnpflow_amd.utils import psnr_per_image
+    g = golden("pnp_long_mnist_c1")
+    m, cfg, sd = model_for("mnist")
+    B, Cc, S, sigma = 8, 1, 28, 0.2
+    solver, args = _pnp_solver(m, "denoising", 50, 5, 0.8, 1, B, Cc, S)
+    args.sigma_noise = sigma
+    its = {}
+    log = list(range(0, 50, 5)) + [49]
+    x = solver.restore_batch(torch.from_numpy(g["noisy"]).cuda(), D.Denoising(), sigma, lr=sigma ** 2 * 1.0,
+                             iter_cb=lambda it, xx: its.__setitem__(it, xx.clone().cpu()), cb_iterations=log)
+    for it in log:
+        np.testing.assert_allclose(its[it].numpy(), g[f"x_it{it}"], atol=5e-4, err_msg=f"iterate {it}")
+    clean = det_image((B, Cc, S, S), 31)
+    d = (psnr_per_image(x, clean.cuda()).cpu() - O.psnr_per_image(torch.from_numpy(g["x_it49"]), clean)).abs().max()
+    assert float(d) <= 0.05
+
+
+def _crops_close(t, g, prefix, atol, rtol_sum=2e-5):
+    t = t.cpu(); H = t.shape[2]
+    np.testing.assert_allclose(t[:, :, H // 2 - 16:H // 2 + 16, H // 2 - 16:H // 2 + 16].numpy(), g[prefix + "_crop"], atol=atol, err_msg=prefix)
+    np.testing.assert_allclose(t[:, :, :8, :8].numpy(), g[prefix + "_corner"], atol=atol, err_msg=prefix)
+    d = t.double()
+    np.testing.assert_allclose([float(d.abs().sum()), float((d * d).sum())], g[prefix + "_checksum"][1:], rtol=rtol_sum, err_msg=prefix)
+
+
+@pytest.mark.parametrize("tag", ["c2", "c3", "c4"])
+def test_first_outer_iterations_of_baseline_configs(hip, golden, tag):
+    """The first two outer iterations of BASELINE configs[1..3] on their OWN nets (34.5 M / 31.0 M parameters) and operator parameters
+    (BoxInpainting(20) at 128^2, Gaussian blur sigma 1 at 128^2, superresolution x4 at 256^2; 100 x 5 schedule) against the real
+    reference's iterates (crops + whole-tensor checksums): the solver loop, the operators and the big nets as ONE step of the reference."""
+    import pnpflow_amd.degradations as D
+    net, problem, mk = {"c2": ("celeba128", "inpainting", lambda S: D.BoxInpainting(20)),
+                        "c3": ("celeba128", "gaussian_deblurring_FFT", lambda S: D.GaussianDeblurring(1.0, 61, "fft", 3, S)),
+                        "c4": ("afhq256", "superresolution", lambda S: D.Superresolution(4, S))}[tag]
+    g = golden("pnp_iter_" + tag)
+    m, cfg, sd = model_for(net)
+    S, Cc, B, sigma = cfg["input_height"], 3, int(g["B"]), float(g["sigma"])
+    from pnpflow_amd.methods.pnp_flow import PNP_FLOW
+    from pnpflow_amd.utils import CfgNode
+    args = CfgNode(dict(method="pnp_flow", model="ot", problem=problem, noise_type="gaussian", num_samples=5, steps_pnp=100, lr_pnp=1.0,
+                        gamma_style="alpha_1_minus_t", alpha=float(g["alpha"]), max_batch=1, compute_time=False, compute_memory=False,
+                        save_results=False, batch=0, sigma_noise=sigma))
+    solver = PNP_FLOW(m, torch.device("cuda"), args)
+    # the reference drew 1 + 10 tensors before it was stopped; the engine is handed the same ones for iterations 0 and 1 and zeros after
+    nz = torch.zeros((100 * 5, B, Cc, S, S))
+    for i in range(10):
+        nz[i] = det_normal((B, Cc, S, S), 41, 1 + i)
+    solver.noise = nz.cuda()
+    degradation = mk(S)
+    clean = det_image((B, Cc, S, S), 31)
+    y = degradation.H(clean.cuda()) + sigma * det_normal(tuple(degradation.H(clean.cuda()).shape), 41, 0).cuda()
+    _crops_close(y, g, "noisy", 1e-5)
+    its = {}
+
+    class _Stop(Exception):
+        pass
+
+    def cb(it, xx):
+        its[it] = xx.clone().cpu()
+        if it >= 1:
+            raise _Stop()
+    try:
+        solver.restore_batch(y, degradation, sigma, lr=sigma ** 2 * 1.0, iter_cb=cb, cb_iterations=[0, 1])
+    except _Stop:
+        pass
+    torch.cuda.synchronize()
+    _crops_close(its[0], g, "x_it0", 1e-4)
+    _crops_close(its[1], g, "x_it1", 1e-4)
+
+
+@pytest.mark.parametrize("tag,problem,sigma", [("tiny4_random_inpainting", "random_inpainting", 0.01), ("tiny4_superresolution", "superresolution", 0.05)])
+def test_ot_ode_90_steps_match_reference(hip, golden, tag, problem, sigma):
+    """steps_ode = 100, start_time = 0.1: the 90 Euler steps the C5 configuration runs (ot_ode.py:63-147), against the real reference:
+    first iterate to 1e-3 relative, final PSNR within 0.05 dB."""
+    import pnpflow_amd.degradations as D
+    from pnpflow_amd.methods.ot_ode import OT_ODE
+    from pnpflow_amd.utils import CfgNode, psnr_per_image
+    g = golden("ot_ode_long_" + tag)
+    m, cfg, sd = model_for("tiny4")
+    S, Cc = 64, 3
+    args = CfgNode(dict(method="ot_ode", model="ot", problem=problem, steps_ode=100, start_time=0.1, gamma="constant", max_batch=1,
+                        compute_time=False, compute_memory=False, save_results=False, batch=0))
+    solver = OT_ODE(m, torch.device("cuda"), args)
+    degradation = D.RandomInpainting(0.7) if problem == "random_inpainting" else D.Superresolution(2, S)
+    y = torch.from_numpy(g["noisy"]).cuda()
+    solver.init_noise = det_normal(tuple(degradation.H_adj(y).shape), 61, 1).cuda()
+    its = {}
+    x = solver.restore_batch(y, degradation, sigma, iter_cb=lambda it, xx: its.__setitem__(it, xx.clone().cpu()), cb_iterations=[10, 50, 99])
+    ref = g["x_it10"]
+    np.testing.assert_allclose(its[10].numpy(), ref, atol=1e-3 * float(np.abs(ref).max()), err_msg="iterate 10")
+    clean = det_image((2, Cc, S, S), 31)
+    d = (psnr_per_image(x, clean.cuda()).cpu() - O.psnr_per_image(torch.from_numpy(g["x_it99"]), clean)).abs().max()
+    assert float(d) <= 0.05, d

@@ -286,6 +286,129 @@ def gen_ot_ode(models, degr, utils, only=None):
         print("ot_ode", tag, iterates[steps - 1].abs().mean().item())
 
 
+def _run_pnp(models, degr, utils, pnp, net, problem, mk, alpha, B, steps, num_samples, noise_seed=41, stop_after=None, capture_inputs=False):
+    """The real PNP_FLOW.solve_ip with torch.randn_like replaced by det_normal(noise_seed, call index).  Returns
+    (iterates {logging iteration: x}, inputs-of-iteration list when capture_inputs, noisy measurement, args)."""
+    m, cfg, sd = build_ref_unet(models, net)
+    c = CFGS[net]; S = c["input_height"]
+    degradation, sigma = mk(S)
+    clean = det_image((B, c["input_channels"], S, S), 31)
+    args = utils.CfgNode(dict(method="pnp_flow", model="ot", dataset="celeba", problem=problem, noise_type="gaussian", num_samples=num_samples,
+                              steps_pnp=steps, lr_pnp=1.0, gamma_style="alpha_1_minus_t", alpha=alpha, max_batch=1, compute_time=False,
+                              compute_memory=False, save_results=True, batch=0, save_path_ip="/tmp"))
+    iterates, inputs, seq = {}, [], {"n": 0}
+
+    class _Stop(Exception):
+        pass
+
+    def fake_randn_like(like, **kw):
+        i = seq["n"]; seq["n"] += 1
+        return det_normal(tuple(like.shape), noise_seed, i)   # call 0 = measurement noise, then (iteration, sample) order
+
+    def cap_psnr(clean_img, noisy_img, rec_img, a, H_adj, iter="final"):
+        iterates.setdefault(int(iter), rec_img.clone()); iterates["noisy"] = noisy_img.clone()
+    noop = lambda *a, **k: None
+    saved = (torch.randn_like, utils.compute_psnr, utils.compute_ssim, utils.compute_lpips, utils.save_images,
+             utils.compute_average_psnr, utils.compute_average_ssim, utils.compute_average_lpips)
+    torch.randn_like = fake_randn_like
+    utils.compute_psnr, utils.compute_ssim, utils.compute_lpips, utils.save_images = cap_psnr, noop, noop, noop
+    utils.compute_average_psnr = utils.compute_average_ssim = utils.compute_average_lpips = noop
+    try:
+        solver = pnp.PNP_FLOW(m, torch.device("cpu"), args)
+        if capture_inputs or stop_after is not None:
+            orig = solver.grad_datafit
+
+            def grad_hook(x, y, H, H_adj):       # called once at the top of every outer iteration with that iteration's input
+                inputs.append(x.clone())
+                if stop_after is not None and len(inputs) > stop_after:
+                    raise _Stop()
+                return orig(x, y, H, H_adj)
+            solver.grad_datafit = grad_hook
+        try:
+            solver.solve_ip([(clean, torch.zeros(B))], degradation, sigma)
+        except _Stop:
+            pass
+    finally:
+        (torch.randn_like, utils.compute_psnr, utils.compute_ssim, utils.compute_lpips, utils.save_images,
+         utils.compute_average_psnr, utils.compute_average_ssim, utils.compute_average_lpips) = saved
+    return iterates, inputs, clean, sigma, args, seq["n"]
+
+
+def gen_long(models, degr, utils, pnp):
+    """Full-length recursions of the real solvers:
+      pnp_long_tiny4_*      100 x 5 PnP-Flow on the 4-level test net, B = 2 (the shipped loop length: pnp_flow.py:103-121)
+      pnp_long_mnist_c1     BASELINE configs[0]: MNIST-shaped denoising, B = 8, 50 x 5, iterates 0, 5, ..., 45, 49
+      ot_ode_long_tiny4_*   90 Euler steps (steps_ode 100, start_time 0.1) of the real OT_ODE
+      pnp_iter_{c2,c3,c4}   the first TWO outer iterations of BASELINE configs[1..3] on their own nets (34.5 M / 31.0 M parameters) and
+                            operator parameters, B = 2, 100 x 5 schedule (crops + float64 checksums)"""
+    import pnpflow.methods.ot_ode as ot
+    cases = [("tiny4_inpainting", "tiny4", "inpainting", lambda S: (degr.BoxInpainting(10), 0.05), 0.5),
+             ("tiny4_superresolution", "tiny4", "superresolution", lambda S: (degr.Superresolution(2, S, device="cpu"), 0.05), 0.3),
+             ("tiny4_deblurring", "tiny4", "gaussian_deblurring_FFT", lambda S: (degr.GaussianDeblurring(1.0, 61, "fft", 3, S, "cpu"), 0.05), 0.01)]
+    for tag, net, problem, mk, alpha in cases:
+        its, _, clean, sigma, args, ncalls = _run_pnp(models, degr, utils, pnp, net, problem, mk, alpha, 2, 100, 5)
+        assert ncalls == 1 + 500 and 99 in its
+        rec = dict(steps=np.array(100), num_samples=np.array(5), alpha=np.array(alpha), sigma=np.array(sigma), noisy=its["noisy"].numpy(),
+                   logged=np.array(sorted(k for k in its if k != "noisy")))
+        for it in (0, 10, 50, 90, 99):
+            rec[f"x_it{it}"] = its[it].numpy()
+        np.savez_compressed(os.path.join(OUT, f"pnp_long_{tag}.npz"), **rec)
+        print("long", tag, float(its[99].abs().mean()))
+    # C1
+    its, _, clean, sigma, args, ncalls = _run_pnp(models, degr, utils, pnp, "mnist", "denoising", lambda S: (degr.Denoising(), 0.2), 0.8, 8, 50, 5)
+    assert ncalls == 1 + 250
+    rec = dict(steps=np.array(50), num_samples=np.array(5), alpha=np.array(0.8), sigma=np.array(sigma), noisy=its["noisy"].numpy())
+    for it in list(range(0, 50, 5)) + [49]:
+        rec[f"x_it{it}"] = its[it].numpy()
+    np.savez_compressed(os.path.join(OUT, "pnp_long_mnist_c1.npz"), **rec)
+    print("long c1", float(its[49].abs().mean()))
+    # first two outer iterations of C2 / C3 / C4 on the BASELINE nets
+    big = [("c2", "celeba128", "inpainting", lambda S: (degr.BoxInpainting(20), 0.05), 0.5),
+           ("c3", "celeba128", "gaussian_deblurring_FFT", lambda S: (degr.GaussianDeblurring(1.0, 61, "fft", 3, S, "cpu"), 0.05), 0.01),
+           ("c4", "afhq256", "superresolution", lambda S: (degr.Superresolution(4, S, device="cpu"), 0.05), 0.3)]
+    for tag, net, problem, mk, alpha in big:
+        its, inputs, clean, sigma, args, ncalls = _run_pnp(models, degr, utils, pnp, net, problem, mk, alpha, 2, 100, 5, stop_after=2)
+        assert len(inputs) == 3 and ncalls == 1 + 10        # inputs[k] = x entering iteration k = the result of iteration k - 1
+        rec = dict(steps=np.array(100), num_samples=np.array(5), alpha=np.array(alpha), sigma=np.array(sigma), B=np.array(2))
+        rec.update(crop_rec("noisy", its["noisy"])); rec.update(crop_rec("x_it0", inputs[1])); rec.update(crop_rec("x_it1", inputs[2]))
+        np.savez_compressed(os.path.join(OUT, f"pnp_iter_{tag}.npz"), **rec)
+        print("iter", tag, float(inputs[2].abs().mean()))
+    # 90-step OT-ODE on the test net
+    for tag, problem, mk, gamma in (("tiny4_random_inpainting", "random_inpainting", lambda S: (degr.RandomInpainting(0.7), 0.01), "constant"),
+                                    ("tiny4_superresolution", "superresolution", lambda S: (degr.Superresolution(2, S, device="cpu"), 0.05), "constant")):
+        m, cfg, sd = build_ref_unet(models, "tiny4")
+        S, B, steps, t0 = 64, 2, 100, 0.1
+        degradation, sigma = mk(S)
+        clean = det_image((B, 3, S, S), 31)
+        args = utils.CfgNode(dict(method="ot_ode", model="ot", dataset="celeba", problem=problem, steps_ode=steps, start_time=t0, gamma=gamma,
+                                  max_batch=1, compute_time=False, compute_memory=False, save_results=True, batch=0, save_path_ip="/tmp"))
+        iterates = {}; seq = {"n": 0}
+
+        def fake_randn_like(like, **kw):
+            i = seq["n"]; seq["n"] += 1
+            return det_normal(tuple(like.shape), 61, i)        # call 0: measurement noise, call 1: initialisation noise
+
+        def cap_psnr(clean_img, noisy_img, rec_img, a, H_adj, iter="final"):
+            iterates.setdefault(int(iter), rec_img.clone()); iterates["noisy"] = noisy_img.clone()
+        noop = lambda *a, **k: None
+        saved = (torch.randn_like, utils.compute_psnr, utils.compute_ssim, utils.compute_lpips, utils.save_images,
+                 utils.compute_average_psnr, utils.compute_average_ssim, utils.compute_average_lpips)
+        torch.randn_like = fake_randn_like
+        utils.compute_psnr, utils.compute_ssim, utils.compute_lpips, utils.save_images = cap_psnr, noop, noop, noop
+        utils.compute_average_psnr = utils.compute_average_ssim = utils.compute_average_lpips = noop
+        try:
+            ot.OT_ODE(m, torch.device("cpu"), args).solve_ip([(clean, torch.zeros(B))], degradation, sigma)
+        finally:
+            (torch.randn_like, utils.compute_psnr, utils.compute_ssim, utils.compute_lpips, utils.save_images,
+             utils.compute_average_psnr, utils.compute_average_ssim, utils.compute_average_lpips) = saved
+        assert seq["n"] == 2 and 99 in iterates
+        rec = dict(steps=np.array(steps), start_time=np.array(t0), sigma=np.array(sigma), noisy=iterates["noisy"].numpy(), first=np.array(10))
+        for it in (10, 50, 99):
+            rec[f"x_it{it}"] = iterates[it].numpy()
+        np.savez_compressed(os.path.join(OUT, f"ot_ode_long_{tag}.npz"), **rec)
+        print("ot_ode long", tag, float(iterates[99].abs().mean()))
+
+
 def crop_rec(prefix, t):
     """crop + corner + float64 checksums of a (B,C,H,W) tensor (the big-net fixtures stay small)."""
     H = t.shape[2]
@@ -475,7 +598,7 @@ def gen_ncsnpp():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     models, degr, utils, pnp = import_reference()
-    which = sys.argv[1:] or ["unet", "degr", "traj", "ot_ode", "big", "ops", "ncsnpp"]
+    which = sys.argv[1:] or ["unet", "degr", "traj", "ot_ode", "big", "ops", "ncsnpp", "long"]
     if "unet" in which:
         gen_unet(models)
     if "degr" in which:
@@ -490,5 +613,7 @@ if __name__ == "__main__":
         gen_ops()
     if "ncsnpp" in which:
         gen_ncsnpp()
+    if "long" in which:
+        gen_long(models, degr, utils, pnp)
     if "gmres" in which:
         gen_ot_ode(models, degr, utils, only=("tiny4_deblurring_gmres",))

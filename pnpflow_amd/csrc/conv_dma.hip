@@ -531,8 +531,21 @@ bool conv_dma_supported(const ConvParams& p, int stride, int up, int terms) {
         if (s.C % kc != 0 || (s.taps != 9 && s.taps != 1)) return false;
     }
     if ((size_t)(p.Hs + 2) * (p.Ws + 2) * 128 >= (1ull << 31)) return false;     // 32-bit piece offsets inside a plane
+    if (dma_mode() >= 2) return true;
     const long wgs = (long)p.B * (p.H / DMA_TH) * (p.W / 16) * (p.Cout / DMA_BN);
-    return dma_mode() >= 2 || wgs >= 512;
+    if (wgs < 512) return false;
+    // The prep pass costs one read + one write of every operand element (measured: 30 us on average, 8 % of a forward when every
+    // qualifying launch took this path - profiles/r03_ab_dma_variants.md), the conv it feeds is ~15 % faster than the register-staged
+    // kernel.  It pays where a prepped element feeds enough multiply-adds: MACs per operand element = K_total * Cout / (channels
+    // prepped per output pixel).  Same-box layer table: 2304 (16^2 x 256, one or two 3x3 segments) and the upsampling convs (operand
+    // at quarter resolution) win, 1152 (32^2 x 128) and the launches that drag 1-tap shortcut segments along lose; the pure 1x1
+    // launches win when Cout >= 3 C (q,k,v stacked), not at Cout = C.
+    static const double min_ratio = getenv("PNPFLOW_HIP_DMA_RATIO") ? atof(getenv("PNPFLOW_HIP_DMA_RATIO")) : 2000.0;
+    double macs = 0.0, elts = 0.0; bool all1 = true;
+    for (int i = 0; i < p.nseg; ++i) { macs += (double)p.seg[i].taps * p.seg[i].C * p.Cout; elts += p.seg[i].C; all1 &= p.seg[i].taps == 1; }
+    if (up) elts *= 0.25;
+    if (all1) return p.Cout >= 3 * (int)elts;
+    return macs / elts >= min_ratio;
 }
 
 template <int UP, int TERMS>

@@ -311,28 +311,157 @@ class RandomInpainting(Degradation):
     H_adj = H
 
 
+# ---- cv2.line restated (opencv/modules/imgproc/src/drawing.cpp: ThickLine / FillConvexPoly / Line2 / Circle) -------------------
+# OpenCV (`opencv-python`, unpinned in the reference's requirements.txt) is not installed here: PARITY UNPINNED.  This restatement is
+# written separately from the product's (pnpflow_amd/cv_draw.py walks the edges incrementally; here every edge segment is a closed
+# form x(row) = xs + dx * (row - row0) and the outline / circle points are generated as arrays).
+_XS, _X1 = 16, 1 << 16
+
+
+def _cdiv(a: int, b: int) -> int:
+    q = abs(a) // abs(b)
+    return q if (a >= 0) == (b >= 0) else -q
+
+
+def _cv_line2_points(p1, p2, W, H):
+    """Pixels of Line2 between two 16.16 points (clipped to the image as cv::clipLine does it)."""
+    (x1, y1), (x2, y2) = p1, p2
+    # cv::clipLine on the 16.16 rectangle [0, W << 16) x [0, H << 16): outcodes, then the y borders, then the x borders
+    R, Bm = (W << _XS) - 1, (H << _XS) - 1
+    code = lambda x, y: (x < 0) + (x > R) * 2 + (y < 0) * 4 + (y > Bm) * 8
+    c1, c2 = code(x1, y1), code(x2, y2)
+    if (c1 & c2) == 0 and (c1 | c2) != 0:
+        if c1 & 12:
+            a = 0 if c1 < 8 else Bm
+            x1 += int(float(a - y1) * (x2 - x1) / (y2 - y1)); y1 = a; c1 = (x1 < 0) + (x1 > R) * 2
+        if c2 & 12:
+            a = 0 if c2 < 8 else Bm
+            x2 += int(float(a - y2) * (x2 - x1) / (y2 - y1)); y2 = a; c2 = (x2 < 0) + (x2 > R) * 2
+        if (c1 & c2) == 0 and (c1 | c2) != 0:
+            if c1:
+                a = 0 if c1 == 1 else R
+                y1 += int(float(a - x1) * (y2 - y1) / (x2 - x1)); x1 = a; c1 = 0
+            if c2:
+                a = 0 if c2 == 1 else R
+                y2 += int(float(a - x2) * (y2 - y1) / (x2 - x1)); x2 = a; c2 = 0
+    if (c1 | c2) != 0:
+        return []
+    dx, dy = x2 - x1, y2 - y1
+    ax, ay = abs(dx), abs(dy)
+    pts = [((x2 + (_X1 >> 1)) >> _XS, (y2 + (_X1 >> 1)) >> _XS)]
+    if ax > ay:
+        if dx < 0:
+            x1, x2, y1, y2, dy = x2, x1, y2, y1, -dy
+        step = _cdiv(dy << _XS, ax | 1)
+        n = ((x2 - x1) >> _XS) + 1
+        xs = ((x1 + (_X1 >> 1)) >> _XS) + np.arange(n)
+        ys = ((y1 + (_X1 >> 1)) + step * np.arange(n, dtype=np.int64)) >> _XS
+    else:
+        if dy < 0:
+            x1, x2, y1, y2, dx = x2, x1, y2, y1, -dx
+        step = _cdiv(dx << _XS, ay | 1)
+        n = ((y2 - y1) >> _XS) + 1
+        ys = ((y1 + (_X1 >> 1)) >> _XS) + np.arange(n)
+        xs = ((x1 + (_X1 >> 1)) + step * np.arange(n, dtype=np.int64)) >> _XS
+    pts += list(zip(xs.tolist(), ys.tolist()))
+    return [(x, y) for x, y in pts if 0 <= x < W and 0 <= y < H]
+
+
+def _cv_poly_rows(v):
+    """{row: (x_left, x_right)} of FillConvexPoly's scan conversion for 16.16 vertices (LINE_8: both ends rounded with + 2^15)."""
+    n = len(v)
+    half = _X1 >> 1
+    rows_of = [(p[1] + half) >> _XS for p in v]
+    imin = min(range(n), key=lambda i: (v[i][1], i))
+    y0, ymax = rows_of[imin], max(rows_of)
+
+    def chain(di):
+        """[(row0, row1_exclusive, xs, dx)] of one walker (di = +1 / -1 around the vertex list)"""
+        segs, y, i0 = [], y0, imin
+        for _ in range(n):
+            i1 = (i0 + di) % n
+            ty = rows_of[i1]
+            if ty > y:
+                xs, xe = v[i0][0], v[i1][0]
+                segs.append((y, ty, xs, _cdiv((xe - xs) * 2 + (ty - y), 2 * (ty - y))))
+                y = ty
+            i0 = i1
+        return segs
+    a, b = chain(+1), chain(-1)
+
+    def at(segs, row):
+        for r0, r1, xs, dx in segs:
+            if r0 <= row < r1:
+                return xs + dx * (row - r0)
+        r0, r1, xs, dx = segs[-1]
+        return xs + dx * (row - r0)                       # the last row continues the last segment (the loop ends at ymax inclusive)
+    out = {}
+    last = min(a[-1][1], b[-1][1]) if a and b else y0
+    for row in range(y0, min(ymax, last) + 1):
+        if not a or not b:
+            break
+        if row >= a[-1][1] or row >= b[-1][1]:
+            # a walker that has run out of vertices ends the fill (edges < 0) - except on the final row, where it keeps its slope
+            if row > ymax:
+                break
+        xa, xb = at(a, row), at(b, row)
+        lo, hi = (xb, xa) if xa > xb else (xa, xb)
+        out[row] = ((lo + half) >> _XS, (hi + half) >> _XS)
+    return out
+
+
+def _cv_circle_runs(r):
+    """[(dy, half-width)] runs of the filled midpoint circle (both signs of dy are drawn)"""
+    runs, err, dx, dy, plus, minus = [], 0, r, 0, 1, (r << 1) - 1
+    while dx >= dy:
+        runs.append((dy, dx)); runs.append((dx, dy))
+        dy += 1; err += plus; plus += 2
+        if err > 0:
+            err -= minus; dx -= 1; minus -= 2
+    return runs
+
+
+def cv2_thick_line(img: np.ndarray, p0, p1, thickness: int) -> np.ndarray:
+    """cv2.line(img, p0, p1, 255, thickness), thickness > 1, LINE_8, on a (H, W) uint8 array (in place)."""
+    H, W = img.shape
+    x0, y0, x1, y1 = int(p0[0]) << _XS, int(p0[1]) << _XS, int(p1[0]) << _XS, int(p1[1]) << _XS
+    ddx, ddy = (x0 - x1) / _X1, (y1 - y0) / _X1
+    rr = ddx * ddx + ddy * ddy
+    th = thickness << (_XS - 1)
+    if rr > 2.220446049250313e-16:
+        k = (th + (thickness & 1) * _X1 * 0.5) / math.sqrt(rr)
+        dpx, dpy = int(round(ddy * k)), int(round(ddx * k))
+        v = [(x0 + dpx, y0 + dpy), (x0 - dpx, y0 - dpy), (x1 - dpx, y1 - dpy), (x1 + dpx, y1 + dpy)]
+        for i in range(4):
+            for x, y in _cv_line2_points(v[i - 1], v[i], W, H):
+                img[y, x] = 255
+        for row, (xa, xb) in _cv_poly_rows(v).items():
+            if 0 <= row < H and xb >= 0 and xa < W and xb >= xa:
+                img[row, max(xa, 0):min(xb, W - 1) + 1] = 255
+    rad = (th + (_X1 >> 1)) >> _XS
+    for cx, cy in ((int(p0[0]), int(p0[1])), (int(p1[0]), int(p1[1]))):
+        for dy, hw in _cv_circle_runs(rad):
+            for yy in (cy - dy, cy + dy):
+                if 0 <= yy < H and cx + hw >= 0 and cx - hw < W:
+                    img[yy, max(cx - hw, 0):min(cx + hw, W - 1) + 1] = 255
+    return img
+
+
 def paintbrush_mask_array(B: int, H: int, W: int) -> np.ndarray:
     """pnpflow/utils.py:339-350 with MaskGenerator._generate_mask (:904-924): random.seed(42); per image 10 strokes
-    (endpoints randint(W//2 +- 30), randint(H//2 +- 30), thickness randint(8, int((W+H)*0.08))).  PARITY UNPINNED: the
-    reference rasterises strokes with cv2.line, which is not installed here; a stroke is restated as the capsule cv2's
-    rectangle + round caps approximates (pixels within thickness/2 of the segment); edge pixels may differ by one."""
+    (endpoints randint(W//2 +- 30), randint(H//2 +- 30), thickness randint(8, int((W+H)*0.08))) drawn with cv2.line (restated above,
+    PARITY UNPINNED: cv2 is not installed here).  Keep-mask: 1 = observed, 0 = under a stroke."""
     import random
     rng = random.Random(42)
     size = int((W + H) * 0.08)
-    ys, xs = np.arange(H, dtype=np.float64)[:, None], np.arange(W, dtype=np.float64)[None, :]
     out = np.ones((B, H, W), dtype=np.uint8)
     for b in range(B):
+        img = np.zeros((H, W), dtype=np.uint8)
         for _ in range(10):
             x1 = rng.randint(W // 2 - 30, W // 2 + 30); x2 = rng.randint(W // 2 - 30, W // 2 + 30)
             y1 = rng.randint(H // 2 - 30, H // 2 + 30); y2 = rng.randint(H // 2 - 30, H // 2 + 30)
-            t = rng.randint(8, size)
-            ex, ey = float(x2 - x1), float(y2 - y1)
-            den = ex * ex + ey * ey
-            for yy in range(H):
-                for_x = xs[0]
-                u = np.clip(((for_x - x1) * ex + (yy - y1) * ey) / den, 0.0, 1.0) if den > 0 else np.zeros(W)
-                d2 = (for_x - (x1 + u * ex)) ** 2 + (yy - (y1 + u * ey)) ** 2
-                out[b, yy, d2 <= (t / 2.0) ** 2] = 0
+            cv2_thick_line(img, (x1, y1), (x2, y2), rng.randint(8, size))
+        out[b][img != 0] = 0
     return out
 
 

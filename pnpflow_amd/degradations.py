@@ -132,26 +132,22 @@ def paintbrush_masks(B, H, W):
     """Keep-masks (1 = observed) of pnpflow/utils.py:339-350 + MaskGenerator._generate_mask (:904-924) for a batch of B images:
     `random.seed(42)`, then per image 10 strokes with endpoints randint(W//2-30, W//2+30) x randint(H//2-30, H//2+30) and
     thickness randint(8, int((W+H)*0.08)) - Python's own Mersenne-Twister sequence, so endpoints and thicknesses ARE the
-    reference's.  The reference rasterises each stroke with cv2.line (thick line = filled rectangle + round caps, OpenCV's
-    fixed-point polygon fill); cv2 is not available here, so a stroke is rasterised as the capsule it approximates: pixel
-    centres within thickness/2 of the segment.  Edge pixels of a stroke may differ from OpenCV's by one pixel: PARITY UNPINNED."""
+    reference's.  Each stroke is rasterised as cv2.line does it (cv_draw.py restates OpenCV's ThickLine: 16.16 fixed-point
+    quadrilateral fill + outline + midpoint-circle caps).  cv2 itself is not installed here: PARITY UNPINNED."""
     import random
+    from .cv_draw import thick_line
     if W < 64 or H < 64:
         raise Exception("Width and Height of mask must be at least 64!")
     rng = random.Random(42)
     size = int((W + H) * 0.08)
-    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
     out = np.ones((B, H, W), dtype=np.uint8)
     for b in range(B):
+        img = np.zeros((H, W), dtype=np.uint8)
         for _ in range(10):
             x1, x2 = rng.randint(W // 2 - 30, W // 2 + 30), rng.randint(W // 2 - 30, W // 2 + 30)
             y1, y2 = rng.randint(H // 2 - 30, H // 2 + 30), rng.randint(H // 2 - 30, H // 2 + 30)
-            t = rng.randint(8, size)
-            dx, dy = x2 - x1, y2 - y1
-            L2 = dx * dx + dy * dy
-            u = np.clip(((xx - x1) * dx + (yy - y1) * dy) / L2, 0.0, 1.0) if L2 > 0 else np.zeros_like(xx)
-            d2 = (xx - (x1 + u * dx)) ** 2 + (yy - (y1 + u * dy)) ** 2
-            out[b][d2 <= (t / 2.0) ** 2] = 0
+            thick_line(img, (x1, y1), (x2, y2), rng.randint(8, size))
+        out[b][img != 0] = 0
     return out
 
 

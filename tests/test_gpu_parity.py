@@ -9,6 +9,7 @@ transcendental differences only):
   10-step x 2-sample trajectory: 1e-4 absolute;  PSNR within 0.05 dB (north_star bound)
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -62,6 +63,7 @@ def deg_pairs(S):
     return [("denoising", D.Denoising(), O.Denoising()),
             ("box", D.BoxInpainting(S // 6), O.BoxInpainting(S // 6)),
             ("random", D.RandomInpainting(0.7), O.RandomInpainting(0.7)),
+            ("paintbrush", D.PaintbrushInpainting(), O.PaintbrushInpainting()),
             ("sr2", D.Superresolution(2, S), O.Superresolution(2, S)),
             ("sr4", D.Superresolution(4, S), O.Superresolution(4, S)),
             ("srbic2", D.Superresolution(2, S, mode="bicubic"), O.Superresolution(2, S, mode="bicubic")),
@@ -1224,3 +1226,114 @@ def test_ot_ode_90_steps_match_reference(hip, golden, tag, problem, sigma):
     clean = det_image((2, Cc, S, S), 31)
     d = (psnr_per_image(x, clean.cuda()).cpu() - O.psnr_per_image(torch.from_numpy(g["x_it99"]), clean)).abs().max()
     assert float(d) <= 0.05, d
+
+
+# ---------------------------------------------------------------------------------------------
+# SURVEY 8f N1 executed: a checkpoint file under the reference's path + dataset trees on disk, main.py WITHOUT `synthetic`
+# ---------------------------------------------------------------------------------------------
+def _png_tree(folder, n, w, h, seed):
+    from PIL import Image
+    os.makedirs(folder, exist_ok=True)
+    names, arrays = [], []
+    for i in range(n):
+        g = np.random.Generator(np.random.Philox(key=[seed, i]))
+        a = g.integers(0, 256, size=(h // 8 + 1, w // 8 + 1, 3), dtype=np.uint8)
+        a = np.asarray(Image.fromarray(a).resize((w, h), Image.BICUBIC))          # smooth-ish content
+        name = f"{i + 1:06d}.png"
+        Image.fromarray(a).save(os.path.join(folder, name))
+        names.append(name); arrays.append(a)
+    return names, arrays
+
+
+@pytest.mark.parametrize("dataset", ["celeba", "afhq_cat"])
+def test_main_reads_checkpoint_file_and_dataset_tree(hip, tmp_path, dataset):
+    """The reference's eval path end to end (utils.py:208-226 load_model, main.py:89-95 checkpoint path, dataloaders.py:17-118):
+    `model/<dataset>/ot/model_final.pt` written with torch.save, a CelebA tree (partition CSV + PNGs, 178 x 218) / an AFHQ tree
+    (test/cat/*.png), `python main.py` with NO synthetic opt-in - and its PSNR files equal a run that takes the same weights from
+    memory and the same pixels through an independent restatement of the transform pipeline."""
+    import subprocess, sys
+    from PIL import Image
+    import pnpflow_amd.degradations as D
+    from pnpflow_amd.methods.pnp_flow import PNP_FLOW
+    from pnpflow_amd.utils import CfgNode
+    root = str(tmp_path) + "/"
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.symlink(os.path.join(repo, "config"), os.path.join(root, "config"))
+    net = "celeba128" if dataset == "celeba" else "afhq256"
+    m, cfg, sd = model_for(net)
+    S = cfg["input_height"]
+    os.makedirs(os.path.join(root, "model", dataset, "ot"))
+    torch.save({k: v.clone() for k, v in sd.items()}, os.path.join(root, "model", dataset, "ot", "model_final.pt"))
+    if dataset == "celeba":
+        names, arrays = _png_tree(os.path.join(root, "data", "celeba", "img_align_celeba"), 6, 178, 218, 5)
+        with open(os.path.join(root, "data", "celeba", "list_eval_partition.csv"), "w") as f:
+            f.write("image_id,partition\n")
+            f.write("000000.png,2\n")                        # (the reference's pandas call drops the first listed image)
+            for i, nme in enumerate(names):
+                f.write(f"{nme},{2 if i < 4 else 0}\n")       # four test images, two train images
+        test_arrays = arrays[:4]
+        prep = lambda a: np.asarray(Image.fromarray(a[20:198]).resize((128, 128), Image.BILINEAR))      # CenterCrop(178) of 218 rows, Resize(128)
+        problem, deg, sigma, bs, nb = "inpainting", D.BoxInpainting(20), 0.05, 2, 2
+    else:
+        names, arrays = _png_tree(os.path.join(root, "data", "afhq_cat", "test", "cat"), 2, 256, 256, 6)
+        test_arrays = arrays
+        prep = lambda a: a
+        problem, deg, sigma, bs, nb = "superresolution", D.Superresolution(4, 256), 0.05, 1, 2
+    steps, ns = 4, 2
+    opts = ["main.py", "--opts", "dataset", dataset, "problem", problem, "method", "pnp_flow", "max_batch", str(nb), "batch_size_ip", str(bs),
+            "steps_pnp", str(steps), "num_samples", str(ns), "alpha", "0.5", "root", root, "output_root", root]
+    out = subprocess.run([sys.executable] + opts, cwd=repo, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "SYNTHETIC" not in out.stdout
+    base = os.path.join(root, "results", dataset, "ot", problem, "pnp_flow", "test")
+    sub = [d for d, _, f in os.walk(base) if "psnr_rec_batch0.txt" in f]
+    assert len(sub) == 1, list(os.walk(root))[:20]
+    # the same restoration from memory
+    args = CfgNode(dict(method="pnp_flow", model="ot", problem=problem, noise_type="gaussian", num_samples=ns, steps_pnp=steps, lr_pnp=1.0,
+                        gamma_style="alpha_1_minus_t", alpha=0.5, max_batch=nb,
+                        compute_time=False, compute_memory=False, save_results=True, batch=0, save_path_ip=str(tmp_path / "mem")))
+    os.makedirs(args.save_path_ip)
+    tens = [torch.from_numpy(np.ascontiguousarray(prep(a).transpose(2, 0, 1))).float().div(255).sub(0.5).div(0.5) for a in test_arrays]
+    loader = [(torch.stack(tens[i * bs:(i + 1) * bs]), torch.zeros(bs)) for i in range(nb)]
+    m.set_precision(1)
+    solver = PNP_FLOW(m, torch.device("cuda"), args)
+    solver.solve_ip(loader, deg, sigma)
+    for b in range(nb):
+        for word in ("rec", "noisy"):
+            a = [l.split() for l in open(os.path.join(sub[0], f"psnr_{word}_batch{b}.txt")).read().strip().splitlines()]
+            c = [l.split() for l in open(os.path.join(args.save_path_ip, f"psnr_{word}_batch{b}.txt")).read().strip().splitlines()]
+            assert [x[0] for x in a] == [x[0] for x in c] and len(a) >= 2
+            assert max(abs(float(x[1]) - float(y[1])) for x, y in zip(a, c)) < 2e-3, (b, word, a, c)
+
+
+def test_paintbrush_inpainting_through_the_engine(hip):
+    """PaintbrushInpainting (degradations.py:47-52; masks utils.py:339-350, 904-924 drawn with the restated cv2.line): masks equal the
+    oracle's separately written restatement bit for bit, H = H_adj = mask * x exactly, and a PnP-Flow restoration with it follows the
+    oracle's loop.  (cv2 is not installed: the raster is PARITY UNPINNED against OpenCV itself.)"""
+    import pnpflow_amd.degradations as D
+    from pnpflow_amd.methods.pnp_flow import PNP_FLOW
+    from pnpflow_amd.utils import CfgNode
+    for (B, S) in ((3, 64), (2, 128)):
+        dg = D.PaintbrushInpainting()
+        mask = dg.mask(B, S, S, torch.device("cuda")).cpu().numpy()
+        np.testing.assert_array_equal(mask, O.paintbrush_mask_array(B, S, S))
+        assert 0.03 < float((mask == 0).mean()) < 0.7
+        x = det_normal((B, 3, S, S), 81)
+        hx = dg.H(x.cuda()).cpu()
+        assert torch.equal(hx, torch.from_numpy(mask.astype(np.float32))[:, None] * x)
+        assert torch.equal(dg.H_adj(hx.cuda()).cpu(), hx)
+    m, cfg, sd = model_for("tiny4")
+    S, Cc, B, steps, ns, sigma = 64, 3, 2, 6, 2, 0.05
+    args = CfgNode(dict(method="pnp_flow", model="ot", problem="paintbrush_inpainting", noise_type="gaussian", num_samples=ns, steps_pnp=steps,
+                        lr_pnp=1.0, gamma_style="alpha_1_minus_t", alpha=0.5, max_batch=1, compute_time=False, compute_memory=False,
+                        save_results=False, batch=0, sigma_noise=sigma))
+    solver = PNP_FLOW(m, torch.device("cuda"), args)
+    noise = torch.stack([det_normal((B, Cc, S, S), 83, i) for i in range(steps * ns)])
+    solver.noise = noise.cuda()
+    clean = det_image((B, Cc, S, S), 31)
+    do = O.PaintbrushInpainting()
+    y = O.make_measurement(clean, do, sigma, 0, noise=det_normal((B, Cc, S, S), 82))
+    x = solver.restore_batch(y.cuda(), D.PaintbrushInpainting(), sigma, lr=sigma ** 2)
+    ref = O.pnp_flow_restore(lambda a, t: O.unet_forward(sd, cfg, a, t), do, y, sigma, steps=steps, num_samples=ns, alpha=0.5,
+                             noise_fn=lambda it, s_, like: noise[it * ns + s_])
+    np.testing.assert_allclose(x.cpu().numpy(), ref.numpy(), atol=TRAJ_ATOL)

@@ -253,8 +253,8 @@ def test_operator_attributes_of_the_reference_api(golden=None):
 def test_paintbrush_masks_are_seeded_prefix_consistent_and_match_the_oracle():
     """PaintbrushInpainting (degradations.py:47-52): the stroke parameters come from Python's random.seed(42) sequence exactly as
     in the reference (utils.py:904-924); image i's mask does not depend on the batch size (shards slice the global batch).
-    Rasterisation is a restatement of cv2.line's capsule (parity unpinned: cv2 absent) - product and oracle implement it
-    independently (vectorised vs per row)."""
+    Strokes are rasterised by a restatement of cv2.line (OpenCV's ThickLine: fixed-point quadrilateral + outline + midpoint-circle
+    caps; cv2 is absent, parity unpinned) - product (pnpflow_amd/cv_draw.py) and oracle are written separately."""
     import random
     from oracle import pnpflow_oracle as O
     from pnpflow_amd.degradations import paintbrush_masks
@@ -262,6 +262,7 @@ def test_paintbrush_masks_are_seeded_prefix_consistent_and_match_the_oracle():
     assert m4.shape == (4, 64, 96) and set(np.unique(m4)) <= {0, 1} and 0.02 < (m4 == 0).mean() < 0.6
     np.testing.assert_array_equal(paintbrush_masks(2, 64, 96), m4[:2])
     np.testing.assert_array_equal(O.paintbrush_mask_array(3, 64, 96), m4[:3])
+    np.testing.assert_array_equal(O.paintbrush_mask_array(2, 128, 128), paintbrush_masks(2, 128, 128))
     # the first stroke of the reference's sequence: endpoints / thickness from random.seed(42)
     rng = random.Random(42)
     x1, x2 = rng.randint(48 - 30, 48 + 30), rng.randint(48 - 30, 48 + 30); y1, y2 = rng.randint(32 - 30, 32 + 30), rng.randint(32 - 30, 32 + 30)
@@ -358,3 +359,29 @@ def test_bench_gpus_flag_launches_that_many_ranks():
 def test_bench_refuses_a_world_size_that_is_not_gpus():
     out = _bench(["--gpus", "8", "--workload", "tiny"], {"WORLD_SIZE": "1", "RANK": "0"})
     assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
+
+
+def test_cv2_line_restatement_known_answers():
+    """What OpenCV's thick lines are known for (drawing.cpp ThickLine): an EVEN thickness t covers t + 1 pixel rows (the body is
+    p +- round(t/2 * n) in 16.16 fixed point, both borders inclusive), the end caps are filled midpoint circles of radius (t + 1) // 2
+    around the integer endpoints, a degenerate line is just the cap, and drawing is symmetric under x <-> y transposition."""
+    from oracle import pnpflow_oracle as O
+    from pnpflow_amd.cv_draw import circle_filled, thick_line
+    a = thick_line(np.zeros((40, 40), np.uint8), (10, 20), (30, 20), 8)
+    rows = np.where(a.any(1))[0]; cols = np.where(a.any(0))[0]
+    assert (rows.min(), rows.max()) == (16, 24) and (cols.min(), cols.max()) == (6, 34)
+    assert (a[16, 10:31] == 255).all() and a[16, 9] == 0 and (a[20, 6:35] == 255).all()      # body rows span x1..x2, the caps add 4 px
+    b = thick_line(np.zeros((40, 40), np.uint8), (10, 20), (30, 20), 9)
+    rows = np.where(b.any(1))[0]
+    assert (rows.min(), rows.max()) == (15, 25)                                              # odd thickness: +-5
+    c = thick_line(np.zeros((40, 40), np.uint8), (20, 10), (20, 30), 8)
+    np.testing.assert_array_equal(c, a.T)
+    d = thick_line(np.zeros((40, 40), np.uint8), (20, 20), (20, 20), 8)
+    e = np.zeros((40, 40), np.uint8); circle_filled(e, 20, 20, 4)
+    np.testing.assert_array_equal(d, e)
+    assert [int((r != 0).sum()) for r in e[16:25]] == [1, 5, 7, 7, 9, 7, 7, 5, 1]          # the r = 4 midpoint disc with its one-pixel tips
+    assert e[16, 20] and e[24, 20] and e[20, 16] and e[20, 24] and not e[16, 19]
+    rng = np.random.default_rng(1)
+    for _ in range(60):          # product vs oracle restatement, incl. strokes that touch the border (clipLine path of the product)
+        p0 = tuple(int(v) for v in rng.integers(8, 88, 2)); p1 = tuple(int(v) for v in rng.integers(8, 88, 2)); t = int(rng.integers(8, 16))
+        np.testing.assert_array_equal(thick_line(np.zeros((96, 96), np.uint8), p0, p1, t), O.cv2_thick_line(np.zeros((96, 96), np.uint8), p0, p1, t))

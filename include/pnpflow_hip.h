@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 3
+#define PF_ABI_VERSION 4
 
 typedef enum pf_status {
     PF_OK = 0,
@@ -191,6 +191,20 @@ int pf_psnr(const float* rec, const float* clean, float* out, int B, int n_per_i
  * (pnpflow/utils.py:780-802) - 11x11 Gaussian window sigma 1.5, k1 0.01, k2 0.03, reflect padding, mean over (C,H,W) in
  * fp64 -> out[B] (device, double).  H, W > 5.  PARITY UNPINNED: ignite is absent from the build container. */
 int pf_ssim(const float* rec, const float* clean, double* out, int B, int C, int H, int W, void* stream);
+
+/* ---- LPIPS (AlexNet, v0.1), SURVEY 8f N2 ------------------------------------------------------------------------------------
+ * What the reference logs next to PSNR / SSIM (pnpflow/utils.py:677-724): lpips.LPIPS(net='alex')(img0, img1, normalize=True).
+ * The network (torchvision AlexNet features + lpips' five 1x1 "lin" heads) is restated in csrc/lpips.hip; weights are loaded under
+ * the published names "features.{0,3,6,8,10}.{weight,bias}" (torchvision.models.alexnet) and "lin{0..4}" (the [1][C][1][1] conv of
+ * lpips' NetLinLayer, as [C]).  PARITY UNPINNED: neither package nor their weight files are in the build image. */
+typedef struct pf_lpips pf_lpips;
+int pf_lpips_create(int device_id, pf_lpips** out);
+void pf_lpips_destroy(pf_lpips* l);
+const char* pf_lpips_last_error(const pf_lpips* l);
+int pf_lpips_load_weight(pf_lpips* l, const char* name, const float* host_data, const int64_t* shape, int ndim);
+/* img0, img1: [B][3][H][W] fp32 on the device; out[B] (device) <- LPIPS distance per image pair.  normalize != 0 applies the
+ * package's 2x - 1 first (the reference passes normalize=True on images that already are in [-1, 1]: utils.py:703-708). */
+int pf_lpips_forward(pf_lpips* l, const float* img0, const float* img1, float* out, int B, int H, int W, int normalize, void* stream);
 
 /* ---- the reference's native ops (NCSN++ "rectified" velocity net) ------------------------------------------- */
 /* upfirdn2d (pnpflow/image_generation/op/upfirdn2d_kernel.cu:49-369; definition: op/upfirdn2d.py:142-187): per plane of

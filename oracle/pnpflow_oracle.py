@@ -886,3 +886,47 @@ def fused_bias_act(x: torch.Tensor, bias: Optional[torch.Tensor], ref: Optional[
 def fused_leaky_relu(x: torch.Tensor, bias: torch.Tensor, negative_slope: float = 0.2, scale: float = 2 ** 0.5) -> torch.Tensor:
     """op/fused_act.py:84-96 (the GPU branch: the reference's CPU branch hard-codes the slope 0.2)."""
     return fused_bias_act(x, bias, None, 3, 0, negative_slope, scale)
+
+
+# ---- LPIPS (AlexNet, v0.1) - third-party: `lpips` (unpinned in the reference's requirements.txt) on torchvision's AlexNet ----------
+# Neither package nor the weight files are installed here: PARITY UNPINNED.  Restated from the published definition
+# (lpips/lpips.py: LPIPS.forward, ScalingLayer, NetLinLayer, normalize_tensor, spatial_average; torchvision.models.alexnet.features).
+LPIPS_CONVS = ((0, 3, 64, 11, 4, 2), (3, 64, 192, 5, 1, 2), (6, 192, 384, 3, 1, 1), (8, 384, 256, 3, 1, 1), (10, 256, 256, 3, 1, 1))
+
+
+def synthetic_lpips_state_dict(seed: int = 0) -> dict:
+    """Seed-fixed stand-in for the two published checkpoints, under THEIR key names: torchvision alexnet `features.N.{weight,bias}`
+    and lpips `lin{k}.model.1.weight` ([1, C, 1, 1], non-negative like the trained heads)."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    sd = {}
+    for idx, ci, co, k, s_, p in LPIPS_CONVS:
+        sd[f"features.{idx}.weight"] = torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5
+        sd[f"features.{idx}.bias"] = torch.randn(co, generator=g) * 0.05
+    for kk, (_, _, co, _, _, _) in enumerate(LPIPS_CONVS):
+        sd[f"lin{kk}.model.1.weight"] = torch.rand(1, co, 1, 1, generator=g) * (2.0 / co)
+    return sd
+
+
+def lpips_forward(sd: dict, in0: torch.Tensor, in1: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+    """lpips.LPIPS(net='alex', version='0.1', lpips=True, spatial=False).forward(in0, in1, normalize=normalize).flatten()"""
+    if normalize:
+        in0, in1 = 2 * in0 - 1, 2 * in1 - 1
+    shift = torch.tensor([-0.030, -0.088, -0.188]).view(1, 3, 1, 1); scale = torch.tensor([0.458, 0.448, 0.450]).view(1, 3, 1, 1)
+
+    def feats(x):
+        x = (x - shift) / scale
+        out = []
+        for idx, ci, co, k, s_, p in LPIPS_CONVS:
+            if idx in (3, 6):
+                x = F.max_pool2d(x, kernel_size=3, stride=2)
+            x = F.relu(F.conv2d(x, sd[f"features.{idx}.weight"], sd[f"features.{idx}.bias"], stride=s_, padding=p))
+            out.append(x)
+        return out
+    f0, f1 = feats(in0.float()), feats(in1.float())
+    val = 0
+    for kk in range(5):
+        n0 = f0[kk] / (torch.sqrt(torch.sum(f0[kk] ** 2, dim=1, keepdim=True)) + 1e-10)
+        n1 = f1[kk] / (torch.sqrt(torch.sum(f1[kk] ** 2, dim=1, keepdim=True)) + 1e-10)
+        d = (n0 - n1) ** 2
+        val = val + F.conv2d(d, sd[f"lin{kk}.model.1.weight"]).mean(dim=(2, 3), keepdim=True)
+    return val.flatten()

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PNPFLOW_HIP_LIB") or os.path.join(_HERE, "libpnpflow_hip.so")   # override: A/B builds of the kernels
 
-PF_ABI_VERSION = 3
+PF_ABI_VERSION = 4
 
 PF_DEG_DENOISING, PF_DEG_BOX_INPAINTING, PF_DEG_MASK_INPAINTING, PF_DEG_SUPERRESOLUTION, PF_DEG_GAUSSIAN_BLUR, PF_DEG_SR_FILTERED = range(6)
 
@@ -88,6 +88,11 @@ SIGNATURES = {
     "pf_upfirdn2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 13 + [C.c_void_p]),
     "pf_fused_bias_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "pf_ssim": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pf_lpips_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "pf_lpips_destroy": (None, [C.c_void_p]),
+    "pf_lpips_last_error": (C.c_char_p, [C.c_void_p]),
+    "pf_lpips_load_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "pf_lpips_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "pf_ot_ode_restore": (C.c_int, [C.c_void_p, C.POINTER(PfDegradation), C.POINTER(PfOtOdeParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, ITER_CB, C.c_void_p]),
     "pf_pnp_flow_restore": (C.c_int, [C.c_void_p, C.POINTER(PfDegradation), C.POINTER(PfPnpParams), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, ITER_CB, C.c_void_p]),
     "pf_engine_memory_bytes": (C.c_int64, [C.c_void_p]),

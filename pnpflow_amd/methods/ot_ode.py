@@ -224,6 +224,7 @@ class OT_ODE(object):
             def on_iter(iteration, x):
                 utils.compute_psnr(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=iteration)
                 utils.compute_ssim(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=iteration)
+                utils.compute_lpips(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=iteration)
 
             # the reference's logging iterations (ot_ode.py:149-150): the host is not involved on any other iteration
             log_its = [it for it in range(int(steps * self.args.start_time), int(steps))
@@ -247,9 +248,11 @@ class OT_ODE(object):
             if self.args.save_results:
                 utils.compute_psnr(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=int(steps) - 1)
                 utils.compute_ssim(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=int(steps) - 1)
+                utils.compute_lpips(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=int(steps) - 1)
         if self.args.save_results:
             utils.compute_average_psnr(self.args)
             utils.compute_average_ssim(self.args)
+            utils.compute_average_lpips(self.args)
         if self.args.compute_memory:
             utils.compute_average_memory(self.args)
         if self.args.compute_time:

@@ -201,6 +201,62 @@ def compute_ssim(clean_img, noisy_img, rec_img, args, H_adj, iter='final'):
     return ssim_rec, ssim_noisy
 
 
+# ---- LPIPS (reference utils.py:677-776) ------------------------------------------------------------------------
+_LPIPS = {"model": None, "resolved": False}
+
+
+def set_lpips_model(model):
+    """Installs the LPIPS network the logging uses (tests: synthetic weights under the published key names)."""
+    _LPIPS["model"], _LPIPS["resolved"] = model, True
+
+
+def lpips_model(device_index=0):
+    """The AlexNet-LPIPS network on the engine, or None when its weight files are not on this machine (the reference downloads
+    them on first use; there is no network here): looked up once, where torchvision / lpips keep them (lpips.find_weights)."""
+    if not _LPIPS["resolved"]:
+        from . import lpips as L
+        alex, lin = L.find_weights()
+        _LPIPS["resolved"] = True
+        if alex and lin:
+            _LPIPS["model"] = L.LPIPS.from_files(alex, lin, device_index)
+        else:
+            print("[pnpflow_amd] LPIPS weights not found (alexnet-owt-*.pth / lpips alex.pth; set PNPFLOW_LPIPS_DIR): "
+                  "lpips_*.txt files are not written (`--opts lpips require` makes this an error)")
+    return _LPIPS["model"]
+
+
+def compute_lpips(clean_img, noisy_img, rec_img, args, H_adj, iter='final'):
+    """lpips_{rec,noisy}_batch{b}.txt (reference utils.py:677-724), including its input convention: images post-processed to
+    [0, 1], mapped back to [-1, 1] and then passed with normalize=True (a second 2x - 1: the network sees [-3, 1]); for
+    superresolution the 'noisy' image is postprocess(H_adj(postprocess(y))).  PARITY UNPINNED (pnpflow_amd/lpips.py).
+    args.lpips: 'auto' (default: skipped with one notice when the weight files are absent), 'require', 'off'."""
+    mode = getattr(args, 'lpips', 'auto')
+    if mode == 'off':
+        return None
+    dev = rec_img.device
+    model = lpips_model(dev.index or 0)
+    if model is None:
+        if mode == 'require':
+            raise FileNotFoundError("LPIPS weights (torchvision alexnet-owt-*.pth + lpips weights/v0.1/alex.pth) not found; set PNPFLOW_LPIPS_DIR")
+        return None
+    clean = postprocess(clean_img.to(dev).clone()); noisy = postprocess(noisy_img.to(dev).clone()); rec = postprocess(rec_img.clone())
+    if args.problem in ('superresolution', 'superresolution_bicubic'):
+        noisy = postprocess(H_adj(noisy))
+    clean, rec, noisy = 2 * clean - 1, 2 * rec - 1, 2 * noisy - 1
+    lp_rec = _global_mean(model(clean, rec, normalize=True))
+    lp_noisy = _global_mean(model(clean, noisy, normalize=True))
+    _append_metric(args, 'lpips', 'rec', iter, lp_rec)
+    _append_metric(args, 'lpips', 'noisy', iter, lp_noisy)
+    return lp_rec, lp_noisy
+
+
+def compute_average_lpips(args):
+    """reference utils.py:727-776; nothing to average when LPIPS was skipped (no weight files)."""
+    if getattr(args, 'lpips', 'auto') == 'off' or _LPIPS["model"] is None:
+        return None
+    return _average_metric(args, 'lpips')
+
+
 def _average_metric(args, name):
     """reference utils.py:628-674 (psnr) / 819-863 (ssim): per-iteration mean over the batches, then the last value into
     final_{name}.txt next to the method's hyper-parameters."""

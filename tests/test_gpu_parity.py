@@ -1279,7 +1279,7 @@ def test_main_reads_checkpoint_file_and_dataset_tree(hip, tmp_path, dataset):
         test_arrays = arrays
         prep = lambda a: a
         problem, deg, sigma, bs, nb = "superresolution", D.Superresolution(4, 256), 0.05, 1, 2
-    steps, ns = 4, 2
+    steps, ns = 10, 2          # (>= 10: the reference's should_save_image divides by steps // 10, pnp_flow.py:174-175)
     opts = ["main.py", "--opts", "dataset", dataset, "problem", problem, "method", "pnp_flow", "max_batch", str(nb), "batch_size_ip", str(bs),
             "steps_pnp", str(steps), "num_samples", str(ns), "alpha", "0.5", "root", root, "output_root", root]
     out = subprocess.run([sys.executable] + opts, cwd=repo, capture_output=True, text=True, timeout=900)
@@ -1337,3 +1337,76 @@ def test_paintbrush_inpainting_through_the_engine(hip):
     ref = O.pnp_flow_restore(lambda a, t: O.unet_forward(sd, cfg, a, t), do, y, sigma, steps=steps, num_samples=ns, alpha=0.5,
                              noise_fn=lambda it, s_, like: noise[it * ns + s_])
     np.testing.assert_allclose(x.cpu().numpy(), ref.numpy(), atol=TRAJ_ATOL)
+
+
+# ---------------------------------------------------------------------------------------------
+# LPIPS (AlexNet v0.1) on the engine, PARITY UNPINNED (lpips / torchvision absent: oracle restatement, synthetic weights)
+# ---------------------------------------------------------------------------------------------
+def _lpips_model(seed=0):
+    from pnpflow_amd.lpips import LPIPS
+    sd = O.synthetic_lpips_state_dict(seed)
+    return LPIPS("alex").load_state_dict(sd), sd
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 128, 128), (2, 3, 256, 256), (2, 3, 64, 96)])
+def test_lpips_matches_oracle(hip, shape):
+    """csrc/lpips.hip (direct fp32 convs of the AlexNet feature stack, max-pools, unit-normalise / diff / 1x1 heads / spatial mean)
+    against the oracle's torch restatement of lpips.LPIPS(net='alex'), weights loaded under the published key names; with and
+    without the package's `normalize` (the reference passes normalize=True on [-1, 1] images, utils.py:703-708)."""
+    m, sd = _lpips_model()
+    a = det_image(shape, 91); b = (a + 0.15 * det_normal(shape, 92)).clamp(-1, 1)
+    for normalize in (True, False):
+        ref = O.lpips_forward(sd, a, b, normalize=normalize)
+        out = m(a.cuda(), b.cuda(), normalize=normalize).cpu()
+        assert float(ref.min()) > 1e-4
+        np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=2e-4, atol=1e-6, err_msg=f"normalize={normalize}")
+    assert float(m(a.cuda(), a.cuda(), normalize=True).abs().max()) == 0.0          # identical images: distance exactly 0
+
+
+def test_lpips_accepts_the_published_state_dict_layouts(hip):
+    """lpips.LPIPS(net='alex').state_dict() names (net.slice{j}.{N}.*, lin{k}.model.1.weight, lins.{k}..., scaling_layer.*) and the
+    two separate checkpoints (torchvision alexnet + lpips lin weights, DataParallel 'module.' prefix) give the same network."""
+    from pnpflow_amd.lpips import LPIPS
+    sd = O.synthetic_lpips_state_dict(3)
+    full = {}
+    for j, idx in enumerate((0, 3, 6, 8, 10)):
+        full[f"net.slice{j + 1}.{idx}.weight"] = sd[f"features.{idx}.weight"]; full[f"net.slice{j + 1}.{idx}.bias"] = sd[f"features.{idx}.bias"]
+        full[f"lin{j}.model.1.weight"] = sd[f"lin{j}.model.1.weight"]; full[f"lins.{j}.model.1.weight"] = sd[f"lin{j}.model.1.weight"]
+    full["scaling_layer.shift"] = torch.zeros(1, 3, 1, 1); full["scaling_layer.scale"] = torch.ones(1, 3, 1, 1)
+    a = det_image((2, 3, 64, 64), 93).cuda(); b = det_image((2, 3, 64, 64), 94).cuda()
+    d0 = LPIPS().load_state_dict(sd)(a, b, normalize=True)
+    d1 = LPIPS().load_state_dict(full)(a, b, normalize=True)
+    d2 = LPIPS().load_state_dict({"module." + k: v for k, v in sd.items()})(a, b, normalize=True)
+    assert torch.equal(d0, d1) and torch.equal(d0, d2)
+    with pytest.raises(KeyError):
+        LPIPS().load_state_dict({k: v for k, v in sd.items() if not k.startswith("lin4")})
+
+
+def test_solve_ip_writes_lpips_files(hip, tmp_path):
+    """The reference logs LPIPS next to PSNR / SSIM at its logging iterations (pnp_flow.py:128-139, utils.py:677-776): lpips_rec /
+    lpips_noisy per batch, the averages and final_lpips.txt - values equal the oracle's LPIPS of the logged iterates under the
+    reference's input convention (postprocess, 2x - 1, then normalize=True)."""
+    import pnpflow_amd.degradations as D
+    from pnpflow_amd import utils as U
+    from pnpflow_amd.methods.pnp_flow import PNP_FLOW
+    m, cfg, sd = model_for("tiny4")
+    lp, lsd = _lpips_model(1)
+    U.set_lpips_model(lp)
+    try:
+        save = str(tmp_path / "out"); os.makedirs(save)
+        args = U.CfgNode(dict(method="pnp_flow", model="ot", problem="inpainting", noise_type="gaussian", num_samples=2, steps_pnp=10, lr_pnp=1.0,
+                              gamma_style="alpha_1_minus_t", alpha=0.5, max_batch=1, compute_time=False, compute_memory=False, save_results=True,
+                              batch=0, save_path_ip=save, save_path=save, dict_cfg_method={"alpha": 0.5}))
+        clean = det_image((2, 3, 64, 64), 31)
+        solver = PNP_FLOW(m, torch.device("cuda"), args)
+        solver.solve_ip([(clean, torch.zeros(2))], D.BoxInpainting(10), 0.05)
+        lines = [l.split() for l in open(os.path.join(save, "lpips_rec_batch0.txt")).read().strip().splitlines()]
+        assert [int(l[0]) for l in lines] == list(range(10)) + [9]          # steps // 10 == 1: every iteration is a logging iteration, + the final line
+        x = solver.last_restored.cpu()
+        ref = float(O.lpips_forward(lsd, clean, x, normalize=True).mean())       # postprocess then 2x - 1 is the identity on the values
+        assert abs(float(lines[-1][1]) - ref) <= 2e-4 * max(ref, 1e-3)
+        assert os.path.isfile(os.path.join(save, "lpips_noisy_batch0.txt")) and os.path.isfile(os.path.join(save, "lpips_rec_average.txt"))
+        head = open(os.path.join(save, "final_lpips.txt")).read().splitlines()
+        assert head[0].split()[:2] == ["lpips_rec", "lpips_noisy"] and len(head) == 2
+    finally:
+        U.set_lpips_model(None); U._LPIPS["resolved"] = False

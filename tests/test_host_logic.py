@@ -385,3 +385,24 @@ def test_cv2_line_restatement_known_answers():
     for _ in range(60):          # product vs oracle restatement, incl. strokes that touch the border (clipLine path of the product)
         p0 = tuple(int(v) for v in rng.integers(8, 88, 2)); p1 = tuple(int(v) for v in rng.integers(8, 88, 2)); t = int(rng.integers(8, 16))
         np.testing.assert_array_equal(thick_line(np.zeros((96, 96), np.uint8), p0, p1, t), O.cv2_thick_line(np.zeros((96, 96), np.uint8), p0, p1, t))
+
+
+def test_lpips_oracle_properties_and_key_mapping():
+    """The oracle's LPIPS restatement (lpips.LPIPS(net='alex') forward): zero for identical inputs, symmetric, positive, and the
+    `normalize` flag is exactly the package's 2x - 1; the engine-side key mapping accepts the published checkpoint layouts."""
+    from oracle import pnpflow_oracle as O
+    from pnpflow_amd.lpips import canonical_state_dict
+    sd = O.synthetic_lpips_state_dict(0)
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1; b = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    d = O.lpips_forward(sd, a, b)
+    assert d.shape == (2,) and float(d.min()) > 0
+    assert float(O.lpips_forward(sd, a, a).abs().max()) == 0.0
+    np.testing.assert_allclose(O.lpips_forward(sd, b, a).numpy(), d.numpy(), rtol=1e-6)
+    np.testing.assert_allclose(O.lpips_forward(sd, (a + 1) / 2, (b + 1) / 2, normalize=True).numpy(), d.numpy(), rtol=1e-5)
+    full = {f"net.slice{j + 1}.{idx}.weight": sd[f"features.{idx}.weight"] for j, idx in enumerate((0, 3, 6, 8, 10))}
+    full.update({f"lins.{j}.model.1.weight": sd[f"lin{j}.model.1.weight"] for j in range(5)})
+    full["scaling_layer.shift"] = torch.zeros(1, 3, 1, 1)
+    can = canonical_state_dict(full)
+    assert sorted(can) == sorted([f"features.{i}.weight" for i in (0, 3, 6, 8, 10)] + [f"lin{k}" for k in range(5)])
+    assert can["lin2"].shape == (384,) and torch.equal(can["features.6.weight"], sd["features.6.weight"])

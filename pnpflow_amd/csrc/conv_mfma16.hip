@@ -540,11 +540,16 @@ static long wg_count16(const ConvParams& p, int TH, int BN) {
 template <int S, int UP, int KC, int TERMS>
 static hipError_t launch_sel16(const ConvParams& p, hipStream_t stream) {
     static const long MIN_WGS = getenv("PNPFLOW_HIP_MIN_WGS") ? atol(getenv("PNPFLOW_HIP_MIN_WGS")) : 512;
+    // A/B: smaller tiles (more workgroups per CU) on the HBM-latency-bound 32 / 64 channel levels
+    static const int tile_l0 = getenv("PNPFLOW_HIP_TILE_L0") ? atoi(getenv("PNPFLOW_HIP_TILE_L0")) : 16;
+    static const int tile_l1 = getenv("PNPFLOW_HIP_TILE_L1") ? atoi(getenv("PNPFLOW_HIP_TILE_L1")) : 16;
     if constexpr (S == 1) {
         if (p.Cout <= 32) {
+            if (tile_l0 == 8) return launch_cfg16<1, 1, 4, 1, S, UP, KC, TERMS>(p, stream);                                      // 8x16 px x 32
             return launch_cfg16<2, 1, 4, 1, S, UP, KC, TERMS>(p, stream);                                                        // 16x16 px x 32
         }
         if (p.Cout <= 64) {
+            if (tile_l1 == 8) return launch_cfg16<2, 1, 2, 2, S, UP, KC, TERMS>(p, stream);                                      // 8x16 px x 64
             if (wg_count16(p, 16, 64) >= MIN_WGS) return launch_cfg16<4, 1, 2, 2, S, UP, KC, TERMS>(p, stream);                  // 16x16 px x 64
             if (wg_count16(p, 8, 64) >= MIN_WGS) return launch_cfg16<2, 1, 2, 2, S, UP, KC, TERMS>(p, stream);                   // 8x16 px x 64
             return launch_cfg16<1, 1, 2, 2, S, UP, KC, TERMS>(p, stream);                                                        // 4x16 px x 64

@@ -1291,7 +1291,8 @@ def test_main_reads_checkpoint_file_and_dataset_tree(hip, tmp_path, dataset):
     # the same restoration from memory
     args = CfgNode(dict(method="pnp_flow", model="ot", problem=problem, noise_type="gaussian", num_samples=ns, steps_pnp=steps, lr_pnp=1.0,
                         gamma_style="alpha_1_minus_t", alpha=0.5, max_batch=nb,
-                        compute_time=False, compute_memory=False, save_results=True, batch=0, save_path_ip=str(tmp_path / "mem")))
+                        compute_time=False, compute_memory=False, save_results=True, batch=0, save_path_ip=str(tmp_path / "mem"),
+                        save_path=str(tmp_path / "mem"), dict_cfg_method={"alpha": 0.5}))
     os.makedirs(args.save_path_ip)
     tens = [torch.from_numpy(np.ascontiguousarray(prep(a).transpose(2, 0, 1))).float().div(255).sub(0.5).div(0.5) for a in test_arrays]
     loader = [(torch.stack(tens[i * bs:(i + 1) * bs]), torch.zeros(bs)) for i in range(nb)]

@@ -144,15 +144,24 @@ def cpu_baseline(wl, budget_s=20.0):
 
 FWD_FLOPS = {128: 49.78e9, 256: 189.44e9}      # algorithmic FLOP per image per U-Net forward
 
-def measured_traffic(workload):
-    """HBM bytes per conv-family launch of `workload`, measured with rocprofv3 --pmc in separate FETCH_SIZE / WRITE_SIZE passes
-    (FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950) by tools/pmc_traffic.sh, which writes profiles/traffic.json:
-    {workload: {"bytes_per_launch": ..., "launches": ..., "source": ..., "commit": ...}}.  The bench line carries what that
-    committed file holds (null when the workload has no entry) - never a constant of this script."""
+def measured_traffic(workload, kernel_class=None):
+    """HBM bytes per launch of the dominant conv kernel of `workload`, measured with rocprofv3 --pmc in separate FETCH_SIZE / WRITE_SIZE
+    passes (FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950) by tools/pmc_traffic.sh, which writes profiles/traffic.json:
+    {workload: {"bytes_per_launch": <conv family average>, "kernels": [{kernel, launches, read_mb_per_launch, write_mb_per_launch}], ...}}.
+    The bench line carries what that committed file holds (null when the workload has no entry) - never a constant of this script."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             rec = json.load(fh).get(workload)
-        return (float(rec["bytes_per_launch"]), rec.get("source")) if rec else (None, None)
+        if not rec:
+            return None, None
+        if kernel_class:
+            pat = kernel_class.split(" ")[0].replace("<", "<").split("<")
+            name, tile = pat[0], (pat[1].rstrip(">").split(",") if len(pat) > 1 else None)
+            for k in rec.get("kernels", []):
+                kn = k["kernel"].replace(" ", "")
+                if name in kn and (tile is None or ("<" + ",".join(tile) + ",") in kn):
+                    return (k["read_mb_per_launch"] + k["write_mb_per_launch"]) * 1e6, rec.get("source")
+        return float(rec["bytes_per_launch"]), rec.get("source")
     except Exception:           # noqa: BLE001
         return None, None
 
@@ -224,38 +233,63 @@ class Runner:
 
 
 def conv_roofline(r, precision, workload):
-    """Roofline of the dominant kernel family (split-fp16 implicit-GEMM conv on MFMA): HIP-event timing of every conv-GEMM
-    launch over a profiled slice of the SAME workload at the SAME U-Net batch (eager launches; graph replay hides the
-    per-kernel boundaries)."""
+    """Roofline of the conv family (every 3x3 / 1x1 conv of the U-Net), from HIP-event timing of every conv launch over a profiled
+    slice of the SAME workload at the SAME U-Net batch (eager launches; graph replay hides the per-kernel boundaries; a conv_dma
+    launch is timed together with its prep pass).  Two views:
+      * the DOMINANT kernel class by time decides `bound`: at 256^2 that is the 32-channel full-resolution level
+        (conv_mfma16_kernel<2,1,4,1,...>, ~1/3 of the step), whose floor is HBM - every operand tensor read once, the result written
+        once, the residual read once (`alg_mb` of the engine's per-launch CSV) against the 8 TB/s HBM3E peak;
+      * `mfma_family`: algorithmic FLOPs of ALL conv launches against the dense f16 MFMA peak (the round-1/2 figure)."""
+    import csv, tempfile
     model = r.model
     rep = r.unet_batch() // r.wl["B"]
     n_fw = 2 if rep > 1 else 4
     t_dev = torch.full((r.wl["B"] * rep,), 0.37, device=r.dev)
     zt = (r.clean + 0.1).repeat(rep, 1, 1, 1)
     model(zt, t_dev)                     # builds the plan outside the profiled slice
+    tmp = tempfile.NamedTemporaryFile(prefix="pf_layers_", suffix=".csv", delete=False); tmp.close()
+    os.environ["PNPFLOW_HIP_PROFILE_CSV"] = tmp.name
     model.profile(True)
     for _ in range(n_fw):
         model(zt, t_dev)
     launches, ms, flops = model.profile_read()
     model.profile(False)
+    os.environ.pop("PNPFLOW_HIP_PROFILE_CSV", None)
+    rows = list(csv.DictReader(open(tmp.name))); os.unlink(tmp.name)
     ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0      # ALGORITHMIC (fp32-equivalent) TFLOP/s of the conv-GEMM launches
-    traffic, src = measured_traffic(workload) if (precision == 1 and rep == 5) else (None, None)
-    if precision == 0:
-        peak = 157.3   # TFLOP/s, fp32 MFMA dense peak (MI355X_MICROARCH.md)
-        roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=None,
-                    kernel="conv_mfma_kernel (fp32 32x32x2 MFMA implicit GEMM)")
-    elif precision == 2:
-        peak = 2500.0  # TFLOP/s, f16 MFMA dense peak; one f16 MFMA product per algorithmic product
-        roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=None,
-                    kernel="conv_dma_kernel / conv_mfma16_kernel, TERMS = 1 (one f16 32x32x16 MFMA per product: fp16 operands, f32 accumulate, hi-only operand layouts)")
-    else:
-        peak = 2500.0  # TFLOP/s, f16 MFMA dense peak; every algorithmic product is executed as 3 f16 MFMA products
-        roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=traffic,
-                    traffic_source=src,
-                    kernel="conv family: conv_dma_kernel (LDS-DMA A operand from the prep_split pass, 128/256-channel levels; its prep pass is inside the timed launches) + conv_mfma16_kernel (register-staged, 32/64-channel levels) - f16 32x32x16 MFMA x3 split implicit GEMM; every 3x3/1x1 conv of the U-Net; the fused attention core is a separate launch and not in this family",
-                    mfma_tflops_executed=round(3 * ach, 2), frac_executed=round(3 * ach / peak, 4))
-    roof.update(launches=int(launches // n_fw), avg_launch_us=round(ms * 1e3 / max(1, launches), 2),
-                algorithmic_gflop_per_launch=round(flops / max(1, launches) / 1e9, 4), unet_batch=r.wl["B"] * rep)
+    # kernel classes: the launcher picks the tile by Cout (<= 32: <2,1,4,1>; <= 64: <4,1,2,2>; else <4,1,1,4> or conv_dma)
+    cls = {}
+    for w in rows:
+        key = "conv_dma_kernel (+ prep_split)" if int(w["dma"]) else ("conv_mfma16_kernel<2,1,4,1> (Cout 32)" if int(w["Cout"]) <= 32 else
+               "conv_mfma16_kernel<4,1,2,2> (Cout 64)" if int(w["Cout"]) <= 64 else "conv_mfma16_kernel<4,1,1,4> (Cout >= 128)")
+        c = cls.setdefault(key, dict(us=0.0, mb=0.0, n=0, gflop=0.0))
+        c["us"] += float(w["us"]); c["mb"] += float(w["alg_mb"]); c["n"] += 1; c["gflop"] += float(w["gflop"])
+    tot_us = sum(c["us"] for c in cls.values()) or 1.0
+    dom = max(cls, key=lambda k: cls[k]["us"])
+    d = cls[dom]
+    traffic, src = measured_traffic(workload, dom) if (precision == 1 and rep == 5) else (None, None)
+    dtype_peak = 157.3 if precision == 0 else 2500.0
+    fam = dict(bound="mfma", achieved=round(ach, 2), peak=dtype_peak, unit="TFLOP/s", frac=round(ach / dtype_peak, 4),
+               launches=int(launches // n_fw), avg_launch_us=round(ms * 1e3 / max(1, launches), 2),
+               algorithmic_gflop_per_launch=round(flops / max(1, launches) / 1e9, 4),
+               kernel="conv family: conv_dma_kernel (LDS-DMA A operand from the prep_split pass; selected where a prepped element feeds >= 2000 MACs) + conv_mfma16_kernel "
+                      "(register-staged) - f16 32x32x16 MFMA implicit GEMM, " + {0: "exact fp32 MFMA (conv_mfma_kernel)", 1: "3 MFMAs per product (fp32-equivalent split)", 2: "1 MFMA per product (hi-only operands)"}[precision])
+    if precision == 1:
+        fam.update(mfma_tflops_executed=round(3 * ach, 2), frac_executed=round(3 * ach / dtype_peak, 4))
+    gbs = d["mb"] * 1e6 / (d["us"] * 1e-6) / 1e9
+    tfl = d["gflop"] * 1e9 / (d["us"] * 1e-6) / 1e12
+    hbm_floor_us = d["mb"] * 1e6 / 8e12 * 1e6 / d["n"]
+    mfma_floor_us = (3 if precision == 1 else 1) * d["gflop"] * 1e9 / (dtype_peak * 1e12) * 1e6 / d["n"]
+    hbm_bound = hbm_floor_us >= mfma_floor_us
+    roof = dict(bound="hbm" if hbm_bound else "mfma",
+                achieved=round(gbs, 1) if hbm_bound else round(tfl, 2), peak=8000.0 if hbm_bound else dtype_peak,
+                unit="GB/s" if hbm_bound else "TFLOP/s", frac=round(gbs / 8000.0, 4) if hbm_bound else round(tfl / dtype_peak, 4),
+                traffic=traffic, traffic_source=src, kernel=dom, share_of_conv_time=round(d["us"] / tot_us, 4),
+                launches=d["n"] // n_fw, avg_launch_us=round(d["us"] / d["n"], 2), algorithmic_mb_per_launch=round(d["mb"] / d["n"], 2),
+                hbm_floor_us_at_8tbs=round(hbm_floor_us, 1), mfma_floor_us=round(mfma_floor_us, 1), unet_batch=r.wl["B"] * rep,
+                classes={k: dict(share=round(v["us"] / tot_us, 4), avg_us=round(v["us"] / v["n"], 1), algorithmic_gbs=round(v["mb"] * 1e6 / (v["us"] * 1e-6) / 1e9, 1),
+                                 algorithmic_tflops=round(v["gflop"] * 1e9 / (v["us"] * 1e-6) / 1e12, 1)) for k, v in cls.items()},
+                mfma_family=fam)
     return roof
 
 

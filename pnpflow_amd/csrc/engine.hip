@@ -1923,7 +1923,7 @@ int pf_engine_profile_read(pf_engine* e, int64_t* launches, double* ms_conv_gemm
     if (!e) return PF_ERR_INVALID;
     HIPCHK(e, hipDeviceSynchronize());
     FILE* dump = getenv("PNPFLOW_HIP_PROFILE_CSV") ? fopen(getenv("PNPFLOW_HIP_PROFILE_CSV"), "w") : nullptr;
-    if (dump) fprintf(dump, "idx,H,W,Cout,K,nseg,taps0,stride,up,gflop,us,tflops,wgs,cyc_prologue,cyc_staging,cyc_kloop,cyc_epilogue,cyc_stats\n");
+    if (dump) fprintf(dump, "idx,H,W,Cout,K,nseg,taps0,stride,up,gflop,us,tflops,dma,alg_mb,wgs,cyc_prologue,cyc_staging,cyc_kloop,cyc_epilogue,cyc_stats\n");
     std::vector<unsigned long long> tr;
     if (e->trace_buf) { tr.resize(pf_engine::TRACE_MAX * pf_engine::TRACE_SLOTS * 8); hipMemcpy(tr.data(), e->trace_buf, tr.size() * 8, hipMemcpyDeviceToHost); hipMemset(e->trace_buf, 0, tr.size() * 8); }
     for (size_t i = 0; i < e->ev_used; ++i) {
@@ -1932,8 +1932,11 @@ int pf_engine_profile_read(pf_engine* e, int64_t* launches, double* ms_conv_gemm
         if (dump && i < e->ev_ops.size() && e->ev_ops[i]) {
             const Op& op = *e->ev_ops[i]; size_t K = 0;
             for (int j = 0; j < op.cp.nseg; ++j) K += (size_t)op.cp.seg[j].taps * op.cp.seg[j].C;
-            fprintf(dump, "%zu,%d,%d,%d,%zu,%d,%d,%d,%d,%.4f,%.2f,%.2f", i, op.cp.H, op.cp.W, op.cp.Cout, K, op.cp.nseg, op.cp.seg[0].taps,
-                    op.stride, op.up, op.flops / 1e9, ms * 1e3, op.flops / (ms * 1e-3) / 1e12);
+            // algorithmic HBM bytes of the launch: every operand tensor read once, the result written once, the residual read once
+            double bytes = (double)op.cp.B * op.cp.H * op.cp.W * op.cp.Cout * 4.0 * (op.cp.residual ? 2.0 : 1.0);
+            for (int j = 0; j < op.cp.nseg; ++j) bytes += (double)op.cp.B * op.cp.Hs * op.cp.Ws * op.cp.seg[j].C * 4.0;
+            fprintf(dump, "%zu,%d,%d,%d,%zu,%d,%d,%d,%d,%.4f,%.2f,%.2f,%d,%.3f", i, op.cp.H, op.cp.W, op.cp.Cout, K, op.cp.nseg, op.cp.seg[0].taps,
+                    op.stride, op.up, op.flops / 1e9, ms * 1e3, op.flops / (ms * 1e-3) / 1e12, op.dma, bytes / 1e6);
             if (!tr.empty() && i < pf_engine::TRACE_MAX) {
                 unsigned long long q[8] = {0};
                 for (size_t sl = 0; sl < pf_engine::TRACE_SLOTS; ++sl) for (int k = 0; k < 8; ++k) q[k] += tr[(i * pf_engine::TRACE_SLOTS + sl) * 8 + k];

@@ -122,10 +122,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));       // (a nati
 struct BFrag { u32x4 h, l; };
 
 template <int TERMS>
-__device__ __forceinline__ void bload(BFrag& f, unsigned voff, const char* sbase) {
+__device__ __forceinline__ void bload(BFrag& f, unsigned voff, unsigned voff_lo, const char* sbase) {
     u32x4 h, l;      // (plain locals: an asm operand that is a member reached through a reference is an indirect operand)
     if constexpr (TERMS == 3) {
-        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:32" : "=&v"(h), "=&v"(l) : "v"(voff), "s"(sbase) : "memory");
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %4\n\tglobal_load_dwordx4 %1, %3, %4" : "=&v"(h), "=&v"(l) : "v"(voff), "v"(voff_lo), "s"(sbase) : "memory");
         f.h = h; f.l = l;
     } else {
         asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(h) : "v"(voff), "s"(sbase) : "memory");
@@ -214,9 +214,11 @@ __global__ __launch_bounds__(256, PF_DMA_LB) void conv_dma_kernel(const ConvPara
 
     // weight fragments: per-lane byte offset of this lane's output channel inside a [slice][tap] block, scalar base per step
     const int nclamp = min(n0 + wn * 32 + l31, p.Cout - 1);
-    constexpr int WROW = TERMS == 3 ? 64 : 32;           // bytes per output channel and k16-slice
-    const unsigned b_voff = (unsigned)(nclamp * WROW + hi * 16);
-    const size_t wblk = (size_t)p.Cout * WROW;           // bytes of one [slice][tap] block
+    // block (k16-slice, tap) = [hi halves: Cout x 32 B][lo halves: Cout x 32 B] (TERMS = 1: the hi part only): a wave's fragment load is one
+    // contiguous 1 KiB run
+    const unsigned b_voff = (unsigned)(nclamp * 32 + hi * 16);
+    const unsigned b_voff_lo = b_voff + (unsigned)p.Cout * 32u;
+    const size_t wblk = (size_t)p.Cout * (TERMS == 3 ? 64 : 32);           // bytes of one [slice][tap] block
     // first block of chunk (si, ch): fragment step (tap, j) of the chunk is block j * taps + tap behind it
     auto wchunk = [&](int wsi, int wch) -> const char* {
         const ConvSeg& sg = p.seg[wsi];
@@ -282,8 +284,8 @@ __global__ __launch_bounds__(256, PF_DMA_LB) void conv_dma_kernel(const ConvPara
             return wnext + (size_t)((s2 - NS) * ntaps) * wblk;
         };
         if constexpr (!CARRY) {
-            bload<TERMS>(f0, b_voff, wstep(0));
-            bload<TERMS>(f1, b_voff, wstep(1));
+            bload<TERMS>(f0, b_voff, b_voff_lo, wstep(0));
+            bload<TERMS>(f1, b_voff, b_voff_lo, wstep(1));
         }
         PF_WAITV(2 * NB);                                 // in-order return: everything older than B0 / B1 - this chunk's patch - has landed
         __builtin_amdgcn_s_barrier();                     // raw barrier (no vmcnt(0) drain); every wave has finished reading the other buffer
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(256, PF_DMA_LB) void conv_dma_kernel(const ConvPara
 #define PF_STEP(S, FC, FN, ACUR_H, ACUR_L, ANXT_H, ANXT_L)                                                                     \
         if constexpr ((S) < NS) {                                                                                              \
             constexpr bool REQ_ = CARRY || (S) + 2 < NS;                                                                       \
-            if constexpr (REQ_) bload<TERMS>(FN, b_voff, wstep((S) + 2));                                                      \
+            if constexpr (REQ_) bload<TERMS>(FN, b_voff, b_voff_lo, wstep((S) + 2));                                                      \
             constexpr int W_ = REQ_ ? ((S) < 2 ? 2 * NB + IPW : 2 * NB) : ((S) + 1 < NS ? ((S) < 2 ? NB + IPW : NB) : ((S) < 2 ? IPW : 0)); \
             bwait<TERMS, W_>(FC);                                                                                              \
             if constexpr ((S) + 1 < NS) load_a(lbc, PF_KY((S) + 1), PF_KX((S) + 1), ((S) + 1) % KS, ANXT_H, ANXT_L);            \
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(256, PF_DMA_LB) void conv_dma_kernel(const ConvPara
 #define PF_STEP(S, FC, FN)                                                                                                     \
         if constexpr ((S) < NS) {                                                                                              \
             constexpr bool REQ_ = CARRY || (S) + 2 < NS;                                                                       \
-            if constexpr (REQ_) bload<TERMS>(FN, b_voff, wstep((S) + 2));                                                      \
+            if constexpr (REQ_) bload<TERMS>(FN, b_voff, b_voff_lo, wstep((S) + 2));                                                      \
             constexpr int W_ = REQ_ ? ((S) < 2 ? 2 * NB + IPW : 2 * NB) : ((S) + 1 < NS ? ((S) < 2 ? NB + IPW : NB) : ((S) < 2 ? IPW : 0)); \
             bwait<TERMS, W_>(FC);                                                                                              \
             f16x8 ah_[MT], al_[MT];                                                                                            \
@@ -351,8 +353,8 @@ __global__ __launch_bounds__(256, PF_DMA_LB) void conv_dma_kernel(const ConvPara
     constexpr bool CARRY9 = PF_DMA_CARRY != 0;
     if (CARRY9 && p.seg[0].taps == 9) {
         const char* w0 = wchunk(0, 0);
-        bload<TERMS>(f0, b_voff, w0);
-        bload<TERMS>(f1, b_voff, w0 + (size_t)9 * wblk);      // step 1 = (tap 0, slice 1)
+        bload<TERMS>(f0, b_voff, b_voff_lo, w0);
+        bload<TERMS>(f1, b_voff, b_voff_lo, w0 + (size_t)9 * wblk);      // step 1 = (tap 0, slice 1)
     }
     // 9-tap segments first (conv_dma_supported orders them so), then the 1-tap ones: two loops, one body each
     while (more && p.seg[si].taps == 9) {

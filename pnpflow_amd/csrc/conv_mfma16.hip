@@ -9,7 +9,7 @@
 //   * activations: split after GroupNorm/SiLU while staging; LDS row of a pixel =
 //     [KC hi halfs | KC lo halfs | pad] = KC+4 dwords (the same conflict-free stride as the fp32 patch);
 //   * weights: split on the host after an exact 2^8 pre-scale (keeps w_lo a normal fp16 number; the
-//     epilogue multiplies by 2^-8), packed [k16-step][Cout][16 hi | 16 lo] so that the B fragments of a
+//     epilogue multiplies by 2^-8), packed [k16-step][hi | lo][Cout][16] so that each B fragment load of a
 //     wave (32 channels x 16 k, hi and lo) are one contiguous 2 KiB run, and read straight from L1/L2
 //     into a register ring two steps ahead of their use (as in conv_mfma.hip).  At this MFMA rate the
 //     weight stream is 16/3 x denser per matrix-pipe cycle than in the fp32 kernel, so the tile shapes
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16
         const size_t kidx = ((size_t)ch * KS + j) * sg.taps + tap;     // global 16-channel slice index x taps + tap
         const uint4* wp = reinterpret_cast<const uint4*>(sg.w16) + kidx * ((size_t)p.Cout * 4) + hi;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { dh[nt] = wp[(size_t)nclamp[nt] * 4]; if constexpr (TERMS == 3) dl[nt] = wp[(size_t)nclamp[nt] * 4 + 2]; else dl[nt] = dh[nt]; }
+        for (int nt = 0; nt < NT; ++nt) { dh[nt] = wp[(size_t)nclamp[nt] * 2]; if constexpr (TERMS == 3) dl[nt] = wp[(size_t)p.Cout * 2 + (size_t)nclamp[nt] * 2]; else dl[nt] = dh[nt]; }
     };
 
     int si = 0, ch = 0;

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvParams p, con
         const size_t kidx = ((size_t)ch * KS + j) * sg.taps + tap;
         const uint4* wp = reinterpret_cast<const uint4*>(sg.w16) + kidx * ((size_t)p.Cout * 4) + hi;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) { dh[nt] = wp[(size_t)nc[nt] * 4]; dl[nt] = wp[(size_t)nc[nt] * 4 + 2]; }
+        for (int nt = 0; nt < NT; ++nt) { dh[nt] = wp[(size_t)nc[nt] * 2]; dl[nt] = wp[(size_t)p.Cout * 2 + (size_t)nc[nt] * 2]; }      // [hi | lo][Cout][16] blocks (round 3 repack)
     };
     // B register ring: RD - 1 k-steps ahead of use.  4 x 2 accumulator tiles leave room for a 2-deep ring only (one k-step
     // there is 24 MFMAs = 768 matrix-pipe cycles, longer than an L2 round trip)

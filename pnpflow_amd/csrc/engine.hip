@@ -340,7 +340,7 @@ static float* packed_conv(pf_engine* e, const std::string& wname, int lo, int hi
     return upload(e, key, out);
 }
 
-// split-fp16 repack of the same slice: [chunk][tap][Cout][16 hi | 16 lo] halfs, values pre-scaled by 2^8
+// split-fp16 repack of the same slice: [chunk][tap][hi | lo][Cout][16] halfs, values pre-scaled by 2^8
 static const void* packed_conv16(pf_engine* e, const std::string& wname, int lo, int hi) {
     const std::string key = wname + "#h" + std::to_string(lo) + ":" + std::to_string(hi);
     auto it = e->dev.find(key);
@@ -358,8 +358,12 @@ static const void* packed_conv16(pf_engine* e, const std::string& wname, int lo,
                     const float w = t.data[((size_t)n * I + lo + c) * kk + tap] * 256.0f;
                     const _Float16 h = (_Float16)w;
                     const _Float16 l = (_Float16)(w - (float)h);
-                    const size_t row = (((size_t)chn * kk + tap) * O + n) * 32;
-                    out[row + k] = h; out[row + 16 + k] = l;
+                    // block (16-channel slice, tap) = [hi halves: Cout x 16][lo halves: Cout x 16]: the hi (lo) fragment load of a wave
+                    // (32 output channels x 32 B) is ONE contiguous 1 KiB run - with hi and lo interleaved per output channel every
+                    // fragment load touched 2 KiB of half-used lines (round 3: the texture addresser is the busiest unit of the
+                    // 32-channel level, profiles/r03_pmc_level0_counters.md)
+                    const size_t blk = ((size_t)chn * kk + tap) * O * 32;
+                    out[blk + (size_t)n * 16 + k] = h; out[blk + (size_t)O * 16 + (size_t)n * 16 + k] = l;
                 }
     std::vector<float> raw(out.size() / 2);
     memcpy(raw.data(), out.data(), out.size() * sizeof(_Float16));

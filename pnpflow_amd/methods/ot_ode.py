@@ -69,7 +69,9 @@ class OT_ODE(object):
         if hasattr(self.model, "set_solver_time_scale"):
             self.model.set_solver_time_scale(999.0 if args.model == "rectified" else 1.0)       # model_fn(x, t * 999), ot_ode.py:21-25
         if problem not in ("denoising", "inpainting", "random_inpainting", "paintbrush_inpainting", "superresolution", "gaussian_deblurring_FFT"):
-            # any other problem name: the reference's generic branch, a per-image GMRES on r_t^2 H H^T + sigma^2 I (ot_ode.py:118-128).
+            # OUT OF THE SURVEY 8 HOT-PATH SCOPE (unreachable for the five problems of main.py's table; kept from round 2,
+            # host-orchestrated, golden-pinned, not part of any coverage claim): any other problem name takes the reference's generic
+            # branch, a per-image GMRES on r_t^2 H H^T + sigma^2 I (ot_ode.py:118-128).
             # No entry of main.py's problem table reaches it; it runs as a host-orchestrated loop (not the device loop below).
             return self._restore_batch_generic(noisy_img, degradation, sigma_noise, iter_cb, cb_iterations)
         steps, delta = int(args.steps_ode), 1 / args.steps_ode

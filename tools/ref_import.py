@@ -1,7 +1,7 @@
 """Import the *real* reference (read-only at /root/reference) in the build container.
 
-Only used by tools/make_golden.py and tools/check_oracle_vs_reference.py, i.e. to
-generate golden vectors and to validate oracle/ here.  Nothing under tests/ (gpu or
+Only used by tools/make_golden.py, i.e. to generate the golden vectors under tests/golden/
+(tests/test_oracle_golden.py then validates oracle/ against them).  Nothing under tests/ (gpu or
 not), bench.py or __graft_entry__.py imports this: /root/reference does not exist on
 the GPU box.
 

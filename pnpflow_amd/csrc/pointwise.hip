@@ -2,6 +2,7 @@
 // operators (NCHW fp32 images).  Reference: pnpflow/methods/pnp_flow.py:39-52,109-121,
 // pnpflow/degradations.py:15-127, pnpflow/utils.py:283-361, 560-611.
 #include <algorithm>
+#include <cstdlib>
 #include "pf_common.h"
 
 namespace pf {
@@ -243,9 +244,97 @@ static inline dim3 grid_for(int n_per_image, int B) {
     return dim3(gx, B);
 }
 
+// One pass per application of the separable circular filter (round 3): a workgroup stages the (TS + 2r)^2 neighbourhood of a TS x TS output
+// tile once (wrap resolved while staging), filters it along x into a second LDS array and along y into the outputs.  Against the
+// row pass + column pass pair this halves the HBM traffic of an application (no intermediate tensor) and the launches; the halo
+// re-reads (2.1x at r = 7, TS = 32) are L2 hits.  Odd tap counts with 2r < min(H, W) and r <= 24 only (the Gaussian's visible taps: 15
+// at sigma 1, 43 at sigma 3); anything else keeps the two-pass path.  mode / sign as above; the taps are flipped once for the
+// convolution so that both directions are the correlation  out[i] = sum_k g'[k] in[i - r + k].
+template <int TS>
+__global__ __launch_bounds__(256) void blur2d_fused_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ taps,
+                                                          int ntaps, int H, int W, int sign, int mode,
+                                                          const float* __restrict__ aux, const float* __restrict__ coef, int planes_per_image) {
+    extern __shared__ float s_f[];
+    const int r = ntaps / 2, PW = TS + 2 * r, PWP = PW + 1;        // +1: row pitch off the bank period
+    float* s_in = s_f;                         // [PW][PWP]
+    float* s_h = s_in + PW * PWP + 4;          // [PW + 3][TS + 1]   (filtered along x; the sliding windows read up to 3 elements / rows past the last tap)
+    float* s_g = s_h + (PW + 3) * (TS + 1);
+    const int tid = threadIdx.x;
+    for (int k = tid; k < ntaps; k += 256) s_g[k] = taps[sign > 0 ? ntaps - 1 - k : k];
+    const int plane = blockIdx.z, x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+    const float* src = in + (size_t)plane * H * W;
+    for (int i = tid; i < PW * PW; i += 256) {
+        const int py = i / PW, px = i - py * PW;
+        int gy = y0 - r + py, gx = x0 - r + px;
+        gy += gy < 0 ? H : 0; gy -= gy >= H ? H : 0; gy -= gy >= H ? H : 0;      // (a tile past the image edge wraps twice at most: TS + r < 2H)
+        gx += gx < 0 ? W : 0; gx -= gx >= W ? W : 0; gx -= gx >= W ? W : 0;
+        s_in[py * PWP + px] = src[(size_t)gy * W + gx];
+    }
+    __syncthreads();
+    // four consecutive outputs per thread with a sliding window: one LDS read per tap feeds four multiply-adds
+    for (int i = tid; i < PW * (TS / 4); i += 256) {
+        const int py = i / (TS / 4), x = (i - py * (TS / 4)) * 4;
+        const float* row = s_in + py * PWP + x;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        float w0 = row[0], w1 = row[1], w2 = row[2];
+        for (int k = 0; k < ntaps; ++k) {
+            const float w3 = row[k + 3], gk = s_g[k];
+            a0 = fmaf(gk, w0, a0); a1 = fmaf(gk, w1, a1); a2 = fmaf(gk, w2, a2); a3 = fmaf(gk, w3, a3);
+            w0 = w1; w1 = w2; w2 = w3;
+        }
+        float* hp = s_h + py * (TS + 1) + x;
+        hp[0] = a0; hp[1] = a1; hp[2] = a2; hp[3] = a3;
+    }
+    __syncthreads();
+    const int b = plane / planes_per_image;
+    for (int i = tid; i < (TS / 4) * TS; i += 256) {
+        const int yq = i / TS, x = i - yq * TS, y = yq * 4;
+        const float* col = s_h + y * (TS + 1) + x;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        float w0 = col[0], w1 = col[TS + 1], w2 = col[2 * (TS + 1)];
+        for (int k = 0; k < ntaps; ++k) {
+            const float w3 = col[(k + 3) * (TS + 1)], gk = s_g[k];
+            a[0] = fmaf(gk, w0, a[0]); a[1] = fmaf(gk, w1, a[1]); a[2] = fmaf(gk, w2, a[2]); a[3] = fmaf(gk, w3, a[3]);
+            w0 = w1; w1 = w2; w2 = w3;
+        }
+        if (x0 + x >= W) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (y0 + y + j >= H) break;
+            float v = a[j];
+            const size_t o = ((size_t)plane * H + y0 + y + j) * W + x0 + x;
+            if (mode == 1) v = v - aux[o];
+            else if (mode == 2) v = aux[o] - coef[b] * v;
+            else if (mode == 3) v = (v - aux[o]) > 0.f ? 1.f : -1.f;
+            out[o] = v;
+        }
+    }
+}
+
 static hipError_t blur2(const DegView& d, const float* in, float* tmp, float* out, int B, int C, int H, int W, int sign,
                         int mode, const float* aux, const float* coef, hipStream_t s) {
     if (W + d.ntaps > BL_MAXW || H + d.ntaps > BL_MAXW) return hipErrorInvalidValue;
+    static const bool fused_env = !(getenv("PNPFLOW_HIP_BLUR_FUSED") && atoi(getenv("PNPFLOW_HIP_BLUR_FUSED")) == 0);
+    if (fused_env && (d.ntaps & 1) && d.ntaps / 2 <= 24 && d.ntaps < H && d.ntaps < W && in != out &&
+        (d.ntaps / 2 <= 8 ? 32 : 64) + d.ntaps / 2 <= 2 * std::min(H, W)) {      // (the staging loop resolves at most two wraps)
+        const int r = d.ntaps / 2;
+        if (r <= 8) {
+            constexpr int TS = 32;
+            const int PW = TS + 2 * r;
+            const size_t lds = ((size_t)PW * (PW + 1) + 4 + (size_t)(PW + 3) * (TS + 1) + 128) * sizeof(float);
+            hipLaunchKernelGGL(blur2d_fused_kernel<TS>, dim3((W + TS - 1) / TS, (H + TS - 1) / TS, B * C), dim3(256), lds, s, in, out, d.taps, d.ntaps, H, W, sign, mode,
+                               aux, coef, C);
+        } else {
+            constexpr int TS = 64;
+            const int PW = TS + 2 * r;
+            const size_t lds = ((size_t)PW * (PW + 1) + 4 + (size_t)(PW + 3) * (TS + 1) + 128) * sizeof(float);
+            static unsigned long long attr64 = 0ull;
+            { hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(blur2d_fused_kernel<TS>), attr64, 160 * 1024); if (e != hipSuccess) return e; }
+            hipLaunchKernelGGL(blur2d_fused_kernel<TS>, dim3((W + TS - 1) / TS, (H + TS - 1) / TS, B * C), dim3(256), lds, s, in, out, d.taps, d.ntaps, H, W, sign, mode,
+                               aux, coef, C);
+        }
+        return hipGetLastError();
+    }
     const int r = d.ntaps / 2;
     // rows: 64-wide row groups, 256 threads per workgroup
     const int tx = 64, ty = 4, rows = B * C * H;

@@ -257,6 +257,12 @@ def compute_average_lpips(args):
     return _average_metric(args, 'lpips')
 
 
+PARITY_UNPINNED = {
+    'ssim': "ignite.metrics.SSIM restated from its published algorithm (ignite is not installed in the build image); checked against this repo's own oracle only",
+    'lpips': "lpips.LPIPS(net='alex') restated from the lpips / torchvision definitions (neither package installed in the build image); checked against this repo's own oracle only",
+}
+
+
 def _average_metric(args, name):
     """reference utils.py:628-674 (psnr) / 819-863 (ssim): per-iteration mean over the batches, then the last value into
     final_{name}.txt next to the method's hyper-parameters."""
@@ -281,6 +287,14 @@ def _average_metric(args, name):
         if os.stat(path).st_size == 0:
             f.write(f'{name}_rec {name}_noisy ' + ''.join(f'{k} ' for k in args.dict_cfg_method.keys()) + '\n')
         f.write(f"{final['rec']} {final['noisy']} " + ''.join(f'{v} ' for v in args.dict_cfg_method.values()) + '\n')
+    if name in PARITY_UNPINNED:
+        # the result files keep the reference's exact format (scripts parse them); what is a restatement of an absent third-party
+        # implementation is said in a sidecar next to them
+        note = os.path.join(args.save_path, 'PARITY_UNPINNED.txt')
+        line = f'final_{name}.txt, {name}_*: {PARITY_UNPINNED[name]}\n'
+        if not os.path.isfile(note) or line not in open(note).read():
+            with open(note, 'a') as f:
+                f.write(line)
     return final
 
 

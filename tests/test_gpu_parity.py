@@ -1409,5 +1409,7 @@ def test_solve_ip_writes_lpips_files(hip, tmp_path):
         assert os.path.isfile(os.path.join(save, "lpips_noisy_batch0.txt")) and os.path.isfile(os.path.join(save, "lpips_rec_average.txt"))
         head = open(os.path.join(save, "final_lpips.txt")).read().splitlines()
         assert head[0].split()[:2] == ["lpips_rec", "lpips_noisy"] and len(head) == 2
+        note = open(os.path.join(save, "PARITY_UNPINNED.txt")).read()          # SSIM / LPIPS are restatements of absent packages: said next to the files
+        assert "final_ssim.txt" in note and "final_lpips.txt" in note
     finally:
         U.set_lpips_model(None); U._LPIPS["resolved"] = False

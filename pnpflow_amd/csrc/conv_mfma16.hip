@@ -546,6 +546,7 @@ static hipError_t launch_sel16(const ConvParams& p, hipStream_t stream) {
     if constexpr (S == 1) {
         if (p.Cout <= 32) {
             if (tile_l0 == 8) return launch_cfg16<1, 1, 4, 1, S, UP, KC, TERMS>(p, stream);                                      // 8x16 px x 32
+            if (tile_l0 == 32) return launch_cfg16<4, 1, 4, 1, S, UP, KC, TERMS>(p, stream);                                     // 32x16 px x 32 (half the weight loads per pixel)
             return launch_cfg16<2, 1, 4, 1, S, UP, KC, TERMS>(p, stream);                                                        // 16x16 px x 32
         }
         if (p.Cout <= 64) {

@@ -1413,3 +1413,41 @@ def test_solve_ip_writes_lpips_files(hip, tmp_path):
         assert "final_ssim.txt" in note and "final_lpips.txt" in note
     finally:
         U.set_lpips_model(None); U._LPIPS["resolved"] = False
+
+
+# ---------------------------------------------------------------------------------------------
+# round 3: the LDS-DMA conv path (conv_dma.hip) is what runs at the solver's U-Net batch, and it is bit-identical to the register-staged kernel
+# ---------------------------------------------------------------------------------------------
+def test_conv_dma_path_is_selected_at_the_solver_batch_and_bit_identical(hip, tmp_path):
+    """At the C2 U-Net batch (160 x 128^2) the launcher sends the 16^2 x 256 3x3 convs, the upsampling convs and the stacked q,k,v
+    1x1 convs through prep_split + conv_dma (the engine's per-launch CSV says which); the forward equals, bit for bit, the one with
+    PNPFLOW_HIP_DMA=0 (every launch on conv_mfma16_kernel) - same products, same accumulation order - and in precision mode 2
+    (hi-only operand records and weights) the two agree to the mode's own rounding."""
+    import csv, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for prec in (1, 2):
+        for dma in ("0", "1"):
+            env = dict(os.environ, PNPFLOW_HIP_DMA=dma)
+            f = str(tmp_path / f"v_p{prec}_d{dma}.npy")
+            r = subprocess.run([sys.executable, "tools/gpu_dma_check.py", "run", "celeba128", "160", str(prec), f], cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs[(prec, dma)] = np.load(f)
+    assert np.array_equal(outs[(1, "0")], outs[(1, "1")])
+    ref = np.abs(outs[(2, "0")]).max()
+    assert np.abs(outs[(2, "0")] - outs[(2, "1")]).max() <= 5e-3 * ref
+    # which launches took the new path (this process: default selection)
+    m, cfg, sd = model_for("celeba128")
+    x = det_normal((160, 3, 128, 128), 5).cuda(); t = torch.full((160,), 0.3).cuda()
+    m(x, t)
+    path = str(tmp_path / "layers.csv")
+    os.environ["PNPFLOW_HIP_PROFILE_CSV"] = path
+    try:
+        m.profile(True); m(x, t); m.profile_read(); m.profile(False)
+    finally:
+        os.environ.pop("PNPFLOW_HIP_PROFILE_CSV", None)
+    rows = list(csv.DictReader(open(path)))
+    dma_rows = [r for r in rows if int(r["dma"])]
+    assert len(rows) == 142 and 30 <= len(dma_rows) <= 80, (len(rows), len(dma_rows))
+    assert all(int(r["Cout"]) % 128 == 0 for r in dma_rows)
+    assert any(int(r["up"]) == 1 for r in dma_rows) and any(int(r["taps0"]) == 1 and int(r["Cout"]) == 768 for r in dma_rows)

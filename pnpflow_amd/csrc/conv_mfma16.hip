@@ -33,7 +33,11 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // v_exp_f32 / v_rcp_f32 (1 ulp each); __frcp_rn would be a correctly rounded division: 10 instructions per element
+#ifdef PF_AB_NOSILU        // timing-only A/B build (wrong results): what the two quarter-rate transcendentals of the staging cost
+__device__ __forceinline__ float silu_fast16(float x) { return x; }
+#else
 __device__ __forceinline__ float silu_fast16(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+#endif
 
 // A/B switches of the profiling builds (tools/ab_variants.sh): PF_AB_GN_INKERNEL re-derives the GroupNorm coefficients in every
 // workgroup's prologue as round 1 did; PF_AB_NO_RESCALE drops the per-segment accumulator rescale and the register bound it needs
@@ -138,15 +142,21 @@ __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16
                 const int a_p = (tid + i * 256) / KQ;
                 const int a_lds = (a_p / PW) * RS + (a_p % PW) * ROW + qi * 2;      // dword offset of this thread's 4 hi halfs (lo at +KH)
                 float4 v = ra[i];
+#ifdef PF_AB_RAWSTAGE      // timing-only A/B build (wrong results): no GroupNorm / SiLU / scale / zero-select in the staging
+                if (false) {
+#else
                 if (sg.xform != 0) {
+#endif
                     v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
                     v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
                     if (sg.xform == 2) {
                         v.x = silu_fast16(v.x); v.y = silu_fast16(v.y); v.z = silu_fast16(v.z); v.w = silu_fast16(v.w);
                     }
                 }
+#ifndef PF_AB_RAWSTAGE
                 v.x *= a_scale; v.y *= a_scale; v.z *= a_scale; v.w *= a_scale;
                 if (!(cok && a_pix[i] >= 0)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
                 // opaque to the optimiser: the hi that is stored and the hi that is subtracted must be the SAME rounding of
                 // the SAME fp32 value.  With -ffp-contract=fast hipcc may otherwise fuse the producing multiply into the
                 // subtraction (v_fma_mix*) while the stored hi comes from the rounded product - they differ at double-rounding

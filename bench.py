@@ -232,6 +232,9 @@ class Runner:
         return self.wl["B"] * (self.wl["ns"] if getattr(self.solver, "batch_samples", False) else 1)
 
 
+STREAM_CEILING_GBS = 5500.0      # measured, not a spec figure: see roofline.streaming_ceiling_source
+
+
 def conv_roofline(r, precision, workload):
     """Roofline of the conv family (every 3x3 / 1x1 conv of the U-Net), from HIP-event timing of every conv launch over a profiled
     slice of the SAME workload at the SAME U-Net batch (eager launches; graph replay hides the per-kernel boundaries; a conv_dma
@@ -287,6 +290,9 @@ def conv_roofline(r, precision, workload):
                 traffic=traffic, traffic_source=src, kernel=dom, share_of_conv_time=round(d["us"] / tot_us, 4),
                 launches=d["n"] // n_fw, avg_launch_us=round(d["us"] / d["n"], 2), algorithmic_mb_per_launch=round(d["mb"] / d["n"], 2),
                 hbm_floor_us_at_8tbs=round(hbm_floor_us, 1), mfma_floor_us=round(mfma_floor_us, 1), unet_batch=r.wl["B"] * rep,
+                # what a pure streaming kernel reaches on tensors of this size with the same read / write mix (tools/ubench/stream_mix.hip)
+                streaming_ceiling_gbs=STREAM_CEILING_GBS, frac_of_streaming_ceiling=round(gbs / STREAM_CEILING_GBS, 4) if hbm_bound else None,
+                streaming_ceiling_source="profiles/r03_level0_bound_ab.md section 1: 5.2-5.8 TB/s for 1R+1W ... 3R+1W on 268 MB / 1.34 GB tensors",
                 classes={k: dict(share=round(v["us"] / tot_us, 4), avg_us=round(v["us"] / v["n"], 1), algorithmic_gbs=round(v["mb"] * 1e6 / (v["us"] * 1e-6) / 1e9, 1),
                                  algorithmic_tflops=round(v["gflop"] * 1e9 / (v["us"] * 1e-6) / 1e12, 1)) for k, v in cls.items()},
                 mfma_family=fam)

@@ -248,6 +248,7 @@ class OT_ODE(object):
                 torch.cuda.synchronize()
                 utils.save_time_use({"batch": batch, "time_per_batch": perf_counter() - t0 - self.last_callback_seconds}, self.args)
             if self.args.save_results:
+                utils.save_images(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter='final')
                 utils.compute_psnr(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=int(steps) - 1)
                 utils.compute_ssim(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=int(steps) - 1)
                 utils.compute_lpips(clean_img, noisy_img, x.detach().clone(), self.args, H_adj, iter=int(steps) - 1)

@@ -201,6 +201,83 @@ def compute_ssim(clean_img, noisy_img, rec_img, args, H_adj, iter='final'):
     return ssim_rec, ssim_noisy
 
 
+# ---- image grids (reference utils.py:433-538) ---------------------------------------------------------------------------------
+_WARNED = set()
+
+
+def _imshow_grid(path, imgs: np.ndarray, gray: bool):
+    """One figure with every image of the batch, laid out as the reference lays it out: 1 image -> a plain figure, 2 -> one row,
+    otherwise int(sqrt(B)) columns x int(B / cols) rows on a 20 x 20 inch canvas, image k = i + j * rows at axes (i, j), ticks off.
+    Drawn with matplotlib's object API on an Agg canvas (the process-wide pyplot state and backend are left alone)."""
+    from matplotlib.backends.backend_agg import FigureCanvasAgg
+    from matplotlib.figure import Figure
+    B = imgs.shape[0]
+    show = lambda ax, im: ax.imshow(im[..., 0], cmap='gray', vmin=0, vmax=1) if gray else ax.imshow(im)
+    if B == 1:
+        fig = Figure(); FigureCanvasAgg(fig)
+        show(fig.add_subplot(111), imgs[0])
+    elif B == 2:
+        fig = Figure(); FigureCanvasAgg(fig)
+        axes = fig.subplots(1, 2)
+        for k in range(2):
+            show(axes[k], imgs[k]); axes[k].set_xticks([]); axes[k].set_yticks([])
+    else:
+        cols = int(np.sqrt(B)); rows = int(B / cols)
+        fig = Figure(figsize=(20, 20)); FigureCanvasAgg(fig)
+        axes = fig.subplots(rows, cols, squeeze=False)     # (the reference indexes a squeezed array: it raises for B = 3)
+        for i in range(rows):
+            for j in range(cols):
+                show(axes[i, j], imgs[i + j * rows]); axes[i, j].set_xticks([]); axes[i, j].set_yticks([])
+    fig.savefig(path)
+
+
+def save_images(clean_img, noisy_img, rec_img, args, H_adj, iter='final'):
+    """Image files of one batch (reference utils.py:433-538, called with iter='final' from pnp_flow.py:156 / ot_ode.py:182):
+      iter != 'final':  {problem}_{method}_batch{b}_iter{iter}.png          grid of the restored images
+      iter == 'final':  {problem}_{clean|noisy|<method>}_batch{b}_final.png  one grid each
+      eval_split == 'test' and batch < 4: one .eps per image (clean / measurement / restored), the PSNR of the image in the file name.
+    Everything goes through postprocess (no clamp; imshow clips to [0, 1]).  With several ranks the shards are gathered in image
+    order (every rank must call this) and rank 0 draws.  Needs matplotlib, as the reference does; without it a warning is printed once
+    and nothing is written."""
+    from . import parallel
+    dev = rec_img.device
+    noisy_dev = noisy_img.to(dev)
+    tensors = (clean_img.to(dev), noisy_dev, rec_img, H_adj(torch.ones_like(noisy_dev)))
+    full = [parallel.gather_in_image_order(postprocess(t.detach().float()).contiguous().reshape(-1)).reshape((-1,) + tuple(t.shape[1:])) for t in tensors]
+    if not _is_writer() or full[0].shape[0] == 0:
+        return
+    try:
+        import matplotlib  # noqa: F401
+    except ImportError:
+        if 'matplotlib' not in _WARNED:
+            _WARNED.add('matplotlib'); print('save_images: matplotlib is not installed - no image files are written')
+        return
+    from matplotlib.backends.backend_agg import FigureCanvasAgg
+    from matplotlib.figure import Figure
+    clean, noisy, rec, hadj_ones = (t.permute(0, 2, 3, 1).cpu().numpy() for t in full)
+    gray = int(getattr(args, 'num_channels', clean.shape[-1])) == 1
+    words = ['clean', 'noisy', args.method]
+    if iter != 'final':
+        _imshow_grid(os.path.join(args.save_path_ip, f"{args.problem}_{args.method}_batch{args.batch}_iter{iter}.png"), rec, gray)
+    else:
+        for word, imgs in zip(words, (clean, noisy, rec)):
+            _imshow_grid(os.path.join(args.save_path_ip, f"{args.problem}_{word}_batch{args.batch}_final.png"), imgs, gray)
+    if getattr(args, 'eval_split', None) == 'test' and ((args.batch < 8 and args.method == 'd_flow') or args.batch < 4):
+        psnr = lambda a, b: float(10.0 * np.log10(1.0 / np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))   # skimage's, data_range 1
+        for i in range(clean.shape[0]):
+            measured = hadj_ones[i] if args.problem in ('superresolution', 'superresolution_bicubic') else noisy[i]   # (sic: H_adj of ones, utils.py:436,509-511)
+            p_noisy, p_rec = psnr(clean[i], measured), psnr(clean[i], rec[i])
+            stem = os.path.join(args.save_path_ip, f"{args.problem}_")
+            targets = []
+            if args.method == 'pnp_flow':
+                targets += [(clean[i], f"{stem}clean_batch{args.batch}_im{i}.eps"), (noisy[i], f"{stem}noisy_batch{args.batch}_im{i}_pnsr{p_noisy:4.2f}.eps")]
+            targets.append((rec[i], f"{stem}{args.method}_batch{args.batch}_im{i}_iter{iter}_pnsr{p_rec:4.2f}.eps"))
+            for im, path in targets:
+                fig = Figure(); FigureCanvasAgg(fig)
+                ax = fig.add_subplot(111); ax.imshow(im[..., 0] if im.shape[-1] == 1 else im); ax.axis('off')
+                fig.savefig(path, bbox_inches='tight', pad_inches=0)
+
+
 # ---- LPIPS (reference utils.py:677-776; SURVEY 8f N2) ------------------------------------------------------------------------
 _LPIPS = {"model": None, "resolved": False}
 

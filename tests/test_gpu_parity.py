@@ -428,6 +428,12 @@ def test_solve_ip_api_and_files(hip, tmp_path):
     assert os.path.isfile(os.path.join(ip, "psnr_rec_average.txt"))
     assert os.path.isfile(os.path.join(str(tmp_path), "final_psnr.txt"))
     assert solver.last_restored.shape == (2, 3, 64, 64) and torch.isfinite(solver.last_restored).all()
+    # the image files of save_images (utils.py:433-538): three grids per batch, and - test split, batch < 4 - three .eps per image
+    names = os.listdir(ip)
+    for b in (0, 1):
+        for word in ("clean", "noisy", "pnp_flow"):
+            assert f"inpainting_{word}_batch{b}_final.png" in names
+        assert sum(n.startswith(f"inpainting_pnp_flow_batch{b}_im") and n.endswith(".eps") for n in names) == 2
 
 
 def test_philox_path_is_deterministic_and_graph_equals_eager(hip):
@@ -1051,6 +1057,10 @@ def test_main_two_ranks_write_the_single_process_result_files(hip, tmp_path):
         assert len(sub) == 1, list(os.walk(base))
         outs[n] = {f: open(os.path.join(sub[0], f)).read() for f in ("psnr_rec_batch0.txt", "psnr_rec_batch1.txt", "psnr_noisy_batch1.txt", "psnr_rec_average.txt")}
         assert os.path.isfile(os.path.join(base, "final_psnr.txt")) and os.path.isfile(os.path.join(sub[0], "time_average.txt"))
+        # rank 0 draws the grids of the GLOBAL batch (the shards are gathered in image order): 4 images -> 4 restored .eps per batch
+        names = os.listdir(sub[0])
+        assert "random_inpainting_pnp_flow_batch1_final.png" in names
+        assert sum(x.startswith("random_inpainting_pnp_flow_batch1_im") for x in names) == 4, names
     for f in outs[1]:
         a = [l.split() for l in outs[1][f].strip().splitlines()]; b = [l.split() for l in outs[2][f].strip().splitlines()]
         assert [x[0] for x in a] == [x[0] for x in b], f

@@ -406,3 +406,31 @@ def test_lpips_oracle_properties_and_key_mapping():
     can = canonical_state_dict(full)
     assert sorted(can) == sorted([f"features.{i}.weight" for i in (0, 3, 6, 8, 10)] + [f"lin{k}" for k in range(5)])
     assert can["lin2"].shape == (384,) and torch.equal(can["features.6.weight"], sd["features.6.weight"])
+
+
+# ---- image grids (reference utils.py:433-538) -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,C", [(1, 3), (2, 3), (6, 3), (4, 1), (3, 3)])
+def test_save_images_writes_the_reference_file_set(tmp_path, B, C):
+    pytest.importorskip("matplotlib")
+    import types
+    from pnpflow_amd import utils
+    g = torch.Generator().manual_seed(B * 10 + C)
+    clean = torch.rand(B, C, 12, 12, generator=g) * 2 - 1
+    noisy = clean + 0.1 * torch.randn(B, C, 12, 12, generator=g)
+    rec = clean + 0.01 * torch.randn(B, C, 12, 12, generator=g)
+    args = types.SimpleNamespace(save_path_ip=str(tmp_path), problem="denoising", method="pnp_flow", batch=1, num_channels=C, eval_split="test")
+    utils.save_images(clean, noisy, rec, args, lambda t: t, iter='final')
+    names = sorted(os.listdir(tmp_path))
+    for word in ("clean", "noisy", "pnp_flow"):
+        assert f"denoising_{word}_batch1_final.png" in names
+    # batch < 4 on the test split: one .eps per image and kind, the image's own PSNR (data range 1, after postprocess) in the name
+    eps = [n for n in names if n.endswith(".eps")]
+    assert len(eps) == 3 * B
+    p0 = 10 * np.log10(1.0 / float((((rec[0] - clean[0]) / 2).double() ** 2).mean()))
+    assert f"denoising_pnp_flow_batch1_im0_iterfinal_pnsr{p0:4.2f}.eps" in names
+    assert "denoising_clean_batch1_im0.eps" in names
+    # an intermediate iteration writes one grid of the restored images only; later batches write no per-image files
+    args.batch = 7
+    utils.save_images(clean, noisy, rec, args, lambda t: t, iter=50)
+    names2 = set(os.listdir(tmp_path)) - set(names)
+    assert names2 == {"denoising_pnp_flow_batch7_iter50.png"}

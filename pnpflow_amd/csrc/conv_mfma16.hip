@@ -55,7 +55,11 @@ __device__ __forceinline__ float silu_fast16(float x) { return x * __builtin_amd
 // TF32 convolutions the reference's own CUDA runs use by PyTorch default; one third of the matrix-pipe work, no low halves staged.
 template <int MT, int NT, int WM, int WN, int S, int UP, int KC, bool GNB = false, int TERMS = 3>
 __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16_kernel(const ConvParams p) {
-    constexpr int ROW = KC + 4;                  // dwords per LDS row: KC/2 (hi) + KC/2 (lo) + 4 (pad)
+#ifdef PF_AB_T1_FULLROW      // A/B: the one-term mode with the three-term row pitch (dead low halves), as before round 3
+    constexpr int ROW = KC + 4;
+#else
+    constexpr int ROW = (TERMS == 3 ? KC : KC / 2) + 4;   // dwords per LDS row: KC/2 (hi) + KC/2 (lo; not in the one-term mode) + 4 (pad); always 4 x odd
+#endif
     constexpr int KQ = KC / 4, KH = KC / 2, KS = KC / 16;
     constexpr int TH = 2 * MT * WM, TW = 16;
     constexpr int HALO = KC == 64 ? 0 : 1;      // KC = 64 is instantiated for pure 1x1 launches only: their patch has no halo
@@ -513,7 +517,11 @@ __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16
 
 template <int MT, int NT, int WM, int WN, int S, int UP, int KC, int TERMS>
 static hipError_t launch_cfg16(const ConvParams& p, hipStream_t stream) {
+#ifdef PF_AB_T1_FULLROW
     constexpr int ROW = KC + 4;
+#else
+    constexpr int ROW = (TERMS == 3 ? KC : KC / 2) + 4;
+#endif
     constexpr int TH = 2 * MT * WM, TW = 16;
     constexpr int HALO = KC == 64 ? 0 : 1;
     constexpr int PH = (TH - 1) * S + 1 + 2 * HALO, PW = (TW - 1) * S + 1 + 2 * HALO;

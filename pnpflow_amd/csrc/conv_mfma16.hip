@@ -151,14 +151,18 @@ __global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16
 #else
                 if (sg.xform != 0) {
 #endif
+#ifndef PF_AB_NOGN
                     v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
                     v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+#endif
                     if (sg.xform == 2) {
                         v.x = silu_fast16(v.x); v.y = silu_fast16(v.y); v.z = silu_fast16(v.z); v.w = silu_fast16(v.w);
                     }
                 }
-#ifndef PF_AB_RAWSTAGE
+#if !defined(PF_AB_RAWSTAGE) && !defined(PF_AB_NOSCALE)
                 v.x *= a_scale; v.y *= a_scale; v.z *= a_scale; v.w *= a_scale;
+#endif
+#if !defined(PF_AB_RAWSTAGE) && !defined(PF_AB_NOSELECT)
                 if (!(cok && a_pix[i] >= 0)) v = make_float4(0.f, 0.f, 0.f, 0.f);
 #endif
                 // opaque to the optimiser: the hi that is stored and the hi that is subtracted must be the SAME rounding of

@@ -8,7 +8,7 @@
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Optional, Sequence
+from typing import Dict
 
 import numpy as np
 import torch

@@ -127,7 +127,6 @@ def postprocess(img, args=None):
 def psnr_per_image(rec: torch.Tensor, clean: torch.Tensor) -> torch.Tensor:
     """PSNR (data_range 1) of postprocess(rec) vs postprocess(clean) per image, on the GPU
     (pf_psnr).  Restates torchmetrics peak_signal_noise_ratio(dim=(1,2,3))."""
-    import ctypes as C
     lib = _lib.load()
     rec = rec.contiguous().float(); clean = clean.to(rec.device).contiguous().float()
     out = torch.empty(rec.shape[0], dtype=torch.float32, device=rec.device)

@@ -54,7 +54,12 @@ __device__ __forceinline__ float silu_fast16(float x) { return x * __builtin_amd
 // fp16 (11-bit significands, the power-of-two operand scales keep them in range), fp32 accumulate: the precision class of the
 // TF32 convolutions the reference's own CUDA runs use by PyTorch default; one third of the matrix-pipe work, no low halves staged.
 template <int MT, int NT, int WM, int WN, int S, int UP, int KC, bool GNB = false, int TERMS = 3>
-__global__ __launch_bounds__(256, (PF_LB3(MT, WM, KC) ? 3 : 1)) void conv_mfma16_kernel(const ConvParams p) {
+#ifdef PF_AB_LB4          // A/B: four workgroups per CU on the 16x16 px x 32 tile with 16-channel chunks (128 registers)
+#define PF_LBN(MT, WM, KC) (((MT) == 2 && (WM) == 4 && (KC) == 16) ? 4 : (PF_LB3(MT, WM, KC) ? 3 : 1))
+#else
+#define PF_LBN(MT, WM, KC) (PF_LB3(MT, WM, KC) ? 3 : 1)
+#endif
+__global__ __launch_bounds__(256, PF_LBN(MT, WM, KC)) void conv_mfma16_kernel(const ConvParams p) {
 #ifdef PF_AB_T1_FULLROW      // A/B: the one-term mode with the three-term row pitch (dead low halves), as before round 3
     constexpr int ROW = KC + 4;
 #else

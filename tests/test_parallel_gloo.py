@@ -118,3 +118,44 @@ def test_empty_shard_joins_every_collective(tmp_path):
     assert res[0][2] == 1 and res[1][2] == 0 and res[0][1] == res[1][1] == [0, 5, 9]
     lines = [l.split() for l in open(os.path.join(str(tmp_path), "psnr_rec_batch0.txt")).read().strip().splitlines()]
     assert [(int(a), float(b)) for a, b in lines] == [(0, 0.0), (5, 5.0), (9, 9.0)]      # the mean over the ONE image of the global batch
+
+
+def _worker_images(rank, world, port, G, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import types
+    from pnpflow_amd import utils
+    lo, hi = shard_range(G, rank, world)
+    g = torch.Generator().manual_seed(11)
+    clean = (torch.rand(G, 3, 8, 8, generator=g) * 2 - 1)
+    rec = clean + 0.02 * torch.randn(G, 3, 8, 8, generator=g)
+    args = types.SimpleNamespace(save_path_ip=os.environ["PF_TEST_DIR"], problem="denoising", method="pnp_flow", batch=2, num_channels=3, eval_split="test")
+    # every rank calls it with its shard (rank 1 of G = 1: an empty one); rank 0 draws the GLOBAL batch
+    utils.save_images(clean[lo:hi], clean[lo:hi], rec[lo:hi], args, lambda t: t, iter='final')
+    p = [10 * np.log10(1.0 / float((((rec[i] - clean[i]) / 2).double() ** 2).mean())) for i in range(G)]
+    q.put((rank, p))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("G", [5, 1])
+def test_save_images_gathers_the_shards_in_image_order(G, tmp_path):
+    """save_images under two ranks: the per-image .eps files rank 0 writes carry the PSNR of GLOBAL image i (shards of 3 + 2 images;
+    with G = 1 rank 1 owns an empty shard and still has to join the gathers)."""
+    pytest.importorskip("matplotlib")
+    world, port = 2, _free_port()
+    os.environ["PF_TEST_DIR"] = str(tmp_path)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_images, args=(r, world, port, G, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    names = os.listdir(tmp_path)
+    assert "denoising_pnp_flow_batch2_final.png" in names
+    for i, psnr in enumerate(res[0]):
+        assert f"denoising_pnp_flow_batch2_im{i}_iterfinal_pnsr{psnr:4.2f}.eps" in names, (i, psnr, sorted(names))
+    assert sum(n.endswith(".eps") for n in names) == 3 * G

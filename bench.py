@@ -232,7 +232,23 @@ class Runner:
         return self.wl["B"] * (self.wl["ns"] if getattr(self.solver, "batch_samples", False) else 1)
 
 
-STREAM_CEILING_GBS = 5500.0      # measured, not a spec figure: see roofline.streaming_ceiling_source
+STREAM_CEILING_GBS = 5500.0      # fallback when the probe binary is absent (profiles/r03_level0_bound_ab.md section 1); normally measured in this run
+GUIDE_COPY_GBS = 6300.0          # MI355X_MICROARCH.md: what a float4 copy reaches (79 % of the 8 TB/s spec peak)
+
+
+def streaming_ceiling(tensor_bytes, passes):
+    """The HBM rate a pure float4 streaming kernel reaches ON THIS BOX, NOW, on tensors of the dominant kernel's size with its read /
+    write mix (tools/ubench/stream_mix.hip `quick`: the best of two grid-stride grids and a 16 KB-per-workgroup split).  Run as a child
+    process while this process's GPU queue is idle.  -> (GB/s, measured_this_run, detail)"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "ubench", "stream_mix")
+    try:
+        res = subprocess.run([exe, "quick", str(int(tensor_bytes))], capture_output=True, text=True, timeout=120)
+        d = json.loads(res.stdout.strip().splitlines()[-1])
+        key = {2: "1R+1W", 3: "2R+1W"}.get(int(round(passes)), "3R+1W")
+        return float(d[key]), True, d
+    except Exception as exc:          # noqa: BLE001   (a missing probe must not take the measured line with it)
+        return STREAM_CEILING_GBS, False, {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
 
 def conv_roofline(r, precision, workload):
@@ -284,15 +300,21 @@ def conv_roofline(r, precision, workload):
     hbm_floor_us = d["mb"] * 1e6 / 8e12 * 1e6 / d["n"]
     mfma_floor_us = (3 if precision == 1 else 1) * d["gflop"] * 1e9 / (dtype_peak * 1e12) * 1e6 / d["n"]
     hbm_bound = hbm_floor_us >= mfma_floor_us
+    tensor_bytes = r.wl["B"] * rep * r.wl["dim"] ** 2 * 32 * 4          # one full-resolution 32-channel activation at the U-Net batch
+    passes = d["mb"] * 1e6 / d["n"] / tensor_bytes if "Cout 32" in dom else 3.0
+    torch.cuda.synchronize()
+    ceil_gbs, ceil_measured, ceil_detail = streaming_ceiling(tensor_bytes, passes)
     roof = dict(bound="hbm" if hbm_bound else "mfma",
                 achieved=round(gbs, 1) if hbm_bound else round(tfl, 2), peak=8000.0 if hbm_bound else dtype_peak,
                 unit="GB/s" if hbm_bound else "TFLOP/s", frac=round(gbs / 8000.0, 4) if hbm_bound else round(tfl / dtype_peak, 4),
-                traffic=traffic, traffic_source=src, kernel=dom, share_of_conv_time=round(d["us"] / tot_us, 4),
+                traffic=traffic, traffic_source=src, traffic_measured_this_run=False if traffic is not None else None, kernel=dom, share_of_conv_time=round(d["us"] / tot_us, 4),
                 launches=d["n"] // n_fw, avg_launch_us=round(d["us"] / d["n"], 2), algorithmic_mb_per_launch=round(d["mb"] / d["n"], 2),
                 hbm_floor_us_at_8tbs=round(hbm_floor_us, 1), mfma_floor_us=round(mfma_floor_us, 1), unet_batch=r.wl["B"] * rep,
-                # what a pure streaming kernel reaches on tensors of this size with the same read / write mix (tools/ubench/stream_mix.hip)
-                streaming_ceiling_gbs=STREAM_CEILING_GBS, frac_of_streaming_ceiling=round(gbs / STREAM_CEILING_GBS, 4) if hbm_bound else None,
-                streaming_ceiling_source="profiles/r03_level0_bound_ab.md section 1: 5.2-5.8 TB/s for 1R+1W ... 3R+1W on 268 MB / 1.34 GB tensors",
+                # what a pure streaming kernel reaches on tensors of this size with the same read / write mix, measured in THIS run
+                streaming_ceiling_gbs=round(ceil_gbs, 1), frac_of_streaming_ceiling=round(gbs / ceil_gbs, 4) if hbm_bound else None,
+                streaming_ceiling={"measured_this_run": ceil_measured, "probe": "tools/ubench/stream_mix quick", "tensor_bytes": tensor_bytes,
+                                   "tensor_passes_per_launch": round(passes, 2), "detail": ceil_detail, "guide_float4_copy_gbs": GUIDE_COPY_GBS,
+                                   "frac_of_guide_copy": round(gbs / GUIDE_COPY_GBS, 4) if hbm_bound else None},
                 classes={k: dict(share=round(v["us"] / tot_us, 4), avg_us=round(v["us"] / v["n"], 1), algorithmic_gbs=round(v["mb"] * 1e6 / (v["us"] * 1e-6) / 1e9, 1),
                                  algorithmic_tflops=round(v["gflop"] * 1e9 / (v["us"] * 1e-6) / 1e12, 1)) for k, v in cls.items()},
                 mfma_family=fam)
@@ -464,6 +486,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary BASELINE configs and the pointwise block (N=1 default runs include them)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="override the workload's batch per GPU (tests)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (backend 'nccl' = RCCL) even for a one-rank job and execute the job's collectives "
+                         "(barrier, all_reduce(MAX) of the step time, all_gather of the per-image PSNR) on device tensors: the RCCL path on a 1-GPU box")
     ap.add_argument("--precision", type=int, default=1, choices=[0, 1, 2],
                     help="1 (default): fp32-equivalent split-fp16 MFMA (3 x f16 MFMA per product); 0: exact fp32 MFMA; 2: one f16 MFMA per product")
     a = ap.parse_args()
@@ -482,9 +507,12 @@ def main():
     local = int(os.environ.get("PNPFLOW_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    dist_on = world > 1 or a.force_dist
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -504,7 +532,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -515,14 +543,14 @@ def main():
         x = r.step(a.warmup + i)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = comm(torch.tensor([dt], device=dev, dtype=torch.float64))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     # the ONE data-path collective: per-image PSNR gathered in global image order
     psnr = psnr_per_image(x, r.clean)
-    if world > 1:
+    if dist_on:
         psnr = comm(psnr)
         allp = [torch.empty_like(psnr) for _ in range(world)]
         dist.all_gather(allp, psnr)
@@ -534,8 +562,9 @@ def main():
         out = {
             "metric": "restored images/sec", "value": round(total_images / dt, 4), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
-            "collective_backend": (("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else None),
-            "ranks_in_job": (dist.get_world_size() if world > 1 else 1),
+            "collective_backend": (("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if dist_on else None),
+            "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if dist_on and backend == "nccl" else None),
+            "ranks_in_job": (dist.get_world_size() if dist_on else 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {0: "f32", 1: "f32-equivalent (f16 hi+lo split operands, 3 x f16 MFMA per product, f32 accumulate)",
                       2: "f16 operands (power-of-two scaled), f32 accumulate - TF32-class, not fp32-equivalent"}[a.precision],
@@ -623,7 +652,7 @@ def main():
             except Exception as exc:          # noqa: BLE001
                 out["pointwise"] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

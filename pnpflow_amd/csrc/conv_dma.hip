@@ -27,16 +27,6 @@
 #include <type_traits>
 #include "pf_common.h"
 
-// A/B switches (tools/build_variant.py; the defaults are the production configuration)
-#ifndef PF_DMA_APIPE
-#define PF_DMA_APIPE 0       // 1: A fragments software-pipelined one k16-step ahead (second register set)
-#endif
-#ifndef PF_DMA_CARRY
-#define PF_DMA_CARRY 0       // 1: the weight ring of the 9-tap loop runs across chunk boundaries (no cold start per chunk)
-#endif
-#ifndef PF_DMA_LB
-#define PF_DMA_LB 3          // waves per SIMD the register allocation is bounded for
-#endif
 
 namespace pf {
 
@@ -149,7 +139,7 @@ __device__ __forceinline__ void glds16(unsigned voff, const char* sbase, unsigne
 }
 
 template <int MT, int NT, int WM, int WN, int UP, int TERMS, bool GNB>
-__global__ __launch_bounds__(256, PF_DMA_LB) void conv_dma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvParams p) {
     static_assert(NT == 1, "one 32-channel N-tile per wave (the weight ring is sized for it)");
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int KC = TERMS == 3 ? 32 : 64;     // channels per chunk = one 128-byte record per pixel
@@ -295,29 +285,6 @@ __global__ __launch_bounds__(256, PF_DMA_LB) void conv_dma_kernel(const ConvPara
         for (int kx = 0; kx < 3; ++kx) lbc[kx] = lb[kx] + (unsigned)(cur * BUF);
 #define PF_KY(S) (TAPS == 9 ? ((S) / KS) / 3 : 1)
 #define PF_KX(S) (TAPS == 9 ? ((S) / KS) % 3 : 1)
-#if PF_DMA_APIPE
-        f16x8 ahA[MT], alA[MT], ahB[MT], alB[MT];
-        load_a(lbc, PF_KY(0), PF_KX(0), 0, ahA, alA);
-#define PF_STEP(S, FC, FN, ACUR_H, ACUR_L, ANXT_H, ANXT_L)                                                                     \
-        if constexpr ((S) < NS) {                                                                                              \
-            constexpr bool REQ_ = CARRY || (S) + 2 < NS;                                                                       \
-            if constexpr (REQ_) bload<TERMS>(FN, b_voff, b_voff_lo, wstep((S) + 2));                                                      \
-            constexpr int W_ = REQ_ ? ((S) < 2 ? 2 * NB + IPW : 2 * NB) : ((S) + 1 < NS ? ((S) < 2 ? NB + IPW : NB) : ((S) < 2 ? IPW : 0)); \
-            bwait<TERMS, W_>(FC);                                                                                              \
-            if constexpr ((S) + 1 < NS) load_a(lbc, PF_KY((S) + 1), PF_KX((S) + 1), ((S) + 1) % KS, ANXT_H, ANXT_L);            \
-            if constexpr (PF_DMA_APIPE == 1) __builtin_amdgcn_sched_barrier(0);      /* reads of step S+1 issue before the MFMAs of step S */ \
-            mma(ACUR_H, ACUR_L, FC);                                                                                           \
-            if constexpr (PF_DMA_APIPE == 2 && (S) + 1 < NS) {                       /* ... or interleaved with them, one read behind each of the first MFMAs */ \
-                _Pragma("unroll") for (int q_ = 0; q_ < (TERMS == 3 ? 2 : 1) * MT; ++q_) {                                      \
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }     \
-                __builtin_amdgcn_sched_group_barrier(0x008, (TERMS == 3 ? 3 : 1) * MT - (TERMS == 3 ? 2 : 1) * MT, 0);          \
-            }                                                                                                                  \
-        }
-#define PF_STEP6(S) PF_STEP((S), f0, f2, ahA, alA, ahB, alB) PF_STEP((S) + 1, f1, f0, ahB, alB, ahA, alA) PF_STEP((S) + 2, f2, f1, ahA, alA, ahB, alB) \
-                    PF_STEP((S) + 3, f0, f2, ahB, alB, ahA, alA) PF_STEP((S) + 4, f1, f0, ahA, alA, ahB, alB) PF_STEP((S) + 5, f2, f1, ahB, alB, ahA, alA)
-        PF_STEP6(0) PF_STEP6(6) PF_STEP6(12) PF_STEP6(18) PF_STEP6(24) PF_STEP6(30)
-#undef PF_STEP6
-#else
 #define PF_STEP(S, FC, FN)                                                                                                     \
         if constexpr ((S) < NS) {                                                                                              \
             constexpr bool REQ_ = CARRY || (S) + 2 < NS;                                                                       \
@@ -331,7 +298,6 @@ __global__ __launch_bounds__(256, PF_DMA_LB) void conv_dma_kernel(const ConvPara
 #define PF_STEP3(S) PF_STEP((S), f0, f2) PF_STEP((S) + 1, f1, f0) PF_STEP((S) + 2, f2, f1)
         PF_STEP3(0) PF_STEP3(3) PF_STEP3(6) PF_STEP3(9) PF_STEP3(12) PF_STEP3(15) PF_STEP3(18) PF_STEP3(21) PF_STEP3(24) PF_STEP3(27) PF_STEP3(30) PF_STEP3(33)
 #undef PF_STEP3
-#endif
 #undef PF_STEP
 #undef PF_KY
 #undef PF_KX
@@ -350,7 +316,7 @@ __global__ __launch_bounds__(256, PF_DMA_LB) void conv_dma_kernel(const ConvPara
     dma(0, 0, 0);
     int si = 0, ch = 0, cur = 0;
     bool more = true;
-    constexpr bool CARRY9 = PF_DMA_CARRY != 0;
+    constexpr bool CARRY9 = false;      // (the weight ring carried across chunk boundaries measured <= 0.5 %: profiles/r03_ab_dma_variants.md)
     if (CARRY9 && p.seg[0].taps == 9) {
         const char* w0 = wchunk(0, 0);
         bload<TERMS>(f0, b_voff, b_voff_lo, w0);
@@ -557,9 +523,8 @@ static hipError_t launch_dma_t(const ConvParams& p, hipStream_t stream) {
     const size_t lds = 2 * BUF;
     const int tiles = p.B * (p.H / DMA_TH) * (p.W / 16);
     dim3 grid(tiles, p.Cout / DMA_BN);
-    static const bool xcd_env = !(getenv("PNPFLOW_HIP_XCD") && atoi(getenv("PNPFLOW_HIP_XCD")) == 0);
     ConvParams pp = p; pp.xcd_map = 0;
-    if (xcd_env && ((long)grid.x * grid.y) % 8 == 0) { pp.xcd_map = 1; grid = dim3(grid.x * grid.y, 1); }
+    if (((long)grid.x * grid.y) % 8 == 0) { pp.xcd_map = 1; grid = dim3(grid.x * grid.y, 1); }
     if (p.gnb_x != nullptr) {
         if constexpr (UP == 0) {
             hipLaunchKernelGGL((conv_dma_kernel<MT, 1, WM, WN, UP, TERMS, true>), grid, dim3(256), lds, stream, pp);

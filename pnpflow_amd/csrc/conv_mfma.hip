@@ -173,16 +173,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         const ConvSeg& sg = p.seg[si];
         const bool first = (si == 0 && ch == 0);
         __syncthreads();          // every wave finished reading the previous chunk (and s_sc is written)
-        if (!(p.dbg & 2) || first) store_lds(si, ch);
+        store_lds(si, ch);
         __syncthreads();
         int nsi = si, nch = ch + 1;
         if (nch * KC >= sg.C) { nsi = si + 1; nch = 0; }
         const bool more = nsi < p.nseg;
 
-        const int nsteps = (p.dbg & 1) ? 0 : sg.taps * KS;
+        const int nsteps = sg.taps * KS;
         float4 b0[NT], b1[NT], b2[NT];
         if (nsteps > 0) { load_b(sg, ch, 0, b0); load_b(sg, ch, min(1, nsteps - 1), b1); }
-        if (more && !(p.dbg & 2)) prefetch(nsi, nch);   // issued after the first two B fragments: the
+        if (more) prefetch(nsi, nch);                  // issued after the first two B fragments: the
                                                         // in-order vmcnt wait for them does not drag these along
         // one k-step: 8 input channels of one tap.  `bc`/`ac` hold this step's B / A fragments, `bl`
         // receives the B fragments of step s+2 and `al` the A fragments of step s+1 (register rings

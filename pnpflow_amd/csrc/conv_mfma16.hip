@@ -19,52 +19,22 @@
 
 namespace pf {
 
-// Ablation switches (ConvParams::dbg, -DPF_CONV_DEBUG) and per-phase cycle tracing (ConvParams::trace, -DPF_CONV_TRACE)
-// are compiled in only for the profiling builds (libpnpflow_hip_dbg.so / _trace.so, tools/ablate.sh): even as uniform
-// run-time branches the switches cost the production kernel 15 % (registers, conservative waitcnts).
-#ifdef PF_CONV_DEBUG
-#define PF_DBG(bit) ((p.dbg & (bit)) != 0)
-#else
-#define PF_DBG(bit) (false)
-#endif
-
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // v_exp_f32 / v_rcp_f32 (1 ulp each); __frcp_rn would be a correctly rounded division: 10 instructions per element
-#ifdef PF_AB_NOSILU        // timing-only A/B build (wrong results): what the two quarter-rate transcendentals of the staging cost
-__device__ __forceinline__ float silu_fast16(float x) { return x; }
-#else
 __device__ __forceinline__ float silu_fast16(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-#endif
 
-// A/B switches of the profiling builds (tools/ab_variants.sh): PF_AB_GN_INKERNEL re-derives the GroupNorm coefficients in every
-// workgroup's prologue as round 1 did; PF_AB_NO_RESCALE drops the per-segment accumulator rescale and the register bound it needs
-#ifndef PF_ROW_PAD
-#define PF_ROW_PAD 1      // 0: the round-1 patch layout (A/B builds)
-#endif
-#ifdef PF_AB_NO_RESCALE
-#define PF_LB3(MT, WM, KC) ((MT) == 4 && (WM) == 2 && (KC) == 16)
-#else
-#define PF_LB3(MT, WM, KC) (((MT) == 4 && (WM) == 2 && (KC) == 16) || ((KC) != 64 && (((MT) == 4 && (WM) == 1) || ((MT) == 2 && (WM) == 4))))
-#endif
+// waves per SIMD the register allocation is bounded for: 3 on the tiles whose accumulators stay in VGPRs for the per-segment rescale
+constexpr int conv16_lb(int MT, int WM, int KC) { return ((MT == 4 && WM == 2 && KC == 16) || (KC != 64 && ((MT == 4 && WM == 1) || (MT == 2 && WM == 4)))) ? 3 : 1; }
 
 // TERMS = 3: every product as a_lo*w_hi + a_hi*w_lo + a_hi*w_hi (fp32-equivalent).  TERMS = 1: a_hi*w_hi only - operands rounded to
 // fp16 (11-bit significands, the power-of-two operand scales keep them in range), fp32 accumulate: the precision class of the
 // TF32 convolutions the reference's own CUDA runs use by PyTorch default; one third of the matrix-pipe work, no low halves staged.
 template <int MT, int NT, int WM, int WN, int S, int UP, int KC, bool GNB = false, int TERMS = 3>
-#ifdef PF_AB_LB4          // A/B: four workgroups per CU on the 16x16 px x 32 tile with 16-channel chunks (128 registers)
-#define PF_LBN(MT, WM, KC) (((MT) == 2 && (WM) == 4 && (KC) == 16) ? 4 : (PF_LB3(MT, WM, KC) ? 3 : 1))
-#else
-#define PF_LBN(MT, WM, KC) (PF_LB3(MT, WM, KC) ? 3 : 1)
-#endif
-__global__ __launch_bounds__(256, PF_LBN(MT, WM, KC)) void conv_mfma16_kernel(const ConvParams p) {
-#ifdef PF_AB_T1_FULLROW      // A/B: the one-term mode with the three-term row pitch (dead low halves), as before round 3
-    constexpr int ROW = KC + 4;
-#else
+__global__ __launch_bounds__(256, conv16_lb(MT, WM, KC)) void conv_mfma16_kernel(const ConvParams p) {
     constexpr int ROW = (TERMS == 3 ? KC : KC / 2) + 4;   // dwords per LDS row: KC/2 (hi) + KC/2 (lo; not in the one-term mode) + 4 (pad); always 4 x odd
-#endif
     constexpr int KQ = KC / 4, KH = KC / 2, KS = KC / 16;
     constexpr int TH = 2 * MT * WM, TW = 16;
     constexpr int HALO = KC == 64 ? 0 : 1;      // KC = 64 is instantiated for pure 1x1 launches only: their patch has no halo
@@ -74,7 +44,7 @@ __global__ __launch_bounds__(256, PF_LBN(MT, WM, KC)) void conv_mfma16_kernel(co
     // = 4 * odd the 16 pixels of ONE row land on 16 different 16-B bank slots; a row pitch that is not 0 mod 64 dwords shifts the
     // second row's slots onto the first's (PW * ROW = 648: 2-way conflicts on half of the A-fragment reads, SQ_LDS_BANK_CONFLICT =
     // 48 % of SQ_LDS_IDX_ACTIVE, profiles/r02_pmc_sq_*).
-    constexpr int RS = PF_ROW_PAD ? ((PW * ROW + 63) / 64) * 64 : PW * ROW;
+    constexpr int RS = ((PW * ROW + 63) / 64) * 64;
     constexpr int BN = WN * NT * 32;
     constexpr int A_F4 = PP * KQ, A_PER = (A_F4 + 255) / 256;
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -133,11 +103,7 @@ __global__ __launch_bounds__(256, PF_LBN(MT, WM, KC)) void conv_mfma16_kernel(co
         const int c = min(ch * KC + q4, sg.C - 4);
         const float* base = sg.src + sg.coff + c;
 #pragma unroll
-#ifdef PF_AB_NOINPUT       // timing-only A/B build (wrong results): no activation loads at all - the upper bound of what hiding the input latency can buy
-        for (int i = 0; i < A_PER; ++i) { const float f = (float)(a_pix[i] & 7) + (float)(size_t)base * 0.f; ra[i] = make_float4(f, f, f, f); }
-#else
         for (int i = 0; i < A_PER; ++i) ra[i] = *reinterpret_cast<const float4*>(base + (size_t)max(a_pix[i], 0) * sg.cstride);
-#endif
     };
     auto store_lds = [&](int si, int ch) {
         const ConvSeg& sg = p.seg[si];
@@ -155,25 +121,15 @@ __global__ __launch_bounds__(256, PF_LBN(MT, WM, KC)) void conv_mfma16_kernel(co
                 const int a_p = (tid + i * 256) / KQ;
                 const int a_lds = (a_p / PW) * RS + (a_p % PW) * ROW + qi * 2;      // dword offset of this thread's 4 hi halfs (lo at +KH)
                 float4 v = ra[i];
-#ifdef PF_AB_RAWSTAGE      // timing-only A/B build (wrong results): no GroupNorm / SiLU / scale / zero-select in the staging
-                if (false) {
-#else
                 if (sg.xform != 0) {
-#endif
-#ifndef PF_AB_NOGN
                     v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
                     v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-#endif
                     if (sg.xform == 2) {
                         v.x = silu_fast16(v.x); v.y = silu_fast16(v.y); v.z = silu_fast16(v.z); v.w = silu_fast16(v.w);
                     }
                 }
-#if !defined(PF_AB_RAWSTAGE) && !defined(PF_AB_NOSCALE)
                 v.x *= a_scale; v.y *= a_scale; v.z *= a_scale; v.w *= a_scale;
-#endif
-#if !defined(PF_AB_RAWSTAGE) && !defined(PF_AB_NOSELECT)
                 if (!(cok && a_pix[i] >= 0)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
                 // opaque to the optimiser: the hi that is stored and the hi that is subtracted must be the SAME rounding of
                 // the SAME fp32 value.  With -ffp-contract=fast hipcc may otherwise fuse the producing multiply into the
                 // subtraction (v_fma_mix*) while the stored hi comes from the rounded product - they differ at double-rounding
@@ -191,60 +147,9 @@ __global__ __launch_bounds__(256, PF_LBN(MT, WM, KC)) void conv_mfma16_kernel(co
         }
     };
 
-#ifdef PF_CONV_TRACE
-    // phase cycle sums, accumulated in registers and flushed once per workgroup into one of 256 slots (a single
-    // accumulator per launch serialises ~10^5 same-address atomics and doubles the kernel time)
-    unsigned long long t_prev = p.trace ? clock64() : 0ull, t_acc[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
-    auto mark = [&](int k) {
-        if (p.trace != nullptr && tid == 0) { const unsigned long long now = clock64(); t_acc[k] += now - t_prev; t_prev = now; }
-    };
-#else
-    auto mark = [](int) {};
-#endif
     // GroupNorm coefficients of image b: finalised once per launch by gn_coef_kernel (unet_misc.hip); requested BEFORE the
     // first patch chunk (loads return in order) and parked in LDS behind the patch, where the staging reads them.
     constexpr int GNP = 4;                       // passes of 256 channels: gn_C <= 1024 (checked by the launcher)
-#ifdef PF_AB_GN_INKERNEL
-    double gsum[GNP], gsq[GNP]; float gga[GNP], gbe[GNP];
-#pragma unroll
-    for (int i = 0; i < GNP; ++i) {
-        const int c = tid + i * 256;
-        gsum[i] = 0.0; gsq[i] = 0.0; gga[i] = 0.f; gbe[i] = 0.f;
-        if (c < p.gn_C) {
-            for (int si = 0; si < p.nseg; ++si) {
-                const ConvSeg& sg = p.seg[si];
-                if (sg.xform != 0 && c >= sg.gn_off && c < sg.gn_off + sg.C) {
-                    const double* st = sg.stats + ((size_t)b * sg.C + (c - sg.gn_off)) * 2;
-                    gsum[i] = st[0]; gsq[i] = st[1];
-                }
-            }
-            gga[i] = p.gamma[c]; gbe[i] = p.beta[c];
-        }
-    }
-    prefetch(0, 0);
-    if (p.gn_C > 0) {
-        double* s_st = reinterpret_cast<double*>(s_patch);
-#pragma unroll
-        for (int i = 0; i < GNP; ++i) { const int c = tid + i * 256; if (c < p.gn_C) { s_st[2 * c] = gsum[i]; s_st[2 * c + 1] = gsq[i]; } }
-        __syncthreads();
-        const double inv_n = 1.0 / ((double)p.gn_cpg * (double)p.Hs * (double)p.Ws);
-#pragma unroll
-        for (int i = 0; i < GNP; ++i) {
-            const int c = tid + i * 256;
-            if (c < p.gn_C) {
-                const int g0 = (c / p.gn_cpg) * p.gn_cpg;
-                double sm = 0.0, ss = 0.0;
-                for (int j = g0; j < g0 + p.gn_cpg; ++j) { sm += s_st[2 * j]; ss += s_st[2 * j + 1]; }
-                const double mean = sm * inv_n;
-                double var = ss * inv_n - mean * mean;
-                var = var > 0.0 ? var : 0.0;
-                const float rstd = __builtin_amdgcn_rsqf((float)(var + (double)p.gn_eps));
-                const float sc = gga[i] * rstd;
-                s_sc[c] = sc; s_sh[c] = gbe[i] - (float)mean * sc;
-            }
-        }
-    }
-#else
     float csc[GNP], csh[GNP];
     {
         const float* cb = p.coef + (size_t)b * 2 * p.coef_stride;
@@ -263,7 +168,6 @@ __global__ __launch_bounds__(256, PF_LBN(MT, WM, KC)) void conv_mfma16_kernel(co
         const int c = tid + i * 256;
         if (c < p.gn_C) { s_sc[c] = csc[i]; s_sh[c] = csh[i]; }          // visible to store_lds after the chunk loop's first barrier
     }
-#endif
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -290,17 +194,12 @@ __global__ __launch_bounds__(256, PF_LBN(MT, WM, KC)) void conv_mfma16_kernel(co
     };
 
     int si = 0, ch = 0;
-    mark(0);
     while (true) {
         const ConvSeg& sg = p.seg[si];
         if (ch == 0 && si > 0) {
             // the accumulator changes units: from segment si-1's operand scale to segment si's (both powers of two: exact)
             const float ratio = (si == 1 ? seg_scale[1] * seg_inv[0] : seg_scale[2] * seg_inv[1]);
-#ifndef PF_AB_NO_RESCALE
             if (ratio != 1.0f)
-#else
-            if (false)
-#endif
             {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
@@ -311,9 +210,8 @@ __global__ __launch_bounds__(256, PF_LBN(MT, WM, KC)) void conv_mfma16_kernel(co
             }
         }
         __syncthreads();
-        if (!PF_DBG(2) || (si == 0 && ch == 0)) store_lds(si, ch);
+        store_lds(si, ch);
         __syncthreads();
-        mark(1);
         int nsi = si, nch = ch + 1;
         if (nch * KC >= sg.C) { nsi = si + 1; nch = 0; }
         const bool more = nsi < p.nseg;
@@ -321,10 +219,10 @@ __global__ __launch_bounds__(256, PF_LBN(MT, WM, KC)) void conv_mfma16_kernel(co
         const int nsteps = sg.taps * KS;      // k16-steps per chunk: 9 / 1 (KC 16), 18 / 2 (KC 32), 4 (KC 64, 1-tap launches)
         uint4 bh0[NT], bl0[NT], bh1[NT], bl1[NT], bh2[NT], bl2[NT];
         load_b(sg, ch, 0, bh0, bl0); load_b(sg, ch, min(1, nsteps - 1), bh1, bl1);
-        if (more && !PF_DBG(2)) prefetch(nsi, nch);
+        if (more) prefetch(nsi, nch);
 
         auto k_step = [&](int s, uint4 (&ch_)[NT], uint4 (&cl_)[NT], uint4 (&nh_)[NT], uint4 (&nl_)[NT]) {
-            if (!PF_DBG(8)) load_b(sg, ch, min(s + 2, nsteps - 1), nh_, nl_);
+            load_b(sg, ch, min(s + 2, nsteps - 1), nh_, nl_);
             __builtin_amdgcn_sched_barrier(0);
             const int tap = s / KS, j = s % KS;
             const int ky = sg.taps == 9 ? tap / 3 : HALO, kx = sg.taps == 9 ? tap % 3 : HALO;
@@ -332,23 +230,13 @@ __global__ __launch_bounds__(256, PF_LBN(MT, WM, KC)) void conv_mfma16_kernel(co
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int poff = (((wm * MT + mt) * 2 + prow) * S + ky) * RS + (pcol * S + kx) * ROW;
-                if (PF_DBG(4)) { ah[mt] = *reinterpret_cast<const f16x8*>(&ch_[0]); al[mt] = *reinterpret_cast<const f16x8*>(&cl_[0]); continue; }
                 ah[mt] = *reinterpret_cast<const f16x8*>(s_patch + poff + j * 8 + hi * 4);
                 if constexpr (TERMS == 3) al[mt] = *reinterpret_cast<const f16x8*>(s_patch + poff + KH + j * 8 + hi * 4); else al[mt] = ah[mt];
             }
-#ifndef PF_AB_NO_A_FIRST
             // every A fragment of the k-step is requested before its first MFMA (the MFMAs then wait with counted lgkmcnt):
             // left alone hipcc recycles ONE register quad for the four low-half fragments and emits ds_read -> lgkmcnt(0) -> MFMA
             // four times per k-step.  Not on the 8x16x128 tile, where the extra live fragments spill at its 168-register bound.
             if constexpr (!(MT == 4 && WM == 1)) __builtin_amdgcn_sched_barrier(0);
-#endif
-            if (PF_DBG(1)) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(ah[mt]), "v"(al[mt]));
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(ch_[nt].x), "v"(ch_[nt].y), "v"(ch_[nt].z), "v"(ch_[nt].w), "v"(cl_[nt].x), "v"(cl_[nt].y), "v"(cl_[nt].z), "v"(cl_[nt].w));
-                return;
-            }
             if constexpr (TERMS == 3) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -375,7 +263,6 @@ __global__ __launch_bounds__(256, PF_LBN(MT, WM, KC)) void conv_mfma16_kernel(co
         if (nsteps - s >= 1) k_step(s, bh0, bl0, bh2, bl2);
         if (nsteps - s == 2) k_step(s + 1, bh1, bl1, bh0, bl0);
         __builtin_amdgcn_s_setprio(0);
-        mark(2);
         if (!more) break;
         si = nsi; ch = nch;
     }
@@ -429,11 +316,7 @@ __global__ __launch_bounds__(256, PF_LBN(MT, WM, KC)) void conv_mfma16_kernel(co
                         }
                 }
             }
-#ifdef PF_AB_NOEPI          // timing-only A/B build (wrong results): no residual loads and no output stores
-            if (false) {
-#else
-            if (mt % RG == 0 && p.residual != nullptr && !PF_DBG(32)) {
-#endif
+            if (mt % RG == 0 && p.residual != nullptr) {
 #pragma unroll
                 for (int g = 0; g < RG; ++g)
 #pragma unroll
@@ -457,15 +340,9 @@ __global__ __launch_bounds__(256, PF_LBN(MT, WM, KC)) void conv_mfma16_kernel(co
                 const int px = (lane >> 3) + 8 * i;    // pixel of the 32-pixel M-tile (2 rows x 16 cols)
                 const int oy = oy0 + (wm * MT + mt) * 2 + (px >> 4), ox = ox0 + (px & 15);
                 float4 v = *reinterpret_cast<const float4*>(s_tr + px * TP + cq * 4);
-#ifdef PF_AB_NOEPI
-                if (nok4 && oy < p.H && ox < p.W && v.x == 1.2345f) {
+                if (nok4 && oy < p.H && ox < p.W) {
                     const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
-                    if (false) {
-#else
-                if (nok4 && oy < p.H && ox < p.W && !(PF_DBG(16) && v.x != 1.2345f)) {
-                    const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
-                    if (p.residual != nullptr && !PF_DBG(32)) {
-#endif
+                    if (p.residual != nullptr) {
                         const float rsc = p.res_scale;
                         v.x = fmaf(rv[mt % RG][i].x, rsc, v.x); v.y = fmaf(rv[mt % RG][i].y, rsc, v.y); v.z = fmaf(rv[mt % RG][i].z, rsc, v.z); v.w = fmaf(rv[mt % RG][i].w, rsc, v.w);
                     }
@@ -498,7 +375,7 @@ __global__ __launch_bounds__(256, PF_LBN(MT, WM, KC)) void conv_mfma16_kernel(co
             __builtin_amdgcn_wave_barrier();            // scratch is rewritten by the next tile
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        if ((GNB || p.stats_out != nullptr) && !PF_DBG(128)) {
+        if (GNB || p.stats_out != nullptr) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -513,8 +390,7 @@ __global__ __launch_bounds__(256, PF_LBN(MT, WM, KC)) void conv_mfma16_kernel(co
             }
         }
     }
-    mark(3);
-    if ((GNB || p.stats_out != nullptr) && !PF_DBG(128)) {
+    if (GNB || p.stats_out != nullptr) {
         __syncthreads();
         for (int t = tid; t < BN * 2; t += 256) {
             const int col = t >> 1, which = t & 1;
@@ -528,35 +404,22 @@ __global__ __launch_bounds__(256, PF_LBN(MT, WM, KC)) void conv_mfma16_kernel(co
             }
         }
     }
-    mark(4);
-#ifdef PF_CONV_TRACE
-    if (p.trace != nullptr && tid == 0) {
-        unsigned long long* slot = p.trace + (blockIdx.x & 255) * 8;
-        for (int k = 0; k < 5; ++k) atomicAdd(slot + k, t_acc[k]);
-        atomicAdd(slot + 5, 1ull);
-    }
-#endif
 }
 
 template <int MT, int NT, int WM, int WN, int S, int UP, int KC, int TERMS>
 static hipError_t launch_cfg16(const ConvParams& p, hipStream_t stream) {
-#ifdef PF_AB_T1_FULLROW
-    constexpr int ROW = KC + 4;
-#else
     constexpr int ROW = (TERMS == 3 ? KC : KC / 2) + 4;
-#endif
     constexpr int TH = 2 * MT * WM, TW = 16;
     constexpr int HALO = KC == 64 ? 0 : 1;
     constexpr int PH = (TH - 1) * S + 1 + 2 * HALO, PW = (TW - 1) * S + 1 + 2 * HALO;
-    constexpr int RS = PF_ROW_PAD ? ((PW * ROW + 63) / 64) * 64 : PW * ROW;
+    constexpr int RS = ((PW * ROW + 63) / 64) * 64;
     constexpr int BN = WN * NT * 32;
     constexpr int EPI = 4 * 32 * 36 + WM * BN * 2;           // epilogue: 4 per-wave transpose tiles + statistics scratch (floats)
     const size_t lds = (size_t)((PH * RS > EPI ? PH * RS : EPI) + 2 * ((p.gn_C + 3) & ~3)) * 4;
     const int tiles = p.B * ((p.H + TH - 1) / TH) * ((p.W + TW - 1) / TW);
     dim3 grid(tiles, (p.Cout + BN - 1) / BN);
-    static const bool xcd_env = !(getenv("PNPFLOW_HIP_XCD") && atoi(getenv("PNPFLOW_HIP_XCD")) == 0);
     ConvParams pp = p; pp.xcd_map = 0;
-    if (xcd_env && ((long)grid.x * grid.y) % 8 == 0) { pp.xcd_map = 1; grid = dim3(grid.x * grid.y, 1); }
+    if (((long)grid.x * grid.y) % 8 == 0) { pp.xcd_map = 1; grid = dim3(grid.x * grid.y, 1); }
     if constexpr (S == 1 && UP == 0) {
         if (p.gnb_x != nullptr) {        // adjoint conv with the fused GroupNorm-backward first stage
             static unsigned long long attr_set_g = 0ull;
@@ -580,18 +443,12 @@ static long wg_count16(const ConvParams& p, int TH, int BN) {
 
 template <int S, int UP, int KC, int TERMS>
 static hipError_t launch_sel16(const ConvParams& p, hipStream_t stream) {
-    static const long MIN_WGS = getenv("PNPFLOW_HIP_MIN_WGS") ? atol(getenv("PNPFLOW_HIP_MIN_WGS")) : 512;
-    // A/B: smaller tiles (more workgroups per CU) on the HBM-latency-bound 32 / 64 channel levels
-    static const int tile_l0 = getenv("PNPFLOW_HIP_TILE_L0") ? atoi(getenv("PNPFLOW_HIP_TILE_L0")) : 16;
-    static const int tile_l1 = getenv("PNPFLOW_HIP_TILE_L1") ? atoi(getenv("PNPFLOW_HIP_TILE_L1")) : 16;
+    constexpr long MIN_WGS = 512;     // >= 2 workgroups per CU
     if constexpr (S == 1) {
         if (p.Cout <= 32) {
-            if (tile_l0 == 8) return launch_cfg16<1, 1, 4, 1, S, UP, KC, TERMS>(p, stream);                                      // 8x16 px x 32
-            if (tile_l0 == 32) return launch_cfg16<4, 1, 4, 1, S, UP, KC, TERMS>(p, stream);                                     // 32x16 px x 32 (half the weight loads per pixel)
             return launch_cfg16<2, 1, 4, 1, S, UP, KC, TERMS>(p, stream);                                                        // 16x16 px x 32
         }
         if (p.Cout <= 64) {
-            if (tile_l1 == 8) return launch_cfg16<2, 1, 2, 2, S, UP, KC, TERMS>(p, stream);                                      // 8x16 px x 64
             if (wg_count16(p, 16, 64) >= MIN_WGS) return launch_cfg16<4, 1, 2, 2, S, UP, KC, TERMS>(p, stream);                  // 16x16 px x 64
             if (wg_count16(p, 8, 64) >= MIN_WGS) return launch_cfg16<2, 1, 2, 2, S, UP, KC, TERMS>(p, stream);                   // 8x16 px x 64
             return launch_cfg16<1, 1, 2, 2, S, UP, KC, TERMS>(p, stream);                                                        // 4x16 px x 64
@@ -610,20 +467,13 @@ static hipError_t launch_sel16(const ConvParams& p, hipStream_t stream) {
 // fp32 kernel (launch_conv) for the generic strided operands of attention.
 template <int TERMS>
 static hipError_t launch_conv16_t(const ConvParams& p, int stride, int up, hipStream_t stream) {
-#ifdef PF_AB_GN_INKERNEL
-    if (p.gn_C > 1024) return hipErrorInvalidValue;
-#else
     if (p.gn_C > 1024 || (p.gn_C > 0 && p.coef == nullptr)) return hipErrorInvalidValue;      // the kernel parks at most 4 x 256 GroupNorm channels
-#endif
     bool all_1tap = true;
     for (int i = 0; i < p.nseg; ++i) {
         if (p.seg[i].w_mode != 0 || p.seg[i].w16 == nullptr) return hipErrorInvalidValue;
         all_1tap &= p.seg[i].taps == 1 && p.seg[i].C % 64 == 0;    // 64-channel chunks need whole chunks: the packed weights end at C/16 slices
     }
-    static const int kc_pref = getenv("PNPFLOW_HIP_KC") ? atoi(getenv("PNPFLOW_HIP_KC")) : 32;
-    static const int kc_l0 = getenv("PNPFLOW_HIP_KC_L0") ? atoi(getenv("PNPFLOW_HIP_KC_L0")) : 32;   // 32-channel layers: one 32-channel chunk reads whole 128-B pixel rows (16-channel chunks: same time, +40 % HBM reads - PMC, profiles/)
-    static const int kc_l1 = getenv("PNPFLOW_HIP_KC_L1") ? atoi(getenv("PNPFLOW_HIP_KC_L1")) : 32;
-    bool all32 = (p.Cout <= 32 ? kc_l0 : p.Cout <= 64 ? kc_l1 : kc_pref) == 32;
+    bool all32 = true;       // 32-channel chunks wherever every segment has whole ones (at the 32-channel level: whole 128-B pixel rows, -30 % HBM reads)
     for (int i = 0; i < p.nseg; ++i) all32 &= p.seg[i].C % 32 == 0;
     if (all_1tap && stride == 1 && !up) return launch_sel16<1, 0, 64, TERMS>(p, stream);
     if (stride == 2) return launch_sel16<2, 0, 16, TERMS>(p, stream);

@@ -168,8 +168,6 @@ struct pf_engine {
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     std::vector<const Op*> ev_ops;   // op of each recorded event pair (profiling detail)
-    unsigned long long* trace_buf = nullptr;   // PNPFLOW_HIP_TRACE: per-launch phase cycle sums of the conv kernel (8 slots per launch)
-    static constexpr size_t TRACE_MAX = 1024, TRACE_SLOTS = 256;
     size_t ev_used = 0;
     int64_t prof_launches = 0; double prof_ms = 0.0, prof_flops = 0.0;
 };
@@ -434,7 +432,6 @@ static ConvParams base_params(int B, int H, int W, int Hs, int Ws, const Tensor&
     ConvParams p{};
     p.B = B; p.H = H; p.W = W; p.Hs = Hs; p.Ws = Ws; p.Cout = out.C; p.out = out.p; p.out_cstride = out.C;
     p.out_scale = 1.0f; p.res_scale = 1.0f; p.stats_out = out.stats; p.gn_eps = 1e-6f;
-    { const char* d = getenv("PNPFLOW_HIP_DBG"); p.dbg = d ? atoi(d) : 0; }
     return p;
 }
 
@@ -464,7 +461,6 @@ static ConvParams with_coef(Builder& bd, ConvParams p, std::vector<Op>& ops) {
     }
     const bool want_scale = bd.e->precision != 0 && packed16 && (raw_stats || p.gn_C > 0);
     if (p.gn_C == 0 && !want_scale) return p;
-    if (getenv("PNPFLOW_HIP_AB_NO_COEF")) return p;      // A/B builds with -DPF_AB_GN_INKERNEL only (tools/ab_variants.sh)
     Op op{}; op.kind = OP_GN_COEF;
     GnCoefParams& g = op.gp;
     g.nseg = p.nseg;
@@ -921,7 +917,6 @@ struct BwdCtx {
 static ConvParams bwd_params(int B, int H, int W, int Hs, int Ws, int Cout) {
     ConvParams p{};
     p.B = B; p.H = H; p.W = W; p.Hs = Hs; p.Ws = Ws; p.Cout = Cout; p.out_scale = 1.0f; p.res_scale = 1.0f; p.gn_eps = 1e-6f;
-    { const char* d = getenv("PNPFLOW_HIP_DBG"); p.dbg = d ? atoi(d) : 0; }
     return p;
 }
 static void raw_seg(ConvParams& p, const float* src, int C, int cstride, int taps, const float* w, const void* w16 = nullptr) {
@@ -1222,9 +1217,6 @@ static hipError_t dispatch_conv(pf_engine* e, const Op& op, hipStream_t s) {
     if (e->precision != 0) {
         bool ok16 = true;
         for (int i = 0; i < op.cp.nseg; ++i) ok16 &= op.cp.seg[i].w_mode == 0 && op.cp.seg[i].w16 != nullptr;
-#ifdef PF_WITH_CONV_WS      // the wave-specialised persistent variant (conv_ws.hip): measured slower on every layer class, debug builds only
-        if (ok16 && e->precision == 1 && conv_ws_supported(op.cp, op.stride, op.up)) return launch_conv_ws(op.cp, s);
-#endif
         if (ok16) return launch_conv16(op.cp, op.stride, op.up, s, e->precision == 2 ? 1 : 3);
     }
     return launch_conv(op.cp, op.stride, op.up, s);
@@ -1259,14 +1251,7 @@ static int run_plan(pf_engine* e, Plan* plan, const float* x, const float* t, fl
                     e->ev_ops[e->ev_used - 1] = &op;
                     if (!prep_open) hipEventRecord(ev.first, s);
                     prep_open = false;
-                    if (getenv("PNPFLOW_HIP_TRACE") && e->ev_used <= pf_engine::TRACE_MAX) {
-                        const size_t tb = pf_engine::TRACE_MAX * pf_engine::TRACE_SLOTS * 64;
-                        if (!e->trace_buf) { hipMalloc(&e->trace_buf, tb); hipMemsetAsync(e->trace_buf, 0, tb, s); }
-                        Op top = op; top.cp.trace = e->trace_buf + (e->ev_used - 1) * pf_engine::TRACE_SLOTS * 8;
-                        r = dispatch_conv(e, top, s);
-                    } else {
-                        r = dispatch_conv(e, op, s);
-                    }
+                    r = dispatch_conv(e, op, s);
                     hipEventRecord(ev.second, s);
                     e->prof_flops += (double)op.flops;
                 } else {
@@ -1927,9 +1912,7 @@ int pf_engine_profile_read(pf_engine* e, int64_t* launches, double* ms_conv_gemm
     if (!e) return PF_ERR_INVALID;
     HIPCHK(e, hipDeviceSynchronize());
     FILE* dump = getenv("PNPFLOW_HIP_PROFILE_CSV") ? fopen(getenv("PNPFLOW_HIP_PROFILE_CSV"), "w") : nullptr;
-    if (dump) fprintf(dump, "idx,H,W,Cout,K,nseg,taps0,stride,up,gflop,us,tflops,dma,alg_mb,wgs,cyc_prologue,cyc_staging,cyc_kloop,cyc_epilogue,cyc_stats\n");
-    std::vector<unsigned long long> tr;
-    if (e->trace_buf) { tr.resize(pf_engine::TRACE_MAX * pf_engine::TRACE_SLOTS * 8); hipMemcpy(tr.data(), e->trace_buf, tr.size() * 8, hipMemcpyDeviceToHost); hipMemset(e->trace_buf, 0, tr.size() * 8); }
+    if (dump) fprintf(dump, "idx,H,W,Cout,K,nseg,taps0,stride,up,gflop,us,tflops,dma,alg_mb\n");
     for (size_t i = 0; i < e->ev_used; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e->ev_pool[i].first, e->ev_pool[i].second) == hipSuccess) { e->prof_ms += ms; e->prof_launches += 1; }
@@ -1941,12 +1924,6 @@ int pf_engine_profile_read(pf_engine* e, int64_t* launches, double* ms_conv_gemm
             for (int j = 0; j < op.cp.nseg; ++j) bytes += (double)op.cp.B * op.cp.Hs * op.cp.Ws * op.cp.seg[j].C * 4.0;
             fprintf(dump, "%zu,%d,%d,%d,%zu,%d,%d,%d,%d,%.4f,%.2f,%.2f,%d,%.3f", i, op.cp.H, op.cp.W, op.cp.Cout, K, op.cp.nseg, op.cp.seg[0].taps,
                     op.stride, op.up, op.flops / 1e9, ms * 1e3, op.flops / (ms * 1e-3) / 1e12, op.dma, bytes / 1e6);
-            if (!tr.empty() && i < pf_engine::TRACE_MAX) {
-                unsigned long long q[8] = {0};
-                for (size_t sl = 0; sl < pf_engine::TRACE_SLOTS; ++sl) for (int k = 0; k < 8; ++k) q[k] += tr[(i * pf_engine::TRACE_SLOTS + sl) * 8 + k];
-                const double n = q[5] ? (double)q[5] : 1.0;
-                fprintf(dump, ",%llu,%.0f,%.0f,%.0f,%.0f,%.0f", q[5], q[0] / n, q[1] / n, q[2] / n, q[3] / n, q[4] / n);
-            }
             fprintf(dump, "\n");
         }
     }

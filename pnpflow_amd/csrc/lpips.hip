@@ -84,9 +84,11 @@ __global__ __launch_bounds__(256) void lp_maxpool_kernel(const float* __restrict
     out[i] = m;
 }
 
-// out[b] += (1 / HW) * sum_pixels sum_c lin[c] * (f0 / (|f0| + eps) - f1 / (|f1| + eps))^2      (one thread per pixel, block-reduced)
+// part[b * nparts + part_off + block] = (1 / HW) * sum over the block's pixels of sum_c lin[c] * (f0 / (|f0| + eps) - f1 / (|f1| + eps))^2
+// (one thread per pixel, block-reduced).  The per-block partials of the five layers are summed in a FIXED order by lp_sum_kernel: the
+// value of an image is bit-reproducible between runs and between 1-rank and N-rank jobs (a float atomicAdd across blocks is not).
 __global__ __launch_bounds__(256) void lp_head_kernel(const float* __restrict__ f0, const float* __restrict__ f1, const float* __restrict__ lin,
-                                                     float* __restrict__ out, int C, int HW) {
+                                                     float* __restrict__ part, int nparts, int part_off, int C, int HW) {
     __shared__ float s_red[4];
     const int b = blockIdx.y;
     const int pix = blockIdx.x * 256 + threadIdx.x;
@@ -102,7 +104,15 @@ __global__ __launch_bounds__(256) void lp_head_kernel(const float* __restrict__ 
     for (int o = 32; o > 0; o >>= 1) val += __shfl_xor(val, o);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = val;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out + b, (s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (float)HW);
+    if (threadIdx.x == 0) part[(size_t)b * nparts + part_off + blockIdx.x] = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (float)HW;
+}
+
+__global__ void lp_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float acc = 0.0f;
+    for (int i = 0; i < nparts; ++i) acc += part[(size_t)b * nparts + i];
+    out[b] = acc;
 }
 
 }  // namespace pf
@@ -117,6 +127,7 @@ struct pf_lpips {
     std::vector<void*> allocs;
     float* buf[2][7] = {{nullptr}};                  // per side: scaled input, f1, p1, f2, p2, f3..f5 share by ping-pong (see forward)
     size_t cap = 0;                                  // floats per activation buffer
+    float* part = nullptr; size_t part_cap = 0;      // per-block partial sums of the five heads
 };
 
 namespace {
@@ -186,12 +197,21 @@ int pf_lpips_forward(pf_lpips* l, const float* img0, const float* img1, float* o
     const int ch[8] = {3, 64, 64, 192, 192, 384, 256, 256};
     size_t need = 0;
     for (int i = 0; i < 8; ++i) need = std::max(need, (size_t)B * ch[i] * h[i] * w[i]);
+    auto drop = [&](float*& p) {                     // free + forget: a failed regrow must leave nothing stale behind (no double free later)
+        if (!p) return;
+        hipFree(p);
+        auto it = std::find(l->allocs.begin(), l->allocs.end(), (void*)p);
+        if (it != l->allocs.end()) l->allocs.erase(it);
+        p = nullptr;
+    };
     if (need > l->cap) {
         hipStreamSynchronize(s);
+        l->cap = 0;
+        for (int side = 0; side < 2; ++side)
+            for (int i = 0; i < 7; ++i) drop(l->buf[side][i]);
         for (int side = 0; side < 2; ++side)
             for (int i = 0; i < 7; ++i) {
-                if (l->buf[side][i]) { hipFree(l->buf[side][i]); l->allocs.erase(std::find(l->allocs.begin(), l->allocs.end(), (void*)l->buf[side][i])); }
-                if (hipMalloc(&l->buf[side][i], need * sizeof(float)) != hipSuccess) { l->err = "hipMalloc failed (activations)"; return PF_ERR_HIP; }
+                if (hipMalloc(&l->buf[side][i], need * sizeof(float)) != hipSuccess) { l->buf[side][i] = nullptr; l->err = "hipMalloc failed (activations)"; return PF_ERR_HIP; }
                 l->allocs.push_back(l->buf[side][i]);
             }
         l->cap = need;
@@ -221,12 +241,22 @@ int pf_lpips_forward(pf_lpips* l, const float* img0, const float* img1, float* o
         conv(4, bf[6], bf[0], h[6], w[6], h[7], w[7]);
         f[side][0] = bf[1]; f[side][1] = bf[3]; f[side][2] = bf[5]; f[side][3] = bf[6]; f[side][4] = bf[0];
     }
-    if (hipMemsetAsync(out, 0, (size_t)B * sizeof(float), s) != hipSuccess) return PF_ERR_HIP;
     const int fh[5] = {h[1], h[3], h[5], h[6], h[7]}, fw[5] = {w[1], w[3], w[5], w[6], w[7]};
+    int nparts = 0, poff[5];
+    for (int k = 0; k < 5; ++k) { poff[k] = nparts; nparts += (fh[k] * fw[k] + 255) / 256; }
+    if ((size_t)B * nparts > l->part_cap) {
+        hipStreamSynchronize(s);
+        l->part_cap = 0;
+        drop(l->part);
+        if (hipMalloc(&l->part, (size_t)B * nparts * sizeof(float)) != hipSuccess) { l->part = nullptr; l->err = "hipMalloc failed (partials)"; return PF_ERR_HIP; }
+        l->allocs.push_back(l->part);
+        l->part_cap = (size_t)B * nparts;
+    }
     for (int k = 0; k < 5; ++k) {
         const int HW = fh[k] * fw[k];
-        hipLaunchKernelGGL(lp_head_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, s, f[0][k], f[1][k], l->w.at("lin" + std::to_string(k)), out, LAYERS[k].Co, HW);
+        hipLaunchKernelGGL(lp_head_kernel, dim3((HW + 255) / 256, B), dim3(256), 0, s, f[0][k], f[1][k], l->w.at("lin" + std::to_string(k)), l->part, nparts, poff[k], LAYERS[k].Co, HW);
     }
+    hipLaunchKernelGGL(lp_sum_kernel, dim3((B + 63) / 64), dim3(64), 0, s, l->part, out, nparts, B);
     if (hipGetLastError() != hipSuccess) { l->err = "LPIPS kernel launch failed"; return PF_ERR_HIP; }
     return PF_OK;
 }

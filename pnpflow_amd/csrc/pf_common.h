@@ -79,9 +79,7 @@ struct ConvParams {
     const float* gnb_gamma; const float* gnb_beta;    // [gnb_Ct]
     int gnb_Ct, gnb_coff, gnb_silu;
     double* gnb_sum;             // [B][gnb_Ct][2] += (sum dyhat, sum dyhat*yhat)
-    unsigned long long* trace;   // profiling only: per-launch phase cycle sums [prologue, staging, k-loop, epilogue, stats, workgroups], or nullptr
     int xcd_map;          // split-fp16 kernel, set by its launcher: 1 = workgroup -> (tile, N-block) mapping that keeps neighbouring tiles and the N-blocks of a tile on one XCD
-    int dbg;              // ablation switches for profiling (0 in production): 1 skip MFMAs, 2 skip re-staging, 4 skip LDS A reads, 8 skip B loads, 16 skip epilogue global traffic
 };
 
 constexpr int CONV_KC = 16;   // channels per K-chunk staged in LDS
@@ -143,8 +141,6 @@ size_t conv_dma_a16_bytes(int B, int C, int Hs, int Ws, int terms);
 
 hipError_t launch_conv(const ConvParams& p, int stride, int up, hipStream_t s);
 hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t s, int terms = 3);   // split-fp16 MFMA variant (terms 3) / single fp16 MFMA (terms 1)
-bool conv_ws_supported(const ConvParams& p, int stride, int up);
-hipError_t launch_conv_ws(const ConvParams& p, hipStream_t s);                     // wave-specialised persistent split-fp16 variant (conv_ws.hip)
 size_t conv_flops(const ConvParams& p);
 hipError_t launch_begin_conv(const EdgeConvParams& p, hipStream_t s);
 hipError_t launch_end_conv(const EdgeConvParams& p, hipStream_t s);

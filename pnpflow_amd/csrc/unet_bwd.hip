@@ -129,14 +129,9 @@ __global__ __launch_bounds__(256) void gn_bwd_post_kernel(const float* __restric
     const float4 r4 = *reinterpret_cast<const float4*>(rs + (size_t)b * Ct + cg);
     const float4 a4 = *reinterpret_cast<const float4*>(m1 + (size_t)b * Ct + cg);
     const float4 b4 = *reinterpret_cast<const float4*>(m2 + (size_t)b * Ct + cg);
-#ifndef PF_POST_UNR
-#define PF_POST_UNR 4
-#endif
-#ifndef PF_POST_NT
-#define PF_POST_NT 1          // dy (read once, dead afterwards) through non-temporal loads, the result through non-temporal stores: -0.6 % on the
-                              // 256^2 VJP, twice on one box (profiles/r03_ab_gn_bwd_post.txt); unroll depth 2 / 4 / 8: no difference
-#endif
-    constexpr int UNR = PF_POST_UNR;
+    // dy (read once, dead afterwards) through non-temporal loads, the result through non-temporal stores: -0.6 % on the 256^2 VJP, twice
+    // on one box (profiles/r03_ab_gn_bwd_post.txt); unroll depth 2 / 4 / 8: no difference
+    constexpr int UNR = 4;
     for (int pix = p0 + pr; pix < p1; pix += lanes_p * UNR) {
         float4 xv[UNR], dv[UNR], av[UNR], ov[UNR];
 #pragma unroll
@@ -144,12 +139,8 @@ __global__ __launch_bounds__(256) void gn_bwd_post_kernel(const float* __restric
             const int pk = min(pix + k * lanes_p, p1 - 1);
             const size_t o = ((size_t)b * HW + pk) * C + q * 4;
             xv[k] = *reinterpret_cast<const float4*>(x + o);
-#if PF_POST_NT
             { typedef float f4v __attribute__((ext_vector_type(4)));
               const f4v t_ = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(dy + o)); dv[k] = make_float4(t_.x, t_.y, t_.z, t_.w); }
-#else
-            dv[k] = *reinterpret_cast<const float4*>(dy + o);
-#endif
             if constexpr (HAS_ADD) av[k] = *reinterpret_cast<const float4*>(add + o);
             if constexpr (ACC) ov[k] = *reinterpret_cast<const float4*>(out + o);
         }
@@ -163,12 +154,8 @@ __global__ __launch_bounds__(256) void gn_bwd_post_kernel(const float* __restric
                 r.w = r4.w * (dv[k].w - a4.w - (xv[k].w - m4.w) * r4.w * b4.w);
                 if constexpr (HAS_ADD) { r.x = fmaf(av[k].x, add_scale, r.x); r.y = fmaf(av[k].y, add_scale, r.y); r.z = fmaf(av[k].z, add_scale, r.z); r.w = fmaf(av[k].w, add_scale, r.w); }
                 if constexpr (ACC) { r.x += ov[k].x; r.y += ov[k].y; r.z += ov[k].z; r.w += ov[k].w; }
-#if PF_POST_NT
                 { typedef float f4v __attribute__((ext_vector_type(4)));
                   f4v t_ = {r.x, r.y, r.z, r.w}; __builtin_nontemporal_store(t_, reinterpret_cast<f4v*>(out + ((size_t)b * HW + pix + k * lanes_p) * C + q * 4)); }
-#else
-                *reinterpret_cast<float4*>(out + ((size_t)b * HW + pix + k * lanes_p) * C + q * 4) = r;
-#endif
             }
         }
     }
@@ -195,12 +182,10 @@ hipError_t launch_gn_bwd_coeffs(const double* bsum, int Ct, int cpg, int HW, flo
 hipError_t launch_gn_bwd_post(const float* dy, const float* x, const float* mu, const float* rs, const float* m1, const float* m2,
                               const float* add, float* out, int B, int HW, int C, int coff, int Ct, int accumulate, hipStream_t s, float add_scale) {
     if (C % 4 || C / 4 > 256) return hipErrorInvalidValue;
-    static const int ppb_env = getenv("PNPFLOW_HIP_POST_PPB") ? atoi(getenv("PNPFLOW_HIP_POST_PPB")) : 0;
     // pixels per workgroup: >= 8 workgroups per CU where the tensor allows it (1024 left the second wave of workgroups 60 % full at
     // 256^2: C5 5.27 -> 5.54 images/s with 256, profiles/r02_ab_variants_same_box.txt)
     int ppb = 256;
     while (ppb > 64 && (long)((HW + ppb - 1) / ppb) * B < 2048) ppb >>= 1;
-    if (ppb_env > 0) ppb = ppb_env;
     const dim3 grid((HW + ppb - 1) / ppb, B);
     if (add != nullptr && accumulate) hipLaunchKernelGGL((gn_bwd_post_kernel<true, true>), grid, dim3(256), 0, s, dy, x, mu, rs, m1, m2, add, out, HW, C, coff, Ct, ppb, add_scale);
     else if (add != nullptr) hipLaunchKernelGGL((gn_bwd_post_kernel<true, false>), grid, dim3(256), 0, s, dy, x, mu, rs, m1, m2, add, out, HW, C, coff, Ct, ppb, add_scale);

@@ -103,9 +103,13 @@ class LPIPS:
         if not in0.is_cuda:
             raise _lib.PnpFlowHipError("LPIPS needs GPU tensors (there is no CPU path)")
         a = in0.contiguous().float(); b = in1.to(a.device).contiguous().float()
+        if b.shape != a.shape:
+            raise ValueError("LPIPS expects two tensors of one shape")
+        if a.shape[1] == 1:          # lpips' ScalingLayer broadcasts a 1-channel image over its three channel constants: grayscale inputs are legal there
+            a = a.expand(-1, 3, -1, -1).contiguous(); b = b.expand(-1, 3, -1, -1).contiguous()
         B, Cc, H, W = a.shape
-        if Cc != 3 or b.shape != a.shape:
-            raise ValueError("LPIPS expects two (B, 3, H, W) tensors")
+        if Cc != 3:
+            raise ValueError("LPIPS expects (B, 3, H, W) or (B, 1, H, W) tensors")
         out = torch.empty(B, dtype=torch.float32, device=a.device)
         if B == 0:
             return out

@@ -27,6 +27,11 @@ def rank_world(group=None) -> Tuple[int, int]:
     return 0, 1
 
 
+def force_collectives() -> bool:
+    import os
+    return os.environ.get("PNPFLOW_DIST_FORCE", "0") == "1"
+
+
 def init_from_env(device_index=None):
     """torchrun entry: joins the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (backend "nccl" = RCCL on ROCm,
     one process per GPU) and returns (rank, world, local_rank).  A plain `python main.py` run returns (0, 1, 0) untouched."""
@@ -40,8 +45,13 @@ def init_from_env(device_index=None):
     backend = os.environ.get("PNPFLOW_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
-    if world > 1 and not dist.is_initialized():
+    # PNPFLOW_DIST_FORCE=1: a one-rank job joins a process group too and executes its collectives (the RCCL path on a 1-GPU box)
+    if (world > 1 or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0)); os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
@@ -74,7 +84,7 @@ def global_measurement_noise(batch: int, global_shape, lo: int, hi: int) -> torc
 def gather_in_image_order(local: torch.Tensor, group=None) -> torch.Tensor:
     """all_gather of a per-image vector; equal shard sizes are not required."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force_collectives()):
         return local
     world = dist.get_world_size(group)
     if dist.get_backend(group) == "gloo" and local.is_cuda:      # gloo collectives run on host tensors

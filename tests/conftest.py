@@ -54,3 +54,22 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"))
     return load
+
+
+@pytest.fixture(scope="session")
+def thirdparty():
+    """Fixtures written by tools/pin_thirdparty.py FROM the third-party packages the reference's metrics / masks live in (ignite, lpips +
+    torchvision, cv2).  None of them is in this image: until someone runs the tool where they are, the rows stay unpinned and say so."""
+    def load(name, package):
+        path = os.path.join(GOLDEN, f"thirdparty_{name}.npz")
+        if not os.path.isfile(path):
+            pytest.skip(f"parity unpinned: tests/golden/thirdparty_{name}.npz absent - run `python tools/pin_thirdparty.py` where {package} is installed")
+        return np.load(path)
+    return load
+
+
+def thirdparty_pair(shape, seed):
+    """(clean, degraded) of tools/pin_thirdparty.py."""
+    a = det_normal(shape, seed).clamp(-1, 1)
+    b = (a + 0.1 * det_normal(shape, seed + 1)).clamp(-1, 1)
+    return a, b

@@ -1041,6 +1041,40 @@ def test_bench_two_ranks_reproduce_the_single_process_run(hip):
     assert abs(two["psnr_db"] - one["psnr_db"]) < 2e-3, (two["psnr_db"], one["psnr_db"])
 
 
+def test_rccl_executes_the_job_collectives_on_one_gpu(hip):
+    """RCCL itself (torch.distributed backend "nccl"), executed on the hardware there is: a ONE-rank process group on cuda:0 runs
+    exactly the collectives of the N > 1 job on device tensors - `bench.py --force-dist` (barrier, all_reduce(MAX) of the step time,
+    all_gather of the per-image PSNR: bench.py main()) and `parallel.gather_in_image_order` under PNPFLOW_DIST_FORCE=1 (the two
+    all_gathers of the metric path).  The line says which library carried them (`collective_backend`, `rccl_version`)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("PNPFLOW_DIST_BACKEND", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MASTER_ADDR"] = "127.0.0.1"
+    args = [sys.executable, "bench.py", "--workload", "tiny", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extra", "--batch", "4"]
+    forced = subprocess.run(args + ["--force-dist"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert forced.returncode == 0, forced.stderr[-2000:]
+    line = json.loads(forced.stdout.strip().splitlines()[-1])
+    assert line["collective_backend"].startswith("rccl") and line["ranks_in_job"] == 1 and line["rccl_version"], line
+    plain = subprocess.run(args, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    assert abs(json.loads(plain.stdout.strip().splitlines()[-1])["psnr_db"] - line["psnr_db"]) < 1e-6
+    # the metric gather of the solvers (utils.compute_average_* -> parallel.gather_in_image_order) through RCCL, in a child process
+    code = ("import os, torch, torch.distributed as dist\n"
+            "os.environ['PNPFLOW_DIST_FORCE'] = '1'\n"
+            "from pnpflow_amd import parallel\n"
+            "rank, world, local = parallel.init_from_env()\n"
+            "assert dist.is_initialized() and dist.get_backend() == 'nccl' and world == 1\n"
+            "v = torch.arange(5, dtype=torch.float32, device='cuda') * 1.5\n"
+            "g = parallel.gather_in_image_order(v)\n"
+            "assert g.is_cuda and torch.equal(g, v)\n"
+            "assert parallel.gather_in_image_order(v[:0]).numel() == 0\n"
+            "assert abs(parallel.mean_psnr(v) - 3.0) < 1e-12\n"
+            "dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group()\n"
+            "print('RCCL_OK', '.'.join(map(str, torch.cuda.nccl.version())))\n")
+    child = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert child.returncode == 0 and "RCCL_OK" in child.stdout, child.stderr[-2000:]
+
+
 def test_main_two_ranks_write_the_single_process_result_files(hip, tmp_path):
     """main.py under torchrun (synthetic opt-in: no checkpoint / dataset offline): rank 0 writes the reference's result files
     for the GLOBAL batches, equal (PSNR to 1e-3 dB) to the single-process run's."""
@@ -1213,6 +1247,81 @@ def test_first_outer_iterations_of_baseline_configs(hip, golden, tag):
     _crops_close(its[1], g, "x_it1", 1e-4)
 
 
+def biglong_cases():
+    import pnpflow_amd.degradations as D
+    return {"c2": ("celeba128", "inpainting", lambda S: D.BoxInpainting(20)),
+            "c3": ("celeba128", "gaussian_deblurring_FFT", lambda S: D.GaussianDeblurring(1.0, 61, "fft", 3, S)),
+            "c4": ("afhq256", "superresolution", lambda S: D.Superresolution(4, S)),
+            "c2_256": ("afhq256", "inpainting", lambda S: D.BoxInpainting(40))}
+
+
+@pytest.mark.parametrize("tag", ["c2", "c3", "c4", "c2_256"])
+@pytest.mark.parametrize("precision", [1, 2])
+def test_full_length_recursion_on_the_baseline_nets(hip, golden, tag, precision):
+    """the shipped recursion (100 outer iterations x 5 samples, pnp_flow.py:103-121) of the REAL reference on the
+    `define_model` nets (utils.py:170-180: 54 ResBlocks, 34.5 M / 31.0 M parameters) with BASELINE configs[1..3]'s own operator
+    parameters and on the headline workload of bench.py (256^2, BoxInpainting(40), main.py:132-136), B = 1 - 500 sequential U-Net
+    evaluations deep.  Default mode: crops + whole-tensor checksums of iterates 0 / 10 / 50 / 99 and the final PSNR within 0.05 dB;
+    precision mode 2 (one f16 MFMA per product): the final PSNR within the north_star's 0.05 dB on the same fixtures."""
+    from pnpflow_amd.utils import psnr_per_image
+    net, problem, mk = biglong_cases()[tag]
+    g = golden("pnp_biglong_" + tag)
+    m, cfg, sd = model_for(net)
+    S, Cc, B, sigma = cfg["input_height"], 3, int(g["B"]), float(g["sigma"])
+    steps, ns = int(g["steps"]), int(g["num_samples"])
+    assert (steps, ns, B) == (100, 5, 1)
+    try:
+        solver, args = _pnp_solver(m, problem, steps, ns, float(g["alpha"]), precision, B, Cc, S)
+        args.sigma_noise = sigma
+        its = {}
+        x = solver.restore_batch(torch.from_numpy(g["noisy"]).cuda(), mk(S), sigma, lr=sigma ** 2 * 1.0,
+                                 iter_cb=lambda it, xx: its.__setitem__(it, xx.clone().cpu()), cb_iterations=[0, 10, 50, 99])
+    finally:
+        m.set_precision(1)
+    clean = det_image((B, Cc, S, S), 31)
+    p_hip = psnr_per_image(x, clean.cuda()).cpu()
+    p_ref = O.psnr_per_image(torch.from_numpy(g["x_final"]), clean)
+    np.testing.assert_allclose(p_ref.numpy(), g["psnr_final"], atol=1e-4)
+    assert float((p_hip - p_ref).abs().max()) <= 0.05, (tag, precision, p_hip, p_ref)
+    if precision == 1:
+        for it in (0, 10, 50, 99):
+            _crops_close(its[it], g, f"x_it{it}", 1e-3, rtol_sum=1e-4)
+        np.testing.assert_allclose(x.cpu().numpy(), g["x_final"], atol=1e-3)
+
+
+@pytest.mark.parametrize("precision", [1, 2])
+def test_c5_all_90_euler_steps_on_its_own_net(hip, golden, precision):
+    """BASELINE configs[4] end to end against the REAL reference (ot_ode.py:63-147): afhq256 net, RandomInpainting(0.7), sigma 0.01,
+    steps_ode 100, start_time 0.1 - all 90 Euler steps (retained forward + hand-written VJP each), B = 1.  First iterate 1e-3
+    relative, final PSNR within 0.05 dB in the default mode and in precision mode 2."""
+    import pnpflow_amd.degradations as D
+    from pnpflow_amd.methods.ot_ode import OT_ODE
+    from pnpflow_amd.utils import CfgNode, psnr_per_image
+    g = golden("ot_ode_biglong_c5")
+    m, cfg, sd = model_for("afhq256")
+    S, Cc, B, sigma = 256, 3, int(g["B"]), float(g["sigma"])
+    args = CfgNode(dict(method="ot_ode", model="ot", problem="random_inpainting", steps_ode=100, start_time=0.1, gamma="constant", max_batch=1,
+                        compute_time=False, compute_memory=False, save_results=False, batch=0))
+    m.set_precision(precision)
+    try:
+        solver = OT_ODE(m, torch.device("cuda"), args)
+        degradation = D.RandomInpainting(0.7)
+        y = torch.from_numpy(g["noisy"]).cuda()
+        solver.init_noise = det_normal(tuple(degradation.H_adj(y).shape), 61, 1).cuda()
+        its = {}
+        x = solver.restore_batch(y, degradation, sigma, iter_cb=lambda it, xx: its.__setitem__(it, xx.clone().cpu()), cb_iterations=[10, 50, 99])
+    finally:
+        m.set_precision(1)
+    clean = det_image((B, Cc, S, S), 31)
+    d = (psnr_per_image(x, clean.cuda()).cpu() - O.psnr_per_image(torch.from_numpy(g["x_final"]), clean)).abs().max()
+    assert float(d) <= 0.05, d
+    if precision == 1:
+        ref = g["x_it10_crop"]
+        H = S
+        got = its[10][:, :, H // 2 - 16:H // 2 + 16, H // 2 - 16:H // 2 + 16].numpy()
+        np.testing.assert_allclose(got, ref, atol=1e-3 * float(np.abs(ref).max()), err_msg="iterate 10")
+
+
 @pytest.mark.parametrize("tag,problem,sigma", [("tiny4_random_inpainting", "random_inpainting", 0.01), ("tiny4_superresolution", "superresolution", 0.05)])
 def test_ot_ode_90_steps_match_reference(hip, golden, tag, problem, sigma):
     """steps_ode = 100, start_time = 0.1: the 90 Euler steps the C5 configuration runs (ot_ode.py:63-147), against the real reference:
@@ -1359,7 +1468,7 @@ def _lpips_model(seed=0):
     return LPIPS("alex").load_state_dict(sd), sd
 
 
-@pytest.mark.parametrize("shape", [(3, 3, 128, 128), (2, 3, 256, 256), (2, 3, 64, 96)])
+@pytest.mark.parametrize("shape", [(3, 3, 128, 128), (2, 3, 256, 256), (2, 3, 64, 96), (2, 1, 64, 64)])
 def test_lpips_matches_oracle(hip, shape):
     """csrc/lpips.hip (direct fp32 convs of the AlexNet feature stack, max-pools, unit-normalise / diff / 1x1 heads / spatial mean)
     against the oracle's torch restatement of lpips.LPIPS(net='alex'), weights loaded under the published key names; with and
@@ -1372,6 +1481,8 @@ def test_lpips_matches_oracle(hip, shape):
         assert float(ref.min()) > 1e-4
         np.testing.assert_allclose(out.numpy(), ref.numpy(), rtol=2e-4, atol=1e-6, err_msg=f"normalize={normalize}")
     assert float(m(a.cuda(), a.cuda(), normalize=True).abs().max()) == 0.0          # identical images: distance exactly 0
+    r1 = m(a.cuda(), b.cuda(), normalize=True); r2 = m(a.cuda(), b.cuda(), normalize=True)
+    assert torch.equal(r1, r2)                                                        # fixed summation order: bit-reproducible
 
 
 def test_lpips_accepts_the_published_state_dict_layouts(hip):
@@ -1463,3 +1574,32 @@ def test_conv_dma_path_is_selected_at_the_solver_batch_and_bit_identical(hip, tm
     assert len(rows) == 142 and 30 <= len(dma_rows) <= 80, (len(rows), len(dma_rows))
     assert all(int(r["Cout"]) % 128 == 0 for r in dma_rows)
     assert any(int(r["up"]) == 1 for r in dma_rows) and any(int(r["taps0"]) == 1 and int(r["Cout"]) == 768 for r in dma_rows)
+
+
+# ---------------------------------------------------------------------------------------------
+# third-party pins (tools/pin_thirdparty.py): run when the fixtures exist, otherwise skipped as "parity unpinned"
+# ---------------------------------------------------------------------------------------------
+def test_engine_ssim_matches_thirdparty_ssim(hip, thirdparty):
+    """pf_ssim vs ignite.metrics.SSIM(data_range=1.0) itself (pnpflow/utils.py:780-816)."""
+    from conftest import thirdparty_pair
+    from pnpflow_amd.utils import ssim_per_image
+    g = thirdparty("ssim", "pytorch-ignite")
+    for i, shape in enumerate(g["shapes"]):
+        a, b = thirdparty_pair(tuple(int(v) for v in shape), int(g["seed"]))
+        got = ssim_per_image(b.cuda(), a.cuda()).double().cpu().numpy()
+        np.testing.assert_allclose(got, g[f"per_image_{i}"], atol=2e-5)
+        np.testing.assert_allclose(got.mean(), float(g[f"batch_{i}"]), atol=2e-5)
+
+
+def test_engine_lpips_matches_thirdparty_lpips(hip, thirdparty):
+    """pf_lpips_forward vs lpips.LPIPS(net='alex')(a, b, normalize=True) on the published weights carried by the fixture
+    (pnpflow/utils.py:677-724); bound = the north_star's +-1e-3."""
+    from conftest import thirdparty_pair
+    from pnpflow_amd.lpips import LPIPS
+    g = thirdparty("lpips", "lpips + torchvision")
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w::")}
+    net = LPIPS("alex").load_state_dict(sd)
+    for i, shape in enumerate(g["shapes"]):
+        a, b = thirdparty_pair(tuple(int(v) for v in shape), int(g["seed"]))
+        got = net(a.cuda(), b.cuda(), normalize=True).double().cpu().numpy()
+        np.testing.assert_allclose(got, g[f"d_{i}"], atol=1e-3)

@@ -404,3 +404,53 @@ def test_first_outer_iterations_of_baseline_configs_match_reference(golden, tag,
     _check_crops(y, g, "noisy", 1e-6)
     _check_crops(its[0], g, "x_it0", 5e-5)
     _check_crops(its[1], g, "x_it1", 5e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# third-party pins (tools/pin_thirdparty.py): picked up when present, "unpinned" in the skip reason otherwise
+# ---------------------------------------------------------------------------------------------
+def test_oracle_ssim_matches_thirdparty_ssim(thirdparty):
+    """oracle SSIM vs ignite.metrics.SSIM(data_range=1.0) itself (pnpflow/utils.py:780-816)."""
+    from conftest import thirdparty_pair
+    g = thirdparty("ssim", "pytorch-ignite")
+    for i, shape in enumerate(g["shapes"]):
+        a, b = thirdparty_pair(tuple(int(v) for v in shape), int(g["seed"]))
+        got = O.ssim_per_image(b, a).double().numpy()
+        np.testing.assert_allclose(got, g[f"per_image_{i}"], atol=2e-5)
+        np.testing.assert_allclose(got.mean(), float(g[f"batch_{i}"]), atol=2e-5)
+
+
+def test_oracle_lpips_matches_thirdparty_lpips(thirdparty):
+    """oracle LPIPS vs lpips.LPIPS(net='alex')(a, b, normalize=True) on the published weights (pnpflow/utils.py:677-724; north_star +-1e-3)."""
+    from conftest import thirdparty_pair
+    g = thirdparty("lpips", "lpips + torchvision")
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w::")}
+    from pnpflow_amd.lpips import canonical_state_dict
+    sd = canonical_state_dict(sd)
+    for i, shape in enumerate(g["shapes"]):
+        a, b = thirdparty_pair(tuple(int(v) for v in shape), int(g["seed"]))
+        np.testing.assert_allclose(O.lpips_forward(sd, a, b, normalize=True).double().numpy(), g[f"d_{i}"], atol=1e-4)
+
+
+def test_paintbrush_raster_matches_thirdparty_paintbrush(thirdparty):
+    """product and oracle rasters vs cv2.line itself on the reference's seeded stroke sequence (pnpflow/utils.py:339-350, :904-969): bit-exact."""
+    from pnpflow_amd.degradations import paintbrush_masks
+    g = thirdparty("paintbrush", "opencv-python")
+    for i, (B, H, W) in enumerate(g["shapes"]):
+        np.testing.assert_array_equal(paintbrush_masks(int(B), int(H), int(W)), g[f"keep_{i}"])
+        np.testing.assert_array_equal(O.paintbrush_mask_array(int(B), int(H), int(W)), g[f"keep_{i}"])
+
+
+def test_biglong_fixtures_are_consistent_with_the_oracle_pieces(golden):
+    """The B = 1 full-length fixtures of the BASELINE nets (tools/make_golden.py biglong): the stored measurement is the oracle's
+    operator applied to the recipe image + the recipe noise, and the stored PSNR is the oracle's PSNR of the stored final iterate
+    (the 500-evaluation recursion itself is followed on the GPU: tests/test_gpu_parity.py)."""
+    from conftest import det_image, det_normal
+    cases = {"c2": (128, O.BoxInpainting(20)), "c2_256": (256, O.BoxInpainting(40)), "c4": (256, O.Superresolution(4, 256))}
+    for tag, (S, deg) in cases.items():
+        g = golden("pnp_biglong_" + tag)
+        clean = det_image((1, 3, S, S), 31)
+        y = deg.H(clean)
+        y = y + float(g["sigma"]) * det_normal(tuple(y.shape), 41, 0)
+        np.testing.assert_allclose(y.numpy(), g["noisy"], atol=1e-6, err_msg=tag)
+        np.testing.assert_allclose(O.psnr_per_image(torch.from_numpy(g["x_final"]), clean).numpy(), g["psnr_final"], atol=1e-4)

@@ -94,7 +94,10 @@ def audit_kernel(name, lines):
                 if scratch: bad.append(f"scratch access: {ln}")
                 if touched & pend: bad.append(f"pending asm-load register touched (+{pc}): {ln}")
             pc += 1
-        if len(bad) > 20 or n_states > 20000: break
+        if len(bad) > 20: break
+        if n_states > 20000:
+            bad.append("state cap reached before the walk finished: coverage is partial")      # a correctness gate must not fail open
+            break
     n_loads = sum(1 for p in prog if p[0] == "asmload"); n_waits = sum(1 for p in prog if p[0] == "asmwait")
     bad = sorted(set(bad))
     for b in bad[:12]: print(f"{name}: {b}")
@@ -110,8 +113,9 @@ def audit(path):
         if m:
             cur = []; kernels[m.group(1)] = cur; continue
         if cur is not None:
-            cur.append(ln)
-            if "s_endpgm" in ln: cur = None
+            # the body ends at the function-end marker, not at the first s_endpgm: code behind an early exit is audited as well
+            if re.match(r"^\.Lfunc_end\d+:", ln) or ln.lstrip().startswith(".size"): cur = None
+            else: cur.append(ln)
     if not kernels:
         print("no conv_dma_kernel found"); return 1
     return 1 if sum(audit_kernel(n, l) for n, l in kernels.items()) else 0

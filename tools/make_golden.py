@@ -409,6 +409,66 @@ def gen_long(models, degr, utils, pnp):
         print("ot_ode long", tag, float(iterates[99].abs().mean()))
 
 
+def gen_biglong(models, degr, utils, pnp, only=None):
+    """Full-length recursions of the real solvers on the BASELINE nets (pnp_flow.py:103-121, ot_ode.py:63-147), B = 1:
+      pnp_biglong_c2      celeba128 net, BoxInpainting(20), sigma 0.05, alpha 0.5, 100 x 5          (BASELINE configs[1])
+      pnp_biglong_c3      celeba128 net, Gaussian blur sigma 1 (61 taps), sigma 0.05, alpha 0.01    (configs[2])
+      pnp_biglong_c4      afhq256 net, superresolution x4, sigma 0.05, alpha 0.3                     (configs[3])
+      pnp_biglong_c2_256  afhq256 net, BoxInpainting(40) - the headline workload of bench.py (main.py:132-136 at 256^2)
+      ot_ode_biglong_c5   afhq256 net, RandomInpainting(0.7), sigma 0.01, steps_ode 100, start_time 0.1: all 90 Euler steps (configs[4])
+    Stored: crops + float64 checksums of the logged iterates, the final iterate in full, the measurement in full."""
+    import pnpflow.methods.ot_ode as ot
+    big = [("c2", "celeba128", "inpainting", lambda S: (degr.BoxInpainting(20), 0.05), 0.5),
+           ("c3", "celeba128", "gaussian_deblurring_FFT", lambda S: (degr.GaussianDeblurring(1.0, 61, "fft", 3, S, "cpu"), 0.05), 0.01),
+           ("c4", "afhq256", "superresolution", lambda S: (degr.Superresolution(4, S, device="cpu"), 0.05), 0.3),
+           ("c2_256", "afhq256", "inpainting", lambda S: (degr.BoxInpainting(40), 0.05), 0.5)]
+    for tag, net, problem, mk, alpha in big:
+        if only is not None and tag not in only:
+            continue
+        its, _, clean, sigma, args, ncalls = _run_pnp(models, degr, utils, pnp, net, problem, mk, alpha, 1, 100, 5)
+        assert ncalls == 1 + 500 and 99 in its
+        rec = dict(steps=np.array(100), num_samples=np.array(5), alpha=np.array(alpha), sigma=np.array(sigma), B=np.array(1),
+                   noisy=its["noisy"].numpy(), x_final=its[99].numpy(), psnr_final=O.psnr_per_image(its[99], clean).numpy())
+        for it in (0, 10, 50, 99):
+            rec.update(crop_rec(f"x_it{it}", its[it]))
+        np.savez_compressed(os.path.join(OUT, f"pnp_biglong_{tag}.npz"), **rec)
+        print("biglong", tag, float(its[99].abs().mean()), rec["psnr_final"], flush=True)
+    if only is None or "c5" in only:
+        m, cfg, sd = build_ref_unet(models, "afhq256")
+        S, B, sigma = 256, 1, 0.01
+        degradation = degr.RandomInpainting(0.7)
+        clean = det_image((B, 3, S, S), 31)
+        args = utils.CfgNode(dict(method="ot_ode", model="ot", dataset="afhq_cat", problem="random_inpainting", steps_ode=100, start_time=0.1,
+                                  gamma="constant", max_batch=1, compute_time=False, compute_memory=False, save_results=True, batch=0,
+                                  save_path_ip="/tmp"))
+        iterates = {}; seq = {"n": 0}
+
+        def fake_randn_like(like, **kw):
+            i = seq["n"]; seq["n"] += 1
+            return det_normal(tuple(like.shape), 61, i)        # call 0: measurement noise, call 1: initialisation noise
+
+        def cap_psnr(clean_img, noisy_img, rec_img, a, H_adj, iter="final"):
+            iterates.setdefault(int(iter), rec_img.clone()); iterates["noisy"] = noisy_img.clone()
+        noop = lambda *a, **k: None
+        saved = (torch.randn_like, utils.compute_psnr, utils.compute_ssim, utils.compute_lpips, utils.save_images,
+                 utils.compute_average_psnr, utils.compute_average_ssim, utils.compute_average_lpips)
+        torch.randn_like = fake_randn_like
+        utils.compute_psnr, utils.compute_ssim, utils.compute_lpips, utils.save_images = cap_psnr, noop, noop, noop
+        utils.compute_average_psnr = utils.compute_average_ssim = utils.compute_average_lpips = noop
+        try:
+            ot.OT_ODE(m, torch.device("cpu"), args).solve_ip([(clean, torch.zeros(B))], degradation, sigma)
+        finally:
+            (torch.randn_like, utils.compute_psnr, utils.compute_ssim, utils.compute_lpips, utils.save_images,
+             utils.compute_average_psnr, utils.compute_average_ssim, utils.compute_average_lpips) = saved
+        assert seq["n"] == 2 and 99 in iterates
+        rec = dict(steps=np.array(100), start_time=np.array(0.1), sigma=np.array(sigma), B=np.array(B), first=np.array(10),
+                   noisy=iterates["noisy"].numpy(), x_final=iterates[99].numpy(), psnr_final=O.psnr_per_image(iterates[99], clean).numpy())
+        for it in (10, 50, 99):
+            rec.update(crop_rec(f"x_it{it}", iterates[it]))
+        np.savez_compressed(os.path.join(OUT, "ot_ode_biglong_c5.npz"), **rec)
+        print("biglong c5", float(iterates[99].abs().mean()), rec["psnr_final"], flush=True)
+
+
 def crop_rec(prefix, t):
     """crop + corner + float64 checksums of a (B,C,H,W) tensor (the big-net fixtures stay small)."""
     H = t.shape[2]
@@ -615,5 +675,7 @@ if __name__ == "__main__":
         gen_ncsnpp()
     if "long" in which:
         gen_long(models, degr, utils, pnp)
+    if "biglong" in which:
+        gen_biglong(models, degr, utils, pnp, only=[w[8:] for w in which if w.startswith("biglong:")] or None)
     if "gmres" in which:
         gen_ot_ode(models, degr, utils, only=("tiny4_deblurring_gmres",))

@@ -6,7 +6,10 @@
 //   3R+1W-inplace  (reads a, b, out; writes out): gn_bwd_post<false, true>
 // build: hipcc --offload-arch=gfx950 -O3 -o stream_mix stream_mix.hip ; run: ./stream_mix
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <vector>
 
 template <int NR, bool INPLACE>
@@ -61,7 +64,25 @@ static double run(const float4* a, const float4* b, const float4* c, float4* o, 
     return (double)(NR + 1) * n4 * 16 * reps / (ms * 1e-3) / 1e9;
 }
 
-int main() {
+// `stream_mix quick <bytes>`: one JSON line for ONE tensor size (what bench.py quotes as roofline.streaming_ceiling_gbs, measured in the
+// run that reports it): the best of two grid-stride grids and the 16 KB-per-workgroup split, per read / write mix
+static int quick(size_t bytes) {
+    const size_t n4 = bytes / 16;
+    float4 *a, *b, *c, *o;
+    if (hipMalloc(&a, n4 * 16) != hipSuccess || hipMalloc(&b, n4 * 16) != hipSuccess || hipMalloc(&c, n4 * 16) != hipSuccess || hipMalloc(&o, n4 * 16) != hipSuccess) return 2;
+    (void)hipMemset(a, 0, n4 * 16); (void)hipMemset(b, 0, n4 * 16); (void)hipMemset(c, 0, n4 * 16); (void)hipMemset(o, 0, n4 * 16);
+    double best[3] = {0, 0, 0};
+    for (int grid : {8192, 32768}) {
+        best[0] = fmax(best[0], run<1, false>(a, b, c, o, n4, grid)); best[1] = fmax(best[1], run<2, false>(a, b, c, o, n4, grid)); best[2] = fmax(best[2], run<3, false>(a, b, c, o, n4, grid));
+    }
+    const int c4 = 16 * 1024 / 16;
+    best[0] = fmax(best[0], run_chunk<1, false>(a, b, c, o, n4, c4)); best[1] = fmax(best[1], run_chunk<2, false>(a, b, c, o, n4, c4)); best[2] = fmax(best[2], run_chunk<3, false>(a, b, c, o, n4, c4));
+    printf("{\"tensor_bytes\": %zu, \"1R+1W\": %.0f, \"2R+1W\": %.0f, \"3R+1W\": %.0f}\n", bytes, best[0], best[1], best[2]);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc >= 3 && std::string(argv[1]) == "quick") return quick((size_t)atoll(argv[2]));
     const size_t sizes_mb[] = {64, 268, 1342};
     for (size_t mb : sizes_mb) {
         const size_t n4 = mb * 1000 * 1000 / 16;

@@ -1,0 +1,525 @@
+// Persistent two-team ("ping-pong") implicit-GEMM convolution for the full-resolution levels of the U-Net (Cout = 32: level 0),
+// split-fp16 MFMA, fp32-equivalent - the same products as conv_mfma16.hip (summed in two interleaved fp32 chains instead of one: the
+// outputs agree with it to fp32 rounding, 4e-7 relative on a whole forward).  Reference: the convolutions of ResidualBlock at level width 32 (pnpflow/models.py:58-113).
+//
+// Why a second structure (profiles/r03_pmc_level0_counters.md, r03_level0_bound_ab.md): at this level the per-tile floor is HBM
+// (~100 KB per 256-pixel tile against 3.5 k matrix-pipe cycles), yet conv_mfma16_kernel spends 12.8 k cycles per tile - every workgroup
+// is a serial chain (first loads -> transform -> barrier -> 54 MFMAs per wave fed by L2 weight fragments -> transposing epilogue), each
+// wave re-fetches the same 36 KB of weights through the texture path per tile, and the generic K-segment walk costs 1.8 k VALU + 1.5 k
+// SALU instructions per wave per tile.  Here:
+//   * ONE 512-thread workgroup per CU lives for the whole launch and walks a contiguous range of 16 x 16-pixel tiles;
+//   * the weights of the launch ([chunk][k16-step][hi | lo][k-half][column][8 halfs], column 8 g + k = output channel 4 k + g: one lane-linear 1 KiB block per B fragment) are
+//     copied to LDS ONCE per workgroup and every B fragment is a ds_read_b128 with an immediate offset;
+//   * the 8 waves form two teams of 4.  A team alternates a VALU phase (epilogue of its previous tile, then GroupNorm + SiLU + operand
+//     scale + fp16 hi / lo split of the raw fp32 halo patch that arrived in registers -> its LDS patch) with an MFMA phase (requests
+//     the NEXT patch + this tile's residual, then walks the chunk's k16-steps from LDS).  The teams are one workgroup barrier apart, so
+//     on every SIMD one wave is in its matrix phase while the other transforms / stores - complementary by construction, and the
+//     next tile's bytes are in flight for a whole phase before they are needed;
+//   * everything that does not depend on the tile (per-lane patch offsets, swizzled LDS addresses of every A fragment, border masks)
+//     is computed once per launch: the k-loop has no VALU / SALU address work at all (immediate offsets only);
+//   * the epilogue transposes each 32 x 32 accumulator tile across lanes (v_permlane16_swap + a DPP row rotation) instead of through LDS:
+//     a lane gets four consecutive channels of one pixel, eight neighbouring lanes the pixel's whole 128-byte row - no scratch, no LDS traffic;
+//   * GroupNorm statistics are summed per lane in fp64 across the tiles of an image and leave as one atomic per (wave, channel) when
+//     the image changes (conv_mfma16: one per (workgroup, channel) per tile).
+// LDS patch of a team: [18 x 18 pixels][8 pieces of 16 B] = (hi k0-7 | hi k8-15 | hi k16-23 | hi k24-31 | lo ...) with piece q of the
+// pixel in column c stored at slot q ^ ((c >> 1) & 7): the 16 pixels a ds_read_b128 lane group touches ({0-3, 12-15} of one tile row +
+// {4-11} of the next, shifted by the tap) land on 16 different 16-byte bank slots for every tap (the swizzle conv_dma.hip uses).
+#include <cstdlib>
+#include "pf_common.h"
+
+namespace pf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// MT = M-tiles (2 rows x 16 pixels) per wave: a team's tile is 8 MT rows x 16 columns, its halo patch (8 MT + 2) x 18 pixels x 128 B
+constexpr int PP_PW = 18;
+constexpr int pp_npix(int MT) { return (8 * MT + 2) * PP_PW; }
+constexpr int pp_patch_bytes(int MT) { return pp_npix(MT) * 128; }                         // MT 1: 23 040 B, MT 2: 41 472 B per team
+constexpr int pp_a9(int MT) { return (pp_npix(MT) * 8 + 255) / 256; }                      // float4 per lane of a 9-tap chunk: 6 / 11
+typedef const __attribute__((address_space(4))) float* pp_float_cptr;
+
+// same expressions as conv_mfma16.hip (bit-identical staging)
+__device__ __forceinline__ float silu_pp(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// 4 x 4 transpose between the registers a0..a3 and the four lanes {k, k + 8, k + 16, k + 24} of a 32-lane half (k = lane & 7): in, a[i] of
+// lane group g holds element (i, g); out, a[g'] of lane group i' holds element (i', g').  Lane bit 4 is exchanged with v_permlane16_swap
+// (one instruction per register pair, gfx950), lane bit 3 with a DPP row rotation by 8 + selects.  With MFMA column n = 8 g + k carrying
+// output channel 4 k + g (the weight image is packed that way) a lane ends up with FOUR CONSECUTIVE channels of one pixel, and the
+// eight lanes k = 0..7 with the pixel's whole 128-byte row: stores and residual loads are 64 contiguous bytes per lane quad (the quad-
+// local DPP transpose of the first version gave every lane of a quad a different pixel: 4 x the vector-memory requests, 107 of 255 us).
+__device__ __forceinline__ void oct_transpose(float& a0, float& a1, float& a2, float& a3, bool bit3) {
+    constexpr int ROR8 = 0x128;                           // row_ror:8 = lane ^ 8 inside a row of 16
+    // (inline asm: with the builtin hipcc 7.2 folds the SECOND result of llvm.amdgcn.permlane16.swap onto the first in this function - seen
+    // in the IR at -O1; the pads are the 2 wait states a VALU write needs before a v_permlane read, and before the DPP reads that follow)
+    float b0 = a0, b1 = a1, b2 = a2, b3 = a3;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1" : "+v"(b0), "+v"(b2), "+v"(b1), "+v"(b3));
+    // (every DPP read is executed by ALL lanes before the selects)
+    const float d0 = dpp_quad<ROR8>(b0), d1 = dpp_quad<ROR8>(b1), d2 = dpp_quad<ROR8>(b2), d3 = dpp_quad<ROR8>(b3);
+    a0 = bit3 ? d1 : b0; a1 = bit3 ? b1 : d0; a2 = bit3 ? d3 : b2; a3 = bit3 ? b3 : d2;
+}
+
+struct PPTile { int b, oy0, ox0, edge; };      // edge bits: 1 top, 2 bottom, 4 left, 8 right (patch rows / columns outside the image)
+
+// PROBE (tools/ubench/conv_pp_probe.hip only; the library instantiates PROBE = 0): timing-only removal of one ingredient -
+// 1 no MFMA phase body, 2 no staging arithmetic, 4 no global loads, 8 no global stores / atomics
+//
+// The K-chunk structure is compile-time: N9 nine-tap chunks (GroupNorm(+SiLU) staging) followed by N1 one-tap chunks (raw: a folded 1x1
+// shortcut), NCH = N9 + N1 steps per tile.  Register prefetch is TWO steps deep: the patch of step s + 2 is requested at the end of the
+// VALU phase of step s into the register set that phase has just staged (sets alternate with the step parity, so the tile loop is unrolled
+// by two and every register has a static name), the residual of a tile two steps before the epilogue that adds it.  One step of distance
+// was not enough: the burst had a single MFMA phase (~0.9 us) to land and every VALU phase began with ~1 us of exposed latency
+// (r4: on-chip 78 us + loads 78 us + stores 97 us were ADDITIVE, 267 us against a 132 us memory skeleton).
+template <int K> struct ic { static constexpr int value = K; };
+#ifdef PP_PROBE_BUILD
+__device__ unsigned long long* g_pp_dbg = nullptr;      // PROBE & 16: s_memtime stamps of workgroup 0, [team][step][8]
+#define PP_STAMP(k) do { if constexpr ((PROBE & 16) != 0) { if (blockIdx.x == 0 && t == 0 && stamp_n < 64) g_pp_dbg[(team * 64 + stamp_n) * 8 + (k)] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define PP_STAMP(k) do { } while (0)
+#endif
+
+template <int MT, int N9, int N1, bool RES, int PROBE = 0, int TEAMS = 2>
+__global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams p) {
+    constexpr int NCH = N9 + N1;
+    constexpr int PP_NPIX = pp_npix(MT), PP_PATCH_BYTES = pp_patch_bytes(MT), PP_A9 = pp_a9(MT), TH = 8 * MT;
+    constexpr int LASTN = PP_NPIX * 8 - (PP_A9 - 1) * 256;          // threads that own a float4 number PP_A9 - 1
+    constexpr int WBYTES = N9 * 36864 + N1 * 4096;                  // LDS weight images: 9-tap chunks first
+    static_assert(NCH >= 1 && NCH <= PP_MAXCH && N9 >= 1, "chunk structure");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int team = TEAMS == 2 ? __builtin_amdgcn_readfirstlane(tid >> 8) : 0;
+    const int t = tid & 255, lane = t & 63, wm = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const unsigned patch0 = (unsigned)WBYTES + (unsigned)team * PP_PATCH_BYTES;      // byte offset of this team's patch in LDS
+    // the per-image operand scales are read through the scalar cache (constant address space): as ordinary global loads hipcc makes them
+    // VECTOR loads, and every wait for one drains the patch prefetch (one in-order vmcnt)
+    const pp_float_cptr scale_c = (pp_float_cptr)(uintptr_t)p.scale;
+    auto wlds = [](int c) constexpr { return c < N9 ? c * 36864 : N9 * 36864 + (c - N9) * 4096; };
+
+    // ---- weights -> LDS, once per workgroup --------------------------------------------------------------------------------------
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const uint4* src = reinterpret_cast<const uint4*>(p.ch[c].wimg);
+        uint4* dst = reinterpret_cast<uint4*>(smem + wlds(c));
+        const int n16 = (c < N9 ? 9 : 1) * 256;             // taps * 2 k16-steps * 2 KiB / 16
+        for (int i = tid; i < n16; i += 256 * TEAMS) dst[i] = src[i];
+    }
+
+    // ---- per-lane constants of the staging (independent of the tile) -----------------------------------------------------------------
+    const int qi = t & 7, p0 = t >> 3;
+    // float4 number i of a 9-tap chunk = patch pixel pp = p0 + 32 i, channel quad qi.  One packed word per i: bits 0-15 pixel offset
+    // py * W + px inside the patch (pixels), bits 16-18 the LDS slot (piece ^ swizzle) of the quad's hi halfs, bits 20-23 the edges the
+    // pixel lies on (top, bottom, left, right)
+    unsigned pk9[PP_A9];
+#pragma unroll
+    for (int i = 0; i < PP_A9; ++i) {
+        const int pp = min(p0 + 32 * i, PP_NPIX - 1);
+        const int py = pp / PP_PW, px = pp - py * PP_PW;
+        pk9[i] = (unsigned)(py * p.W + px) | ((unsigned)((qi >> 1) ^ ((px >> 1) & 7)) << 16) |
+                 ((py == 0 ? 1u : 0u) << 20) | ((py == TH + 1 ? 1u : 0u) << 21) | ((px == 0 ? 1u : 0u) << 22) | ((px == PP_PW - 1 ? 1u : 0u) << 23);
+    }
+    const unsigned ldsw9 = patch0 + (unsigned)min(p0, PP_NPIX - 1) * 128u + (unsigned)((qi & 1) * 8);       // + 4096 i + (slot << 4)
+    const int pix_safe = p.W + 1;                          // patch pixel (1, 1) = tile pixel (0, 0): inside the image for every tile
+    // 1-tap chunks stage the TH x 16 interior only: float4 number t + 256 i = pixel (row (t >> 7) + 2 i, column (t >> 3) & 15), quad qi
+    const int r1 = t >> 7, c1 = (t >> 3) & 15;
+    const int pixoff1 = r1 * p.W + c1;
+    const unsigned ldsw1 = patch0 + (unsigned)((r1 + 1) * PP_PW + c1 + 1) * 128u + (unsigned)((((qi >> 1) ^ (((c1 + 1) >> 1) & 7)) << 4) + (qi & 1) * 8);
+
+    // A-fragment addresses: lane = pixel (row prow of the M-tile's two rows, column pcol), k-half hi; [kx][j][term]
+    const int prow = l31 >> 4, pcol = l31 & 15;
+    unsigned a_addr[3][2][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const unsigned base = patch0 + (unsigned)((wm * 2 * MT + prow) * PP_PW + pcol + kx) * 128u;
+        const unsigned s = (unsigned)(((pcol + kx) >> 1) & 7);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) a_addr[kx][j][tm] = base + ((((unsigned)(j * 2 + hi + 4 * tm)) ^ s) << 4);
+    }
+    const unsigned b_lane = (unsigned)lane * 16u;
+
+    // epilogue geometry: after the transpose the lane holds pixel 8 g + 4 hi + ((lane >> 3) & 3) of the M-tile, channels 4 em .. 4 em + 3
+    const bool bit3 = (lane & 8) != 0;
+    const int em = lane & 7;
+    const int ch_of_col = 4 * (l31 & 7) + (l31 >> 3);                                // output channel carried by MFMA column l31
+    const unsigned e_lane = (unsigned)((4 * hi + ((lane >> 3) & 3)) * 128 + em * 16);  // byte offset inside a tile row of 16 pixels x 128 B
+
+    // ---- this workgroup's tiles ----------------------------------------------------------------------------------------------------
+    const int G = gridDim.x;
+    const int rg = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);                      // XCD-contiguous ranges (G % 8 == 0)
+    const int T = p.B << (p.lx + p.ly);
+    const int t_begin = (int)((long)rg * T / G), t_end = (int)((long)(rg + 1) * T / G);
+    const int ntl = t_end - t_begin;
+    const int niter = (ntl + TEAMS - 1) / TEAMS;
+    const int rot = ntl > 0 ? (int)(((long)rg * p.rot) % ntl) : 0;
+    auto tile_of = [&](int it) __attribute__((always_inline)) -> PPTile {
+        // past the range: the last tile again (its stores are masked).  The walk starts `rot` tiles into the range and wraps: neighbouring
+        // CUs, whose ranges begin a whole number of tile rows apart, would otherwise sit on the same column tile - the same address bits
+        // below the row pitch - at every moment of the launch
+        const int idx = min(it * TEAMS + team, ntl - 1);
+        const int wrapped = idx + rot >= ntl ? idx + rot - ntl : idx + rot;
+        const int tl = t_begin + wrapped;
+        PPTile r;
+        const int tx = tl & ((1 << p.lx) - 1), ty = (tl >> p.lx) & ((1 << p.ly) - 1);
+        r.b = tl >> (p.lx + p.ly); r.oy0 = ty * TH; r.ox0 = tx * 16;
+        r.edge = (ty == 0 ? 1 : 0) | (ty == (1 << p.ly) - 1 ? 2 : 0) | (tx == 0 ? 4 : 0) | (tx == (1 << p.lx) - 1 ? 8 : 0);
+        return r;
+    };
+    auto live_of = [&](int it) __attribute__((always_inline)) -> bool { return it >= 0 && (t_begin + it * TEAMS + team) < t_end; };
+
+    // ---- register sets ---------------------------------------------------------------------------------------------------------------
+    struct Pre {
+        float4 ra[PP_A9];             // raw fp32 patch of a chunk, in flight
+        float4 csc, csh;              // GroupNorm coefficients of this lane's channel quad for that chunk
+        float ascale;                 // operand scale of the chunk's K-segment
+        unsigned inval;               // bit i: float4 i lies outside the image (loaded from a safe pixel, staged as zero)
+    };
+    Pre pre0, pre1;
+    struct Res { float4 rv[MT][4]; float addv; };      // residual + bias (+ time-embedding projection) of one tile
+    Res res0, res1;
+
+    auto issue_patch = [&](Pre& S, const PPTile& tl, auto C_) __attribute__((always_inline)) {
+        constexpr int C = decltype(C_)::value;
+        if constexpr ((PROBE & 4) != 0) { return; }
+        const long bpix = ((long)tl.b * p.H + tl.oy0) * p.W + tl.ox0;
+        const int cstride = p.ch[C].cstride;
+        S.ascale = p.scale != nullptr ? scale_c[8 * tl.b + p.ch[C].seg] : 1.0f;
+        if constexpr (C < N9) {
+            const float* base = p.ch[C].src + (bpix - p.W - 1) * cstride + p.ch[C].coff + qi * 4;
+            unsigned inval = 0;
+#pragma unroll
+            for (int i = 0; i < PP_A9; ++i) inval |= (((pk9[i] >> 20) & (unsigned)tl.edge) != 0u ? 1u : 0u) << i;
+            S.inval = inval;
+            const float* cb = p.coef + (size_t)tl.b * 2 * p.coef_stride + p.ch[C].gn_c0 + qi * 4;
+            S.csc = *reinterpret_cast<const float4*>(cb); S.csh = *reinterpret_cast<const float4*>(cb + p.coef_stride);
+#pragma unroll
+            for (int i = 0; i < PP_A9; ++i) {
+                const int px = ((inval >> i) & 1u) ? pix_safe : (int)(pk9[i] & 0xffffu);
+                S.ra[i] = *reinterpret_cast<const float4*>(base + (unsigned)(px * cstride));
+            }
+        } else {
+            const float* base = p.ch[C].src + bpix * cstride + p.ch[C].coff + qi * 4;
+            S.inval = 0;
+#pragma unroll
+            for (int i = 0; i < TH / 2; ++i) S.ra[i] = *reinterpret_cast<const float4*>(base + (unsigned)((pixoff1 + 2 * i * p.W) * cstride));
+        }
+    };
+
+    auto split_store = [&](float4 v, unsigned addr) __attribute__((always_inline)) {
+        // opaque to the optimiser: the hi that is stored and the hi that is subtracted must be the SAME rounding of the SAME fp32 value
+        asm("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+        f16x4 h, l;
+        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+        l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
+        l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
+        *reinterpret_cast<f16x4*>(smem + addr) = h;
+        *reinterpret_cast<f16x4*>(smem + (addr ^ 64u)) = l;                       // the lo piece q + 4 sits at slot (q ^ s) ^ 4
+    };
+
+    auto transform = [&](const Pre& S, auto C_) __attribute__((always_inline)) {
+        constexpr int C = decltype(C_)::value;
+        if constexpr (C < N9) {
+            const bool silu = p.ch[C].xform == 2;
+#pragma unroll
+            for (int i = 0; i < PP_A9; ++i) {
+                float4 v = S.ra[i];
+                if constexpr ((PROBE & 2) == 0) {
+                    v.x = v.x * S.csc.x + S.csh.x; v.y = v.y * S.csc.y + S.csh.y; v.z = v.z * S.csc.z + S.csh.z; v.w = v.w * S.csc.w + S.csh.w;
+                    if (silu) { v.x = silu_pp(v.x); v.y = silu_pp(v.y); v.z = silu_pp(v.z); v.w = silu_pp(v.w); }
+                    const float f = ((S.inval >> i) & 1u) ? 0.0f : S.ascale;
+                    v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+                }
+                // (the last float4 exists for the first LASTN threads only)
+                if (i < PP_A9 - 1 || t < LASTN) split_store(v, ldsw9 + (unsigned)(i * 4096) + (((pk9[i] >> 16) & 7u) << 4));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TH / 2; ++i) {
+                float4 v = S.ra[i];
+                v.x *= S.ascale; v.y *= S.ascale; v.z *= S.ascale; v.w *= S.ascale;
+                split_store(v, ldsw1 + (unsigned)(2 * i * PP_PW * 128));
+            }
+        }
+    };
+
+    // two accumulators per M-tile (even / odd k16-steps, summed in the epilogue): with one, the 54 MFMAs of a chunk are a single dependent
+    // chain and the wave stalls on every issue (r4 counters: SQ_WAIT_INST_ANY 19 % of the wave's cycles)
+    f32x16 acc[MT], acc2[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[mt][r] = 0.f; acc2[mt][r] = 0.f; }
+    // running (sum, sum of squares) of this lane's four output channels over the tiles of image run_b: fp32 per lane (at most 32 tiles x 4
+    // pixels between flushes - conv_mfma16 sums 256 pixels per channel in fp32 before its fp64 atomic), reduced across the wave's 8 lanes per
+    // channel quad and added to the fp64 statistics when the image changes.  (Reducing and accumulating per TILE - shuffles + an LDS fp64
+    // read-modify-write - was 2.5 k cycles of every VALU phase together with the transposes, r4 stamps.)
+    float run1[4] = {0.f, 0.f, 0.f, 0.f}, run2[4] = {0.f, 0.f, 0.f, 0.f};
+    int run_b = -1, run_n = 0;
+
+    auto mma_step = [&](unsigned wbase, int s, int ky, int kx, int j) __attribute__((always_inline)) {
+        const f16x8 bh = *reinterpret_cast<const f16x8*>(smem + wbase + (unsigned)((s * 2 + 0) * 1024));
+        const f16x8 bl = *reinterpret_cast<const f16x8*>(smem + wbase + (unsigned)((s * 2 + 1) * 1024));
+        f16x8 ah[MT], al[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const unsigned off = (unsigned)((mt * 2 + ky) * PP_PW * 128);
+            ah[mt] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][j][0] + off);
+            al[mt] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][j][1] + off);
+        }
+        if (s & 1) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc2[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc2[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc2[mt], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt], 0, 0, 0);
+        }
+    };
+
+    auto flush_stats = [&]() __attribute__((always_inline)) {
+        if (p.stats_out == nullptr || run_b < 0 || (PROBE & 8) != 0) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double a = (double)run1[j], q = (double)run2[j];
+            a += __shfl_xor(a, 8); q += __shfl_xor(q, 8);
+            a += __shfl_xor(a, 16); q += __shfl_xor(q, 16);
+            a += __shfl_xor(a, 32); q += __shfl_xor(q, 32);
+            if (lane < 8) {
+                double* dst = p.stats_out + ((size_t)run_b * 32 + em * 4 + j) * 2;
+                unsafeAtomicAdd(dst, a); unsafeAtomicAdd(dst + 1, q);
+            }
+            run1[j] = 0.f; run2[j] = 0.f;
+        }
+        run_n = 0;
+    };
+
+    auto epilogue = [&](const Res& R, const PPTile& tl, bool live) __attribute__((always_inline)) {
+        if (!live) return;                                   // (the first VALU phase has no finished tile; a repeated last tile is not stored twice)
+        if (tl.b != run_b || run_n >= 32) { flush_stats(); run_b = tl.b; }
+        ++run_n;
+        const float inv_last = p.scale != nullptr ? scale_c[8 * tl.b + 4 + p.ch[NCH - 1].seg] : 1.0f;
+        const float oscale = p.out_scale * (1.0f / 256.0f) * inv_last;
+        float* obase = p.out + (((size_t)tl.b * p.H + tl.oy0 + wm * 2 * MT) * p.W + tl.ox0) * 32;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float e[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[r] = (acc[mt][r] + acc2[mt][r]) * oscale + R.addv;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                oct_transpose(e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3], bit3);
+                float4 v = make_float4(e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3]);
+                if constexpr (RES) {
+                    const float rsc = p.res_scale; const float4 r4 = R.rv[mt][g];
+                    v.x = fmaf(r4.x, rsc, v.x); v.y = fmaf(r4.y, rsc, v.y); v.z = fmaf(r4.z, rsc, v.z); v.w = fmaf(r4.w, rsc, v.w);
+                }
+                if constexpr ((PROBE & 8) == 0) {
+                    // pixel 8 g + 4 hi + ((lane >> 3) & 3) of the M-tile: row (g >> 1) of its two rows, column 8 (g & 1) + 4 hi + ((lane >> 3) & 3)
+                    char* dst = reinterpret_cast<char*>(obase) + (size_t)((mt * 2 + (g >> 1)) * p.W) * 128 + (g & 1) * 1024 + e_lane;
+                    *reinterpret_cast<float4*>(dst) = v;
+                }
+                run1[0] += v.x; run1[1] += v.y; run1[2] += v.z; run1[3] += v.w;
+                run2[0] += v.x * v.x; run2[1] += v.y * v.y; run2[2] += v.z * v.z; run2[3] += v.w * v.w;
+            }
+        }
+    };
+
+    auto issue_res = [&](Res& R, const PPTile& tl) __attribute__((always_inline)) {
+        if constexpr ((PROBE & 4) != 0) { return; }
+        R.addv = p.addvec != nullptr ? p.addvec[(size_t)tl.b * p.addvec_bs + ch_of_col] : 0.f;
+        if constexpr (RES) {
+            const char* rbase = reinterpret_cast<const char*>(p.residual + (((size_t)tl.b * p.H + tl.oy0 + wm * 2 * MT) * p.W + tl.ox0) * 32);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    R.rv[mt][g] = *reinterpret_cast<const float4*>(rbase + (size_t)((mt * 2 + (g >> 1)) * p.W) * 128 + (g & 1) * 1024 + e_lane);
+        }
+    };
+
+    auto mma_chunk = [&](const PPTile& tl, auto C_) __attribute__((always_inline)) {
+        constexpr int C = decltype(C_)::value;
+        if constexpr (C == 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[mt][r] = 0.f; acc2[mt][r] = 0.f; }
+        } else {
+            if (p.scale != nullptr && p.ch[C - 1].seg != p.ch[C].seg) {
+                // the accumulator changes units: from the previous K-segment's operand scale to this one's (powers of two: exact)
+                const float ratio = scale_c[8 * tl.b + p.ch[C].seg] * scale_c[8 * tl.b + 4 + p.ch[C - 1].seg];
+                if (ratio != 1.0f) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { acc[mt][r] *= ratio; acc2[mt][r] *= ratio; }
+                }
+            }
+        }
+        const unsigned wbase = (unsigned)wlds(C) + b_lane;
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr ((PROBE & 1) != 0) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { acc[mt][0] += (float)wbase; acc2[mt][0] += 1.f; }
+        } else if constexpr (C < N9) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma_step(wbase, tap * 2 + j, tap / 3, tap % 3, j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma_step(wbase, j, 1, 1, j);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    int stamp_n = 0; (void)stamp_n;
+    // ---- one step = VALU phase + MFMA phase of chunk C of the team's it-th tile (PAR = it & 1) -------------------------------------------
+    // register set of step (it, C): the step's global index it * NCH + C, modulo 2
+    auto step = [&](int it, auto PAR_, auto C_, bool last_step) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PAR_)::value, C = decltype(C_)::value;
+        constexpr int SI = (NCH % 2 == 0) ? (C & 1) : ((PAR + C) & 1);
+        Pre& S = SI == 0 ? pre0 : pre1;
+        const PPTile tl = tile_of(it);
+        // ---- VALU phase ---------------------------------------------------------------------------------------------------------------
+        PP_STAMP(0);
+        if constexpr ((PROBE & 16) != 0) { asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); }      // (stamp 1 = the requests of two steps ago have landed)
+        PP_STAMP(1);
+        if constexpr (C == 0) epilogue(PAR == 0 ? res1 : res0, tile_of(it - 1), live_of(it - 1) && it > 0);      // the previous tile (parity PAR ^ 1)
+        PP_STAMP(2);
+        transform(S, C_);
+        PP_STAMP(3);
+        // requests, two steps ahead: the patch of step (it, C) + 2 into the set just staged ...
+        constexpr int C2 = (C + 2) % NCH, DT = (C + 2) / NCH;
+        issue_patch(S, tile_of(it + DT), ic<C2>{});
+        // ... and, when that step opens a tile, the residual of the tile that closes in front of it (tile it + DT - 1, parity PAR + DT - 1)
+        if constexpr (C2 == 0) issue_res(((PAR + DT - 1) & 1) == 0 ? res0 : res1, tile_of(it + DT - 1));
+        PP_STAMP(4);
+        __syncthreads();
+        // ---- MFMA phase (LDS + matrix pipe only) ----------------------------------------------------------------------------------------
+        PP_STAMP(5);
+        mma_chunk(tl, C_);
+        PP_STAMP(6);
+        if (!(TEAMS == 2 && team == 1 && last_step)) __syncthreads();
+        PP_STAMP(7);
+        ++stamp_n;
+    };
+    auto tile_steps = [&](int it, auto PAR_) __attribute__((always_inline)) {
+        const bool last_tile = it == niter - 1;
+        if constexpr (NCH >= 1) step(it, PAR_, ic<0>{}, last_tile && NCH == 1);
+        if constexpr (NCH >= 2) step(it, PAR_, ic<1>{}, last_tile && NCH == 2);
+        if constexpr (NCH >= 3) step(it, PAR_, ic<2>{}, last_tile && NCH == 3);
+        if constexpr (NCH >= 4) step(it, PAR_, ic<3>{}, last_tile && NCH == 4);
+        if constexpr (NCH >= 5) step(it, PAR_, ic<4>{}, last_tile && NCH == 5);
+        if constexpr (NCH >= 6) step(it, PAR_, ic<5>{}, last_tile && NCH == 6);
+    };
+
+    // ---- the walk --------------------------------------------------------------------------------------------------------------------
+    if (ntl <= 0) return;             // (never with the launcher's grid: T >= 8 G)
+    issue_patch(pre0, tile_of(0), ic<0>{});                                        // step 0
+    if constexpr (NCH == 1) { issue_patch(pre1, tile_of(1), ic<0>{}); issue_res(res0, tile_of(0)); }   // step 1 = tile 1; tile 0 closes at step 1
+    else issue_patch(pre1, tile_of(0), ic<1>{});
+    __syncthreads();                  // weights visible
+    if (TEAMS == 2 && team == 1) __syncthreads();
+    // (both halves are unconditional inside the loop: with `if (it + 1 < niter)` around the odd half hipcc's waitcnt pass also has to cover
+    // the path that skips it, on which the even half's registers were requested just 4 vector-memory operations ago - it then waits vmcnt(4)
+    // in every even step, i.e. for the patch of the step before: one step of prefetch distance again)
+    int it = 0;
+    for (; it + 1 < niter; it += 2) {
+        tile_steps(it, ic<0>{});
+        tile_steps(it + 1, ic<1>{});
+    }
+    if (it < niter) tile_steps(it, ic<0>{});
+    if (niter & 1) epilogue(res0, tile_of(niter - 1), live_of(niter - 1));
+    else epilogue(res1, tile_of(niter - 1), live_of(niter - 1));
+    flush_stats();
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------------
+
+static int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
+
+constexpr int PP_MT = 1;      // 8 x 16-pixel team tiles: at 2 waves per SIMD two register sets of raw patch + two of residual + accumulators fit 256 registers
+
+// chunk structures instantiated: ResidualBlock conv1 / conv2 of the down path (one 3x3 chunk, with / without the identity residual), conv1 of
+// the up path over cat[h, skip] (two / three 3x3 chunks), conv2 of the up path with the folded 1x1 shortcut (one 3x3 + two / three 1x1 chunks)
+static bool pp_structure(int n9, int n1, bool res) {
+    if (res) return n9 == 1 && n1 == 0;
+    return (n1 == 0 && n9 >= 1 && n9 <= 3) || (n9 == 1 && (n1 == 2 || n1 == 3));
+}
+
+bool conv_pp_supported(const ConvParams& p, int stride, int up, int terms) {
+    static const int mode = getenv("PNPFLOW_HIP_PP") ? atoi(getenv("PNPFLOW_HIP_PP")) : 1;
+    constexpr int TH = 8 * PP_MT;
+    if (mode == 0 || terms != 3 || stride != 1 || up != 0 || p.gnb_x != nullptr) return false;
+    if (p.Cout != 32 || p.out_cstride != 32 || (p.residual != nullptr && p.res_cstride != 32)) return false;
+    if (p.H % TH || p.W % 16 || p.Hs != p.H || p.Ws != p.W) return false;
+    if (ilog2_exact(p.H / TH) < 0 || ilog2_exact(p.W / 16) < 0) return false;
+    if ((long)p.B * (p.H / TH) * (p.W / 16) < 8L * 256) return false;           // a persistent grid needs a few tiles per team (small batches stay on conv_mfma16)
+    int n9 = 0, n1 = 0;
+    for (int i = 0; i < p.nseg; ++i) {
+        const ConvSeg& s = p.seg[i];
+        if (s.w_mode != 0 || s.w16 == nullptr || s.C % 32) return false;
+        if (s.taps == 9) { if (n1 > 0 || s.xform == 0) return false; n9 += s.C / 32; }     // 9-tap chunks are GroupNorm-ed (their coefficient loads are unconditional)
+        else if (s.taps == 1) { if (s.xform != 0) return false; n1 += s.C / 32; }
+        else return false;
+    }
+    if (!pp_structure(n9, n1, p.residual != nullptr)) return false;
+    if (p.gn_C > 0 && p.coef == nullptr) return false;
+    return (size_t)n9 * 36864 + (size_t)n1 * 4096 + 2 * pp_patch_bytes(PP_MT) <= 160 * 1024;
+}
+
+// TEAMS = 1: two independent 4-wave workgroups per CU (each with its own copy of the weights) where LDS allows - the teams of one
+// 8-wave workgroup wait for each other at every phase boundary, independent workgroups only for their own data (r4: 192 vs 214 us on the
+// one-chunk conv); TEAMS = 2 (one workgroup per CU, weights shared) for the structures whose weights do not fit twice
+template <int N9, int N1, bool RES, int TEAMS>
+static hipError_t launch_pp_tt(const PPParams& p0, hipStream_t s) {
+    static unsigned long long attr_set = 0ull;
+    auto kern = conv_pp_kernel<PP_MT, N9, N1, RES, 0, TEAMS>;
+    { hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(kern), attr_set, 160 * 1024); if (e != hipSuccess) return e; }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+    const int grid = (cus / 8) * 8 * (TEAMS == 1 ? 2 : 1);
+    PPParams p = p0;
+    p.lx = ilog2_exact(p.W / 16); p.ly = ilog2_exact(p.H / (8 * PP_MT));
+    static const int rot_env = getenv("PNPFLOW_HIP_PP_ROT") ? atoi(getenv("PNPFLOW_HIP_PP_ROT")) : 5;
+    p.rot = rot_env;
+    const size_t lds = (size_t)N9 * 36864 + (size_t)N1 * 4096 + TEAMS * pp_patch_bytes(PP_MT);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * TEAMS), lds, s, p);
+    return hipGetLastError();
+}
+
+template <int N9, int N1, bool RES>
+static hipError_t launch_pp_t(const PPParams& p, hipStream_t s) {
+    static const int teams_env = getenv("PNPFLOW_HIP_PP_TEAMS") ? atoi(getenv("PNPFLOW_HIP_PP_TEAMS")) : 0;
+    constexpr size_t one = (size_t)N9 * 36864 + (size_t)N1 * 4096 + pp_patch_bytes(PP_MT);
+    if constexpr (2 * one <= 160 * 1024) { if (teams_env != 2) return launch_pp_tt<N9, N1, RES, 1>(p, s); }
+    return launch_pp_tt<N9, N1, RES, 2>(p, s);
+}
+
+hipError_t launch_conv_pp(const PPParams& p, hipStream_t s) {
+    const bool res = p.residual != nullptr;
+    if (p.n9 == 1 && p.n1 == 0) return res ? launch_pp_t<1, 0, true>(p, s) : launch_pp_t<1, 0, false>(p, s);
+    if (res) return hipErrorInvalidValue;
+    if (p.n9 == 2 && p.n1 == 0) return launch_pp_t<2, 0, false>(p, s);
+    if (p.n9 == 3 && p.n1 == 0) return launch_pp_t<3, 0, false>(p, s);
+    if (p.n9 == 1 && p.n1 == 2) return launch_pp_t<1, 2, false>(p, s);
+    if (p.n9 == 1 && p.n1 == 3) return launch_pp_t<1, 3, false>(p, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace pf

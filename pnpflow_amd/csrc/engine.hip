@@ -45,6 +45,7 @@ struct Op {
     OpKind kind;
     ConvParams cp; int stride = 1, up = 0;
     int dma = 0;                                    // OP_CONV: 1 = conv_dma.hip (its operands were written by the OP_PREP in front of it)
+    int use_pp = 0; PPParams ppp{};                 // OP_CONV: 1 = conv_pp.hip (persistent two-team kernel of the 32-channel level)
     PrepParams pp{};
     EdgeConvParams ep;
     TembParams tp;
@@ -393,6 +394,34 @@ static const void* packed_conv16h(pf_engine* e, const std::string& wname, int lo
     return upload(e, key, raw);
 }
 
+// LDS weight image of ONE 32-channel K-chunk for conv_pp.hip (Cout = 32): [k16-step s = tap * 2 + j][hi | lo][k-half][column][8 halfs], channel of
+// (s, k-half, i) = lo + j * 16 + k-half * 8 + i; the same x 2^8 pre-scale and hi / lo split as packed_conv16, so the products are the same
+static const void* packed_conv_pp(pf_engine* e, const std::string& wname, int lo) {
+    const std::string key = wname + "#pp" + std::to_string(lo);
+    auto it = e->dev.find(key);
+    if (it != e->dev.end()) return it->second;
+    const HostTensor& t = W(e, wname);
+    const int O = (int)t.shape[0], I = (int)t.shape[1], kk = (int)(t.shape[2] * t.shape[3]);
+    std::vector<_Float16> out((size_t)kk * 2 * 2 * 2 * O * 8, (_Float16)0.f);
+    for (int tap = 0; tap < kk; ++tap)
+        for (int j = 0; j < 2; ++j)
+            for (int kh = 0; kh < 2; ++kh)
+                for (int n = 0; n < O; ++n)
+                    for (int i = 0; i < 8; ++i) {
+                        const int c = lo + j * 16 + kh * 8 + i;
+                        const int oc = 4 * (n & 7) + (n >> 3);      // MFMA column n = 8 g + k carries output channel 4 k + g (conv_pp.hip's epilogue transpose)
+                        const float w = t.data[((size_t)oc * I + c) * kk + tap] * 256.0f;
+                        const _Float16 h = (_Float16)w;
+                        const _Float16 l = (_Float16)(w - (float)h);
+                        const size_t blk = (size_t)(tap * 2 + j) * 2 * (2 * O * 8);
+                        out[blk + ((size_t)kh * O + n) * 8 + i] = h;
+                        out[blk + (size_t)2 * O * 8 + ((size_t)kh * O + n) * 8 + i] = l;
+                    }
+    std::vector<float> raw(out.size() / 2);
+    memcpy(raw.data(), out.data(), out.size() * sizeof(_Float16));
+    return upload(e, key, raw);
+}
+
 static void fill_packed_seg(ConvSeg& s, const float* w, int taps, int Cout) {
     (void)taps; (void)Cout;
     s.w = w; s.w_mode = 0; s.w_bs = 0; s.w_cs = 0; s.w_ts = 0; s.w_ns = 0; s.w_ks = 0; s.w16 = nullptr;
@@ -504,10 +533,36 @@ static bool attach_dma(Builder& bd, ConvParams& p, int stride, int up, std::vect
     return true;
 }
 
+// conv_pp.hip (persistent two-team kernel of the 32-channel level): the launch becomes a device-resident list of 32-channel K-chunks
+static bool attach_pp(Builder& bd, const ConvParams& p, int stride, int up, PPParams& q) {
+    pf_engine* e = bd.e;
+    if (e->precision != 1 || !conv_pp_supported(p, stride, up, 3)) return false;
+    q = PPParams{};
+    int n = 0;
+    for (int i = 0; i < p.nseg; ++i) {
+        const ConvSeg& sg = p.seg[i];
+        auto it = e->w16_src.find(sg.w16);
+        if (it == e->w16_src.end()) return false;
+        for (int cc = 0; cc < sg.C / 32; ++cc) {
+            PPChunk& k = q.ch[n++];
+            k.src = sg.src; k.cstride = sg.cstride; k.coff = sg.coff + cc * 32; k.xform = sg.xform;
+            k.gn_c0 = sg.gn_off + cc * 32; k.seg = i;
+            k.wimg = packed_conv_pp(e, it->second.name, it->second.lo + cc * 32);
+            if (!k.wimg) return false;
+            (sg.taps == 9 ? q.n9 : q.n1) += 1;
+        }
+    }
+    q.B = p.B; q.H = p.H; q.W = p.W;
+    q.out = p.out; q.addvec = p.addvec; q.addvec_bs = p.addvec_bs; q.residual = p.residual; q.res_scale = p.res_scale;
+    q.stats_out = p.stats_out; q.out_scale = p.out_scale; q.coef = p.coef; q.coef_stride = p.coef_stride; q.scale = p.scale;
+    return true;
+}
+
 static void push_conv(Builder& bd, const ConvParams& p0, int stride = 1, int up = 0) {
     ConvParams p = with_coef(bd, p0, bd.plan->ops);
     Op op{}; op.kind = OP_CONV;
-    op.dma = attach_dma(bd, p, stride, up, bd.plan->ops) ? 1 : 0;
+    op.use_pp = attach_pp(bd, p, stride, up, op.ppp) ? 1 : 0;
+    op.dma = (!op.use_pp && attach_dma(bd, p, stride, up, bd.plan->ops)) ? 1 : 0;
     op.cp = p; op.stride = stride; op.up = up; op.flops = conv_flops(p);
     bd.plan->gemm_flops += op.flops;
     bd.plan->ops.push_back(op);
@@ -679,7 +734,7 @@ static Tensor resample_conv(Builder& bd, const std::string& pfx, const Tensor& x
 static void fix_stats(Op& op, double* slab) {
     auto fx = [&](const double*& p) { if (p) p = (const double*)((char*)slab + ((uintptr_t)p - 1)); };
     auto fxm = [&](double*& p) { if (p) p = (double*)((char*)slab + ((uintptr_t)p - 1)); };
-    if (op.kind == OP_CONV) { for (int i = 0; i < op.cp.nseg; ++i) fx(op.cp.seg[i].stats); fxm(op.cp.stats_out); fxm(op.cp.gnb_sum); }
+    if (op.kind == OP_CONV) { for (int i = 0; i < op.cp.nseg; ++i) fx(op.cp.seg[i].stats); fxm(op.cp.stats_out); fxm(op.cp.gnb_sum); if (op.use_pp) op.ppp.stats_out = op.cp.stats_out; }
     if (op.kind == OP_GN_COEF) for (int i = 0; i < op.gp.nseg; ++i) fx(op.gp.st[i]);
     if (op.kind == OP_NX_FIR) fxm(op.fp.stats_raw);
     if (op.kind == OP_END) fx(op.ep.stats);
@@ -1213,6 +1268,7 @@ static int run_backward(pf_engine* e, Plan* plan, const float* vec, float* g, hi
 }
 
 static hipError_t dispatch_conv(pf_engine* e, const Op& op, hipStream_t s) {
+    if (op.use_pp && e->precision == 1) return launch_conv_pp(op.ppp, s);
     if (op.dma) return launch_conv_dma(op.cp, op.up, s, e->precision == 2 ? 1 : 3);
     if (e->precision != 0) {
         bool ok16 = true;
@@ -1923,7 +1979,7 @@ int pf_engine_profile_read(pf_engine* e, int64_t* launches, double* ms_conv_gemm
             double bytes = (double)op.cp.B * op.cp.H * op.cp.W * op.cp.Cout * 4.0 * (op.cp.residual ? 2.0 : 1.0);
             for (int j = 0; j < op.cp.nseg; ++j) bytes += (double)op.cp.B * op.cp.Hs * op.cp.Ws * op.cp.seg[j].C * 4.0;
             fprintf(dump, "%zu,%d,%d,%d,%zu,%d,%d,%d,%d,%.4f,%.2f,%.2f,%d,%.3f", i, op.cp.H, op.cp.W, op.cp.Cout, K, op.cp.nseg, op.cp.seg[0].taps,
-                    op.stride, op.up, op.flops / 1e9, ms * 1e3, op.flops / (ms * 1e-3) / 1e12, op.dma, bytes / 1e6);
+                    op.stride, op.up, op.flops / 1e9, ms * 1e3, op.flops / (ms * 1e-3) / 1e12, op.use_pp ? 2 : op.dma, bytes / 1e6);
             fprintf(dump, "\n");
         }
     }

@@ -1053,11 +1053,13 @@ def test_rccl_executes_the_job_collectives_on_one_gpu(hip):
     args = [sys.executable, "bench.py", "--workload", "tiny", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extra", "--batch", "4"]
     forced = subprocess.run(args + ["--force-dist"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert forced.returncode == 0, forced.stderr[-2000:]
-    line = json.loads(forced.stdout.strip().splitlines()[-1])
+    js = [l for l in forced.stdout.splitlines() if l.startswith("{")]
+    assert js, (forced.stdout[-1500:], forced.stderr[-1500:])
+    line = json.loads(js[-1])
     assert line["collective_backend"].startswith("rccl") and line["ranks_in_job"] == 1 and line["rccl_version"], line
     plain = subprocess.run(args, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert plain.returncode == 0, plain.stderr[-2000:]
-    assert abs(json.loads(plain.stdout.strip().splitlines()[-1])["psnr_db"] - line["psnr_db"]) < 1e-6
+    assert abs(json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])["psnr_db"] - line["psnr_db"]) < 1e-6
     # the metric gather of the solvers (utils.compute_average_* -> parallel.gather_in_image_order) through RCCL, in a child process
     code = ("import os, torch, torch.distributed as dist\n"
             "os.environ['PNPFLOW_DIST_FORCE'] = '1'\n"

@@ -1,0 +1,75 @@
+// Stand-alone timing of conv_pp_kernel (pnpflow_amd/csrc/conv_pp.hip) on synthetic tensors, with one ingredient removed at a time
+// (the kernel's PROBE template parameter; results are wrong by construction for PROBE != 0).
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../pnpflow_amd/csrc -o conv_pp_probe conv_pp_probe.hip ; run: ./conv_pp_probe [H W B nch]
+#define PP_PROBE_BUILD 1
+#include "../../pnpflow_amd/csrc/conv_pp.hip"
+#include <cstdio>
+#include <vector>
+using namespace pf;
+
+template <int N9, bool RES, int PROBE, int TEAMS = 2>
+static float run(const PPParams& p0, int H, int W) {
+    auto kern = conv_pp_kernel<1, N9, 0, RES, PROBE, TEAMS>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    PPParams p = p0;
+    int lx = 0; while ((16 << lx) < W) ++lx;
+    int ly = 0; while ((8 << ly) < H) ++ly;
+    p.lx = lx; p.ly = ly; p.rot = getenv("ROT") ? atoi(getenv("ROT")) : 0;
+    const size_t lds = (size_t)N9 * 36864 + TEAMS * pp_patch_bytes(1);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(TEAMS == 2 ? 256 : 512), dim3(256 * TEAMS), lds, 0, p);
+    (void)hipEventRecord(e0);
+    const int reps = 5;
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, dim3(TEAMS == 2 ? 256 : 512), dim3(256 * TEAMS), lds, 0, p);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+    if (hipGetLastError() != hipSuccess) printf("launch error\n");
+    return ms * 1e3f / reps;
+}
+
+int main(int argc, char** argv) {
+    const int H = argc > 1 ? atoi(argv[1]) : 128, W = argc > 2 ? atoi(argv[2]) : 128, B = argc > 3 ? atoi(argv[3]) : 160, nch = argc > 4 ? atoi(argv[4]) : 1;
+    const size_t n = (size_t)B * H * W * 32;
+    float *in, *in2, *res, *out, *coef, *scale, *addv; double* stats; void* wimg;
+    (void)hipMalloc(&in, n * 4); (void)hipMalloc(&in2, n * 4); (void)hipMalloc(&res, n * 4); (void)hipMalloc(&out, n * 4);
+    std::vector<float> h(n); for (size_t i = 0; i < n; ++i) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 32768.f - 1.f;
+    (void)hipMemcpy(in, h.data(), n * 4, hipMemcpyHostToDevice); (void)hipMemcpy(in2, h.data(), n * 4, hipMemcpyHostToDevice); (void)hipMemcpy(res, h.data(), n * 4, hipMemcpyHostToDevice);
+    (void)hipMalloc(&coef, (size_t)B * 2 * 1024 * 4); std::vector<float> c((size_t)B * 2 * 1024, 0.5f); (void)hipMemcpy(coef, c.data(), c.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMalloc(&scale, (size_t)B * 8 * 4); std::vector<float> sc((size_t)B * 8, 1.0f); (void)hipMemcpy(scale, sc.data(), sc.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMalloc(&addv, (size_t)B * 32 * 4); (void)hipMemset(addv, 0, (size_t)B * 32 * 4);
+    (void)hipMalloc(&stats, (size_t)B * 64 * 8); (void)hipMemset(stats, 0, (size_t)B * 64 * 8);
+    (void)hipMalloc(&wimg, 36864); std::vector<_Float16> w(18432); for (size_t i = 0; i < w.size(); ++i) w[i] = (_Float16)(((int)(i * 40503u >> 4) % 200 - 100) * 0.01f); (void)hipMemcpy(wimg, w.data(), 36864, hipMemcpyHostToDevice);
+    PPParams p{};
+    for (int i = 0; i < nch; ++i) { p.ch[i] = PPChunk{}; p.ch[i].src = i == 0 ? in : in2; p.ch[i].wimg = wimg; p.ch[i].cstride = 32; p.ch[i].coff = 0; p.ch[i].xform = 2; p.ch[i].gn_c0 = 32 * i; p.ch[i].seg = i; }
+    p.n9 = nch; p.n1 = 0; p.B = B; p.H = H; p.W = W; p.out = out; p.addvec = addv; p.addvec_bs = 32;
+    p.res_scale = 1.f; p.stats_out = stats; p.out_scale = 1.f; p.coef = coef; p.coef_stride = 1024; p.scale = scale;
+    if (getenv("STAMPS")) {
+        unsigned long long* dbg; (void)hipMalloc(&dbg, 2 * 64 * 8 * 8); (void)hipMemset(dbg, 0, 2 * 64 * 8 * 8);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(pf::g_pp_dbg), &dbg, sizeof(dbg));
+        p.residual = atoi(getenv("STAMPS")) > 1 ? res : nullptr;
+        const float us = p.residual ? run<1, true, 16>(p, H, W) : run<1, false, 16>(p, H, W);
+        std::vector<unsigned long long> hs(2 * 64 * 8); (void)hipMemcpy(hs.data(), dbg, hs.size() * 8, hipMemcpyDeviceToHost);
+        printf("stamped run: %.1f us.  per step of workgroup 0 (cycles since its first stamp): wait | epilogue | transform | issue | barrier | mfma | barrier\n", us);
+        for (int tm = 0; tm < 2; ++tm)
+            for (int sidx = 8; sidx < 20; ++sidx) {
+                const unsigned long long* q = &hs[(tm * 64 + sidx) * 8];
+                printf("team %d step %2d  start %8llu : %6llu | %6llu | %6llu | %6llu | %6llu | %6llu | %6llu\n", tm, sidx, q[0] - hs[(tm * 64 + 8) * 8], q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[6] - q[5], q[7] - q[6]);
+            }
+        return 0;
+    }
+    if (nch == 1) {
+        p.residual = nullptr;
+        printf("%d x %d x %d, 1 chunk, residual 0:  full %7.1f | no MFMA %7.1f | no staging math %7.1f | no MFMA + no math %7.1f | no loads %7.1f | no stores %7.1f | no loads, no stores %7.1f | only barriers + LDS %7.1f  us\n",
+               B, H, W, run<1, false, 0>(p, H, W), run<1, false, 1>(p, H, W), run<1, false, 2>(p, H, W), run<1, false, 3>(p, H, W), run<1, false, 4>(p, H, W), run<1, false, 8>(p, H, W), run<1, false, 12>(p, H, W), run<1, false, 15>(p, H, W));
+        printf("   independent 4-wave workgroups, 2 per CU:  full %7.1f | no MFMA + no math %7.1f | no loads, no stores %7.1f\n", run<1, false, 0, 1>(p, H, W), run<1, false, 3, 1>(p, H, W), run<1, false, 12, 1>(p, H, W));
+        p.residual = res;
+        printf("   independent 4-wave workgroups, 2 per CU, residual:  full %7.1f | no MFMA + no math %7.1f | no loads, no stores %7.1f\n", run<1, true, 0, 1>(p, H, W), run<1, true, 3, 1>(p, H, W), run<1, true, 12, 1>(p, H, W));
+        printf("%d x %d x %d, 1 chunk, residual 1:  full %7.1f | no MFMA %7.1f | no staging math %7.1f | no MFMA + no math %7.1f | no loads %7.1f | no stores %7.1f | no loads, no stores %7.1f | only barriers + LDS %7.1f  us\n",
+               B, H, W, run<1, true, 0>(p, H, W), run<1, true, 1>(p, H, W), run<1, true, 2>(p, H, W), run<1, true, 3>(p, H, W), run<1, true, 4>(p, H, W), run<1, true, 8>(p, H, W), run<1, true, 12>(p, H, W), run<1, true, 15>(p, H, W));
+    } else {
+        p.residual = nullptr;
+        printf("%d x %d x %d, 2 chunks, residual 0:  full %7.1f | no MFMA %7.1f | no staging math %7.1f | no MFMA + no math %7.1f | no loads %7.1f | no stores %7.1f | no loads, no stores %7.1f | only barriers + LDS %7.1f  us\n",
+               B, H, W, run<2, false, 0>(p, H, W), run<2, false, 1>(p, H, W), run<2, false, 2>(p, H, W), run<2, false, 3>(p, H, W), run<2, false, 4>(p, H, W), run<2, false, 8>(p, H, W), run<2, false, 12>(p, H, W), run<2, false, 15>(p, H, W));
+    }
+    return 0;
+}

@@ -191,24 +191,27 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
         const long bpix = ((long)tl.b * p.H + tl.oy0) * p.W + tl.ox0;
         const int cstride = p.ch[C].cstride;
         S.ascale = p.scale != nullptr ? scale_c[8 * tl.b + p.ch[C].seg] : 1.0f;
+        // addresses = one uniform 64-bit base per step (scalar unit) + a 32-bit per-lane byte offset: pixel offset x (cstride * 4) as a
+        // 24-bit multiply-add (v_mad_u32_u24, full rate; the generic 64-bit form cost a v_mul_lo_u32 + v_lshl_add_u64 per load)
+        const unsigned cs4 = (unsigned)cstride * 4u, q16 = (unsigned)qi * 16u;
         if constexpr (C < N9) {
-            const float* base = p.ch[C].src + (bpix - p.W - 1) * cstride + p.ch[C].coff + qi * 4;
+            const char* base = reinterpret_cast<const char*>(p.ch[C].src + (bpix - p.W - 1) * cstride + p.ch[C].coff);
             unsigned inval = 0;
 #pragma unroll
             for (int i = 0; i < PP_A9; ++i) inval |= (((pk9[i] >> 20) & (unsigned)tl.edge) != 0u ? 1u : 0u) << i;
             S.inval = inval;
-            const float* cb = p.coef + (size_t)tl.b * 2 * p.coef_stride + p.ch[C].gn_c0 + qi * 4;
-            S.csc = *reinterpret_cast<const float4*>(cb); S.csh = *reinterpret_cast<const float4*>(cb + p.coef_stride);
+            const char* cb = reinterpret_cast<const char*>(p.coef + (size_t)tl.b * 2 * p.coef_stride + p.ch[C].gn_c0);
+            S.csc = *reinterpret_cast<const float4*>(cb + q16); S.csh = *reinterpret_cast<const float4*>(cb + (unsigned)(p.coef_stride * 4) + q16);
 #pragma unroll
             for (int i = 0; i < PP_A9; ++i) {
-                const int px = ((inval >> i) & 1u) ? pix_safe : (int)(pk9[i] & 0xffffu);
-                S.ra[i] = *reinterpret_cast<const float4*>(base + (unsigned)(px * cstride));
+                const unsigned px = ((inval >> i) & 1u) ? (unsigned)pix_safe : (pk9[i] & 0xffffu);
+                S.ra[i] = *reinterpret_cast<const float4*>(base + (__umul24(px, cs4) + q16));
             }
         } else {
-            const float* base = p.ch[C].src + bpix * cstride + p.ch[C].coff + qi * 4;
+            const char* base = reinterpret_cast<const char*>(p.ch[C].src + bpix * cstride + p.ch[C].coff);
             S.inval = 0;
 #pragma unroll
-            for (int i = 0; i < TH / 2; ++i) S.ra[i] = *reinterpret_cast<const float4*>(base + (unsigned)((pixoff1 + 2 * i * p.W) * cstride));
+            for (int i = 0; i < TH / 2; ++i) S.ra[i] = *reinterpret_cast<const float4*>(base + (__umul24((unsigned)(pixoff1 + 2 * i * p.W), cs4) + q16));
         }
     };
 

@@ -1572,10 +1572,49 @@ def test_conv_dma_path_is_selected_at_the_solver_batch_and_bit_identical(hip, tm
     finally:
         os.environ.pop("PNPFLOW_HIP_PROFILE_CSV", None)
     rows = list(csv.DictReader(open(path)))
-    dma_rows = [r for r in rows if int(r["dma"])]
+    dma_rows = [r for r in rows if int(r["dma"]) == 1]          # (2 = conv_pp.hip: the 32-channel level, test below)
     assert len(rows) == 142 and 30 <= len(dma_rows) <= 80, (len(rows), len(dma_rows))
     assert all(int(r["Cout"]) % 128 == 0 for r in dma_rows)
     assert any(int(r["up"]) == 1 for r in dma_rows) and any(int(r["taps0"]) == 1 and int(r["Cout"]) == 768 for r in dma_rows)
+
+
+def test_conv_pp_path_is_selected_on_the_32_channel_level_and_fp32_equivalent(hip, tmp_path):
+    """conv_pp.hip (persistent workgroups, LDS-resident weights, two-step register prefetch, lane-transpose epilogue) takes the stride-1
+    convs of the 32-channel full-resolution level at the solver's U-Net batch - ResidualBlock conv1 / conv2 of the down path (with the
+    identity residual), the cat[h, skip] convs of the up path (two / three 3x3 chunks) and the conv2 launches with the folded 1x1
+    shortcut (models.py:58-113) - and nothing else; the forward agrees with the one where every launch stays on conv_mfma16_kernel to
+    fp32 rounding (same products, two interleaved fp32 accumulation chains instead of one: 2e-6 of max|v|), at 128^2 and at 256^2."""
+    import csv, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for net, B in (("celeba128", 160), ("afhq256", 40)):
+        outs = {}
+        for pp in ("0", "1"):
+            env = dict(os.environ, PNPFLOW_HIP_PP=pp)
+            f = str(tmp_path / f"v_{net}_pp{pp}.npy")
+            r = subprocess.run([sys.executable, "tools/gpu_dma_check.py", "run", net, str(B), "1", f], cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs[pp] = np.load(f)
+        ref = np.abs(outs["0"]).max()
+        assert np.isfinite(outs["1"]).all() and np.abs(outs["0"] - outs["1"]).max() <= 2e-6 * ref, (net, np.abs(outs["0"] - outs["1"]).max(), ref)
+    if os.environ.get("PNPFLOW_HIP_PP") not in (None, "1"):
+        return
+    m, cfg, sd = model_for("celeba128")
+    x = det_normal((160, 3, 128, 128), 5).cuda(); t = torch.full((160,), 0.3).cuda()
+    m(x, t)
+    path = str(tmp_path / "layers_pp.csv")
+    os.environ["PNPFLOW_HIP_PROFILE_CSV"] = path
+    try:
+        m.profile(True); m(x, t); m.profile_read(); m.profile(False)
+    finally:
+        os.environ.pop("PNPFLOW_HIP_PROFILE_CSV", None)
+    rows = list(csv.DictReader(open(path)))
+    pp_rows = [r for r in rows if int(r["dma"]) == 2]
+    assert len(pp_rows) == 26, len(pp_rows)          # 12 + 6 + 6 + 1 + 1 launches of K = 288 / 576 / 352 / 864 / 384
+    assert all(int(r["Cout"]) == 32 and int(r["H"]) == 128 and int(r["stride"]) == 1 and int(r["up"]) == 0 for r in pp_rows)
+    assert sorted(set(int(r["K"]) for r in pp_rows)) == [288, 352, 384, 576, 864]
+    # small batches stay on the one-tile-per-workgroup kernel (a persistent grid needs a few tiles per team)
+    m2, _, _ = model_for("tiny4")
+    m2(det_normal((2, 3, 64, 64), 6).cuda(), torch.full((2,), 0.3).cuda())
 
 
 # ---------------------------------------------------------------------------------------------

@@ -279,7 +279,7 @@ def conv_roofline(r, precision, workload):
     # kernel classes: the launcher picks the tile by Cout (<= 32: <2,1,4,1>; <= 64: <4,1,2,2>; else <4,1,1,4> or conv_dma)
     cls = {}
     for w in rows:
-        key = "conv_dma_kernel (+ prep_split)" if int(w["dma"]) else ("conv_mfma16_kernel<2,1,4,1> (Cout 32)" if int(w["Cout"]) <= 32 else
+        key = "conv_pp_kernel (Cout 32, persistent)" if int(w["dma"]) == 2 else "conv_dma_kernel (+ prep_split)" if int(w["dma"]) else ("conv_mfma16_kernel<2,1,4,1> (Cout 32)" if int(w["Cout"]) <= 32 else
                "conv_mfma16_kernel<4,1,2,2> (Cout 64)" if int(w["Cout"]) <= 64 else "conv_mfma16_kernel<4,1,1,4> (Cout >= 128)")
         c = cls.setdefault(key, dict(us=0.0, mb=0.0, n=0, gflop=0.0))
         c["us"] += float(w["us"]); c["mb"] += float(w["alg_mb"]); c["n"] += 1; c["gflop"] += float(w["gflop"])
@@ -291,7 +291,7 @@ def conv_roofline(r, precision, workload):
     fam = dict(bound="mfma", achieved=round(ach, 2), peak=dtype_peak, unit="TFLOP/s", frac=round(ach / dtype_peak, 4),
                launches=int(launches // n_fw), avg_launch_us=round(ms * 1e3 / max(1, launches), 2),
                algorithmic_gflop_per_launch=round(flops / max(1, launches) / 1e9, 4),
-               kernel="conv family: conv_dma_kernel (LDS-DMA A operand from the prep_split pass; selected where a prepped element feeds >= 2000 MACs) + conv_mfma16_kernel "
+               kernel="conv family: conv_pp_kernel (persistent, LDS-resident weights: the 32-channel level) + conv_dma_kernel (LDS-DMA A operand from the prep_split pass; selected where a prepped element feeds >= 2000 MACs) + conv_mfma16_kernel "
                       "(register-staged) - f16 32x32x16 MFMA implicit GEMM, " + {0: "exact fp32 MFMA (conv_mfma_kernel)", 1: "3 MFMAs per product (fp32-equivalent split)", 2: "1 MFMA per product (hi-only operands)"}[precision])
     if precision == 1:
         fam.update(mfma_tflops_executed=round(3 * ach, 2), frac_executed=round(3 * ach / dtype_peak, 4))

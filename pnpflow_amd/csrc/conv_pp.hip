@@ -472,7 +472,9 @@ bool conv_pp_supported(const ConvParams& p, int stride, int up, int terms) {
     if (p.Cout != 32 || p.out_cstride != 32 || (p.residual != nullptr && p.res_cstride != 32)) return false;
     if (p.H % TH || p.W % 16 || p.Hs != p.H || p.Ws != p.W) return false;
     if (ilog2_exact(p.H / TH) < 0 || ilog2_exact(p.W / 16) < 0) return false;
-    if ((long)p.B * (p.H / TH) * (p.W / 16) < 8L * 256) return false;           // a persistent grid needs a few tiles per team (small batches stay on conv_mfma16)
+    // a persistent grid pays its prologue (weights -> LDS per workgroup, two-step pipeline fill) over >= 32 tiles per team: measured at 256^2,
+    // B = 8 / 16 / 32 / 80 -> +11 % / +1.5 % / -1.4 % / -3 % on the whole forward; smaller launches stay on conv_mfma16
+    if ((long)p.B * (p.H / TH) * (p.W / 16) < 32L * 512) return false;
     int n9 = 0, n1 = 0;
     for (int i = 0; i < p.nseg; ++i) {
         const ConvSeg& s = p.seg[i];

@@ -157,10 +157,15 @@ def measured_traffic(workload, kernel_class=None):
         if kernel_class:
             pat = kernel_class.split(" ")[0].replace("<", "<").split("<")
             name, tile = pat[0], (pat[1].rstrip(">").split(",") if len(pat) > 1 else None)
+            tot_b, tot_n = 0.0, 0
             for k in rec.get("kernels", []):
                 kn = k["kernel"].replace(" ", "")
                 if name in kn and (tile is None or ("<" + ",".join(tile) + ",") in kn):
-                    return (k["read_mb_per_launch"] + k["write_mb_per_launch"]) * 1e6, rec.get("source")
+                    if tile is not None:
+                        return (k["read_mb_per_launch"] + k["write_mb_per_launch"]) * 1e6, rec.get("source")
+                    tot_b += (k["read_mb_per_launch"] + k["write_mb_per_launch"]) * 1e6 * k["launches"]; tot_n += k["launches"]
+            if tot_n:          # a class made of several instantiations (conv_pp_kernel<chunk structure>): launch-weighted mean
+                return tot_b / tot_n, rec.get("source")
         return float(rec["bytes_per_launch"]), rec.get("source")
     except Exception:           # noqa: BLE001
         return None, None

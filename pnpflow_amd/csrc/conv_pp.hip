@@ -266,6 +266,10 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
     float run1[4] = {0.f, 0.f, 0.f, 0.f}, run2[4] = {0.f, 0.f, 0.f, 0.f};
     int run_b = -1, run_n = 0;
 
+    // one k16-step: A fragments (hi, lo) of the wave's M-tiles + B fragments (hi, lo) from LDS, three MFMAs per M-tile into the accumulator
+    // chain of the step's parity.  (Fragments requested one / two steps ahead in named register sets shorten the MFMA phase from 3.5 k to
+    // 2.6 k cycles - r4 stamps - and change nothing end to end: the VALU phase and the memory queue are the critical path; not kept, the
+    // registers are needed by the two prefetch sets.)
     auto mma_step = [&](unsigned wbase, int s, int ky, int kx, int j) __attribute__((always_inline)) {
         const f16x8 bh = *reinterpret_cast<const f16x8*>(smem + wbase + (unsigned)((s * 2 + 0) * 1024));
         const f16x8 bl = *reinterpret_cast<const f16x8*>(smem + wbase + (unsigned)((s * 2 + 1) * 1024));

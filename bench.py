@@ -284,7 +284,7 @@ def conv_roofline(r, precision, workload):
     # kernel classes: the launcher picks the tile by Cout (<= 32: <2,1,4,1>; <= 64: <4,1,2,2>; else <4,1,1,4> or conv_dma)
     cls = {}
     for w in rows:
-        key = "conv_pp_kernel (Cout 32, persistent)" if int(w["dma"]) == 2 else "conv_dma_kernel (+ prep_split)" if int(w["dma"]) else ("conv_mfma16_kernel<2,1,4,1> (Cout 32)" if int(w["Cout"]) <= 32 else
+        key = "conv_pp_kernel (Cout 32, persistent)" if int(w["dma"]) == 2 else "conv_pp64_kernel (Cout 64, persistent)" if int(w["dma"]) == 3 else "conv_dma_kernel (+ prep_split)" if int(w["dma"]) else ("conv_mfma16_kernel<2,1,4,1> (Cout 32)" if int(w["Cout"]) <= 32 else
                "conv_mfma16_kernel<4,1,2,2> (Cout 64)" if int(w["Cout"]) <= 64 else "conv_mfma16_kernel<4,1,1,4> (Cout >= 128)")
         c = cls.setdefault(key, dict(us=0.0, mb=0.0, n=0, gflop=0.0))
         c["us"] += float(w["us"]); c["mb"] += float(w["alg_mb"]); c["n"] += 1; c["gflop"] += float(w["gflop"])

@@ -25,47 +25,15 @@
 // pixel in column c stored at slot q ^ ((c >> 1) & 7): the 16 pixels a ds_read_b128 lane group touches ({0-3, 12-15} of one tile row +
 // {4-11} of the next, shifted by the tap) land on 16 different 16-byte bank slots for every tap (the swizzle conv_dma.hip uses).
 #include <cstdlib>
-#include "pf_common.h"
+#include "pp_common.h"
 
 namespace pf {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // MT = M-tiles (2 rows x 16 pixels) per wave: a team's tile is 8 MT rows x 16 columns, its halo patch (8 MT + 2) x 18 pixels x 128 B
 constexpr int PP_PW = 18;
 constexpr int pp_npix(int MT) { return (8 * MT + 2) * PP_PW; }
 constexpr int pp_patch_bytes(int MT) { return pp_npix(MT) * 128; }                         // MT 1: 23 040 B, MT 2: 41 472 B per team
 constexpr int pp_a9(int MT) { return (pp_npix(MT) * 8 + 255) / 256; }                      // float4 per lane of a 9-tap chunk: 6 / 11
-typedef const __attribute__((address_space(4))) float* pp_float_cptr;
-
-// same expressions as conv_mfma16.hip (bit-identical staging)
-__device__ __forceinline__ float silu_pp(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_quad(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-
-// 4 x 4 transpose between the registers a0..a3 and the four lanes {k, k + 8, k + 16, k + 24} of a 32-lane half (k = lane & 7): in, a[i] of
-// lane group g holds element (i, g); out, a[g'] of lane group i' holds element (i', g').  Lane bit 4 is exchanged with v_permlane16_swap
-// (one instruction per register pair, gfx950), lane bit 3 with a DPP row rotation by 8 + selects.  With MFMA column n = 8 g + k carrying
-// output channel 4 k + g (the weight image is packed that way) a lane ends up with FOUR CONSECUTIVE channels of one pixel, and the
-// eight lanes k = 0..7 with the pixel's whole 128-byte row: stores and residual loads are 64 contiguous bytes per lane quad (the quad-
-// local DPP transpose of the first version gave every lane of a quad a different pixel: 4 x the vector-memory requests, 107 of 255 us).
-__device__ __forceinline__ void oct_transpose(float& a0, float& a1, float& a2, float& a3, bool bit3) {
-    constexpr int ROR8 = 0x128;                           // row_ror:8 = lane ^ 8 inside a row of 16
-    // (inline asm: with the builtin hipcc 7.2 folds the SECOND result of llvm.amdgcn.permlane16.swap onto the first in this function - seen
-    // in the IR at -O1; the pads are the 2 wait states a VALU write needs before a v_permlane read, and before the DPP reads that follow)
-    float b0 = a0, b1 = a1, b2 = a2, b3 = a3;
-    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1" : "+v"(b0), "+v"(b2), "+v"(b1), "+v"(b3));
-    // (every DPP read is executed by ALL lanes before the selects)
-    const float d0 = dpp_quad<ROR8>(b0), d1 = dpp_quad<ROR8>(b1), d2 = dpp_quad<ROR8>(b2), d3 = dpp_quad<ROR8>(b3);
-    a0 = bit3 ? d1 : b0; a1 = bit3 ? b1 : d0; a2 = bit3 ? d3 : b2; a3 = bit3 ? b3 : d2;
-}
-
-struct PPTile { int b, oy0, ox0, edge; };      // edge bits: 1 top, 2 bottom, 4 left, 8 right (patch rows / columns outside the image)
 
 // PROBE (tools/ubench/conv_pp_probe.hip only; the library instantiates PROBE = 0): timing-only removal of one ingredient -
 // 1 no MFMA phase body, 2 no staging arithmetic, 4 no global loads, 8 no global stores / atomics
@@ -76,7 +44,6 @@ struct PPTile { int b, oy0, ox0, edge; };      // edge bits: 1 top, 2 bottom, 4 
 // by two and every register has a static name), the residual of a tile two steps before the epilogue that adds it.  One step of distance
 // was not enough: the burst had a single MFMA phase (~0.9 us) to land and every VALU phase began with ~1 us of exposed latency
 // (r4: on-chip 78 us + loads 78 us + stores 97 us were ADDITIVE, 267 us against a 132 us memory skeleton).
-template <int K> struct ic { static constexpr int value = K; };
 #ifdef PP_PROBE_BUILD
 __device__ unsigned long long* g_pp_dbg = nullptr;      // PROBE & 16: s_memtime stamps of workgroup 0, [team][step][8]
 #define PP_STAMP(k) do { if constexpr ((PROBE & 16) != 0) { if (blockIdx.x == 0 && t == 0 && stamp_n < 64) g_pp_dbg[(team * 64 + stamp_n) * 8 + (k)] = __builtin_readcyclecounter(); } } while (0)
@@ -216,14 +183,10 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
     };
 
     auto split_store = [&](float4 v, unsigned addr) __attribute__((always_inline)) {
-        // opaque to the optimiser: the hi that is stored and the hi that is subtracted must be the SAME rounding of the SAME fp32 value
-        asm("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
-        f16x4 h, l;
-        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-        l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
-        l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
-        *reinterpret_cast<f16x4*>(smem + addr) = h;
-        *reinterpret_cast<f16x4*>(smem + (addr ^ 64u)) = l;                       // the lo piece q + 4 sits at slot (q ^ s) ^ 4
+        uint2 h, l;
+        split4_pp(v, h.x, h.y, l.x, l.y);
+        *reinterpret_cast<uint2*>(smem + addr) = h;
+        *reinterpret_cast<uint2*>(smem + (addr ^ 64u)) = l;                       // the lo piece q + 4 sits at slot (q ^ s) ^ 4
     };
 
     auto transform = [&](const Pre& S, auto C_) __attribute__((always_inline)) {
@@ -235,7 +198,7 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
                 float4 v = S.ra[i];
                 if constexpr ((PROBE & 2) == 0) {
                     v.x = v.x * S.csc.x + S.csh.x; v.y = v.y * S.csc.y + S.csh.y; v.z = v.z * S.csc.z + S.csh.z; v.w = v.w * S.csc.w + S.csh.w;
-                    if (silu) { v.x = silu_pp(v.x); v.y = silu_pp(v.y); v.z = silu_pp(v.z); v.w = silu_pp(v.w); }
+                    if (silu) silu4_pp(v);
                     const float f = ((S.inval >> i) & 1u) ? 0.0f : S.ascale;
                     v.x *= f; v.y *= f; v.z *= f; v.w *= f;
                 }

@@ -1617,6 +1617,42 @@ def test_conv_pp_path_is_selected_on_the_32_channel_level_and_fp32_equivalent(hi
     m2(det_normal((2, 3, 64, 64), 6).cuda(), torch.full((2,), 0.3).cuda())
 
 
+def test_conv_pp64_path_is_selected_on_the_64_channel_level_and_fp32_equivalent(hip, tmp_path):
+    """conv_pp64.hip (persistent two-team kernel, 16-channel K-chunks, weights streamed through a two-slot LDS ring by LDS-DMA, 64 x 64
+    wave tiles) takes the GroupNorm-ed 3x3 convs of the 64-channel level that carry neither an identity residual nor a folded 1x1
+    shortcut - ResidualBlock conv1 of the down path, conv1 over cat[h, skip] of the up path (models.py:58-113) - and nothing else; the
+    forward agrees with the one where those launches stay on conv_mfma16_kernel to fp32 rounding (same products, another summation
+    order: 2e-6 of max|v|), at 128^2 and at 256^2."""
+    import csv, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for net, B in (("celeba128", 160), ("afhq256", 40)):
+        outs = {}
+        for pp in ("0", "1"):
+            env = dict(os.environ, PNPFLOW_HIP_PP64=pp)
+            f = str(tmp_path / f"v_{net}_pp64_{pp}.npy")
+            r = subprocess.run([sys.executable, "tools/gpu_dma_check.py", "run", net, str(B), "1", f], cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs[pp] = np.load(f)
+        ref = np.abs(outs["0"]).max()
+        assert np.isfinite(outs["1"]).all() and np.abs(outs["0"] - outs["1"]).max() <= 2e-6 * ref, (net, np.abs(outs["0"] - outs["1"]).max(), ref)
+    if os.environ.get("PNPFLOW_HIP_PP64") not in (None, "1"):
+        return
+    m, cfg, sd = model_for("celeba128")
+    x = det_normal((160, 3, 128, 128), 5).cuda(); t = torch.full((160,), 0.3).cuda()
+    m(x, t)
+    path = str(tmp_path / "layers_pp64.csv")
+    os.environ["PNPFLOW_HIP_PROFILE_CSV"] = path
+    try:
+        m.profile(True); m(x, t); m.profile_read(); m.profile(False)
+    finally:
+        os.environ.pop("PNPFLOW_HIP_PROFILE_CSV", None)
+    rows = list(csv.DictReader(open(path)))
+    pp_rows = [r for r in rows if int(r["dma"]) == 3]
+    assert len(pp_rows) == 13, len(pp_rows)          # 1 + 5 + 1 + 5 + 1 launches of K = 288 / 576 / 864 / 1152 / 1728
+    assert all(int(r["Cout"]) == 64 and int(r["H"]) == 64 and int(r["stride"]) == 1 and int(r["up"]) == 0 for r in pp_rows)
+    assert sorted(set(int(r["K"]) for r in pp_rows)) == [288, 576, 864, 1152, 1728]
+
+
 # ---------------------------------------------------------------------------------------------
 # third-party pins (tools/pin_thirdparty.py; VERDICT r3 item 6): run when the fixtures exist, otherwise skipped as "parity unpinned"
 # ---------------------------------------------------------------------------------------------

@@ -15,7 +15,7 @@
 //     weight stream is 16/3 x denser per matrix-pipe cycle than in the fp32 kernel, so the tile shapes
 //     give every wave 4 (or 2) M-tiles per N-tile: one B fragment pair feeds 12 (6) MFMAs.
 #include <cstdlib>
-#include "pf_common.h"
+#include "pp_common.h"
 
 namespace pf {
 
@@ -130,18 +130,18 @@ __global__ __launch_bounds__(256, conv16_lb(MT, WM, KC)) void conv_mfma16_kernel
                 }
                 v.x *= a_scale; v.y *= a_scale; v.z *= a_scale; v.w *= a_scale;
                 if (!(cok && a_pix[i] >= 0)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                // opaque to the optimiser: the hi that is stored and the hi that is subtracted must be the SAME rounding of
-                // the SAME fp32 value.  With -ffp-contract=fast hipcc may otherwise fuse the producing multiply into the
-                // subtraction (v_fma_mix*) while the stored hi comes from the rounded product - they differ at double-rounding
-                // ties (this happened in attention.hip; here the select above currently prevents it, this keeps it that way)
-                asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
-                f16x4 h, l;
-                h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-                *reinterpret_cast<f16x4*>(s_patch + a_lds) = h;
                 if constexpr (TERMS == 3) {
-                    l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
-                    l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
-                    *reinterpret_cast<f16x4*>(s_patch + a_lds + KH) = l;
+                    // hi = RNE16(v), lo = RNE16(v - hi) in six instructions (pp_common.h: hipcc's translation of the C++ expression takes 13;
+                    // bit-identical, and no measurable difference on this kernel: 49.7 vs 49.6 ms per forward, r4); the asm also
+                    // keeps the hi that is stored and the hi that is subtracted the SAME rounding of the SAME fp32 value
+                    uint2 h, l;
+                    split4_pp(v, h.x, h.y, l.x, l.y);
+                    *reinterpret_cast<uint2*>(s_patch + a_lds) = h;
+                    *reinterpret_cast<uint2*>(s_patch + a_lds + KH) = l;
+                } else {
+                    f16x4 h;
+                    h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+                    *reinterpret_cast<f16x4*>(s_patch + a_lds) = h;
                 }
             }
         }

@@ -35,9 +35,6 @@ constexpr int pp_npix(int MT) { return (8 * MT + 2) * PP_PW; }
 constexpr int pp_patch_bytes(int MT) { return pp_npix(MT) * 128; }                         // MT 1: 23 040 B, MT 2: 41 472 B per team
 constexpr int pp_a9(int MT) { return (pp_npix(MT) * 8 + 255) / 256; }                      // float4 per lane of a 9-tap chunk: 6 / 11
 
-// PROBE (tools/ubench/conv_pp_probe.hip only; the library instantiates PROBE = 0): timing-only removal of one ingredient -
-// 1 no MFMA phase body, 2 no staging arithmetic, 4 no global loads, 8 no global stores / atomics
-//
 // The K-chunk structure is compile-time: N9 nine-tap chunks (GroupNorm(+SiLU) staging) followed by N1 one-tap chunks (raw: a folded 1x1
 // shortcut), NCH = N9 + N1 steps per tile.  Register prefetch is TWO steps deep: the patch of step s + 2 is requested at the end of the
 // VALU phase of step s into the register set that phase has just staged (sets alternate with the step parity, so the tile loop is unrolled
@@ -45,13 +42,14 @@ constexpr int pp_a9(int MT) { return (pp_npix(MT) * 8 + 255) / 256; }           
 // was not enough: the burst had a single MFMA phase (~0.9 us) to land and every VALU phase began with ~1 us of exposed latency
 // (r4: on-chip 78 us + loads 78 us + stores 97 us were ADDITIVE, 267 us against a 132 us memory skeleton).
 #ifdef PP_PROBE_BUILD
-__device__ unsigned long long* g_pp_dbg = nullptr;      // PROBE & 16: s_memtime stamps of workgroup 0, [team][step][8]
-#define PP_STAMP(k) do { if constexpr ((PROBE & 16) != 0) { if (blockIdx.x == 0 && t == 0 && stamp_n < 64) g_pp_dbg[(team * 64 + stamp_n) * 8 + (k)] = __builtin_readcyclecounter(); } } while (0)
+// tools/ubench/conv_pp_probe.hip only: s_memtime stamps of workgroup 0, [team][step][8]
+__device__ unsigned long long* g_pp_dbg = nullptr;
+#define PP_STAMP(k) do { if (stamp_buf != nullptr && blockIdx.x == 0 && t == 0 && stamp_n < 64) stamp_buf[(team * 64 + stamp_n) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PP_STAMP(k) do { } while (0)
 #endif
 
-template <int MT, int N9, int N1, bool RES, int PROBE = 0, int TEAMS = 2>
+template <int MT, int N9, int N1, bool RES, int TEAMS = 2>
 __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams p) {
     constexpr int NCH = N9 + N1;
     constexpr int PP_NPIX = pp_npix(MT), PP_PATCH_BYTES = pp_patch_bytes(MT), PP_A9 = pp_a9(MT), TH = 8 * MT;
@@ -154,7 +152,6 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
 
     auto issue_patch = [&](Pre& S, const PPTile& tl, auto C_) __attribute__((always_inline)) {
         constexpr int C = decltype(C_)::value;
-        if constexpr ((PROBE & 4) != 0) { return; }
         const long bpix = ((long)tl.b * p.H + tl.oy0) * p.W + tl.ox0;
         const int cstride = p.ch[C].cstride;
         S.ascale = p.scale != nullptr ? scale_c[8 * tl.b + p.ch[C].seg] : 1.0f;
@@ -196,12 +193,10 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
 #pragma unroll
             for (int i = 0; i < PP_A9; ++i) {
                 float4 v = S.ra[i];
-                if constexpr ((PROBE & 2) == 0) {
-                    v.x = v.x * S.csc.x + S.csh.x; v.y = v.y * S.csc.y + S.csh.y; v.z = v.z * S.csc.z + S.csh.z; v.w = v.w * S.csc.w + S.csh.w;
-                    if (silu) silu4_pp(v);
-                    const float f = ((S.inval >> i) & 1u) ? 0.0f : S.ascale;
-                    v.x *= f; v.y *= f; v.z *= f; v.w *= f;
-                }
+                v.x = v.x * S.csc.x + S.csh.x; v.y = v.y * S.csc.y + S.csh.y; v.z = v.z * S.csc.z + S.csh.z; v.w = v.w * S.csc.w + S.csh.w;
+                if (silu) silu4_pp(v);
+                const float f = ((S.inval >> i) & 1u) ? 0.0f : S.ascale;
+                v.x *= f; v.y *= f; v.z *= f; v.w *= f;
                 // (the last float4 exists for the first LASTN threads only)
                 if (i < PP_A9 - 1 || t < LASTN) split_store(v, ldsw9 + (unsigned)(i * 4096) + (((pk9[i] >> 16) & 7u) << 4));
             }
@@ -261,7 +256,7 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
     };
 
     auto flush_stats = [&]() __attribute__((always_inline)) {
-        if (p.stats_out == nullptr || run_b < 0 || (PROBE & 8) != 0) return;
+        if (p.stats_out == nullptr || run_b < 0) return;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             double a = (double)run1[j], q = (double)run2[j];
@@ -297,11 +292,9 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
                     const float rsc = p.res_scale; const float4 r4 = R.rv[mt][g];
                     v.x = fmaf(r4.x, rsc, v.x); v.y = fmaf(r4.y, rsc, v.y); v.z = fmaf(r4.z, rsc, v.z); v.w = fmaf(r4.w, rsc, v.w);
                 }
-                if constexpr ((PROBE & 8) == 0) {
-                    // pixel 8 g + 4 hi + ((lane >> 3) & 3) of the M-tile: row (g >> 1) of its two rows, column 8 (g & 1) + 4 hi + ((lane >> 3) & 3)
-                    char* dst = reinterpret_cast<char*>(obase) + (size_t)((mt * 2 + (g >> 1)) * p.W) * 128 + (g & 1) * 1024 + e_lane;
-                    *reinterpret_cast<float4*>(dst) = v;
-                }
+                // pixel 8 g + 4 hi + ((lane >> 3) & 3) of the M-tile: row (g >> 1) of its two rows, column 8 (g & 1) + 4 hi + ((lane >> 3) & 3)
+                char* dst = reinterpret_cast<char*>(obase) + (size_t)((mt * 2 + (g >> 1)) * p.W) * 128 + (g & 1) * 1024 + e_lane;
+                *reinterpret_cast<float4*>(dst) = v;
                 run1[0] += v.x; run1[1] += v.y; run1[2] += v.z; run1[3] += v.w;
                 run2[0] += v.x * v.x; run2[1] += v.y * v.y; run2[2] += v.z * v.z; run2[3] += v.w * v.w;
             }
@@ -309,7 +302,6 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
     };
 
     auto issue_res = [&](Res& R, const PPTile& tl) __attribute__((always_inline)) {
-        if constexpr ((PROBE & 4) != 0) { return; }
         R.addv = p.addvec != nullptr ? p.addvec[(size_t)tl.b * p.addvec_bs + ch_of_col] : 0.f;
         if constexpr (RES) {
             const char* rbase = reinterpret_cast<const char*>(p.residual + (((size_t)tl.b * p.H + tl.oy0 + wm * 2 * MT) * p.W + tl.ox0) * 32);
@@ -342,10 +334,7 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
         }
         const unsigned wbase = (unsigned)wlds(C) + b_lane;
         __builtin_amdgcn_s_setprio(1);
-        if constexpr ((PROBE & 1) != 0) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) { acc[mt][0] += (float)wbase; acc2[mt][0] += 1.f; }
-        } else if constexpr (C < N9) {
+        if constexpr (C < N9) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -358,6 +347,9 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
     };
 
     int stamp_n = 0; (void)stamp_n;
+#ifdef PP_PROBE_BUILD
+    unsigned long long* const stamp_buf = g_pp_dbg;      // null: no stamps (the probe's plain timing runs)
+#endif
     // ---- one step = VALU phase + MFMA phase of chunk C of the team's it-th tile (PAR = it & 1) -------------------------------------------
     // register set of step (it, C): the step's global index it * NCH + C, modulo 2
     auto step = [&](int it, auto PAR_, auto C_, bool last_step) __attribute__((always_inline)) {
@@ -367,7 +359,6 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
         const PPTile tl = tile_of(it);
         // ---- VALU phase ---------------------------------------------------------------------------------------------------------------
         PP_STAMP(0);
-        if constexpr ((PROBE & 16) != 0) { asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); }      // (stamp 1 = the requests of two steps ago have landed)
         PP_STAMP(1);
         if constexpr (C == 0) epilogue(PAR == 0 ? res1 : res0, tile_of(it - 1), live_of(it - 1) && it > 0);      // the previous tile (parity PAR ^ 1)
         PP_STAMP(2);
@@ -461,7 +452,7 @@ bool conv_pp_supported(const ConvParams& p, int stride, int up, int terms) {
 template <int N9, int N1, bool RES, int TEAMS>
 static hipError_t launch_pp_tt(const PPParams& p0, hipStream_t s) {
     static unsigned long long attr_set = 0ull;
-    auto kern = conv_pp_kernel<PP_MT, N9, N1, RES, 0, TEAMS>;
+    auto kern = conv_pp_kernel<PP_MT, N9, N1, RES, TEAMS>;
     { hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(kern), attr_set, 160 * 1024); if (e != hipSuccess) return e; }
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }

@@ -46,7 +46,7 @@ __device__ __forceinline__ void glds16_pp(unsigned voff, const char* sbase, unsi
 #ifdef PP_PROBE_BUILD
 // tools/ubench/conv_pp64_probe.hip only: s_memtime stamps of workgroup 0, [team][step][8]
 __device__ unsigned long long* g_pp64_dbg = nullptr;
-#define P64_STAMP(k) do { if (blockIdx.x == 0 && t == 0 && stamp_n < 64) g_pp64_dbg[(team * 64 + stamp_n) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define P64_STAMP(k) do { if (stamp_buf != nullptr && blockIdx.x == 0 && t == 0 && stamp_n < 64) stamp_buf[(team * 64 + stamp_n) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define P64_STAMP(k) do { } while (0)
 #endif
@@ -333,6 +333,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp64_kernel(const PPParams p) {
     // ---- one step = VALU phase + MFMA phase of chunk c of the team's it-th tile; SI = c & 1 (nch is even: the step's global parity, i.e.
     // its coefficient set AND its ring slot) ----------------------------------------------------------------------------------------------
     int stamp_n = 0; (void)stamp_n;
+#ifdef PP_PROBE_BUILD
+    unsigned long long* const stamp_buf = g_pp64_dbg;      // null: no stamps (the probe's plain timing runs)
+#endif
     Desc dn;            // descriptor of the step AFTER the current one
     auto step = [&](int it, int c, auto SI_, bool last_step) __attribute__((always_inline)) {
         constexpr int SI = decltype(SI_)::value;

@@ -45,12 +45,16 @@ int main(int argc, char** argv) {
     p.res_scale = 1.f; p.stats_out = stats; p.out_scale = 1.f; p.coef = coef; p.coef_stride = 1024; p.scale = scale;
     p.residual = useres ? res : nullptr;
     unsigned long long* dbg; (void)hipMalloc(&dbg, 2 * 64 * 8 * 8); (void)hipMemset(dbg, 0, 2 * 64 * 8 * 8);
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(pf::g_pp64_dbg), &dbg, sizeof(dbg));
-    float us = 0;
-    if (MT == 2 && !useres) us = run<2, false>(p, H, W);
-    else if (MT == 1 && !useres) us = run<1, false>(p, H, W);
-    else if (MT == 1 && useres) us = run<1, true>(p, H, W);
-    else { printf("variant not instantiated\n"); return 1; }
+    auto go = [&]() -> float {
+        if (MT == 2 && !useres) return run<2, false>(p, H, W);
+        if (MT == 1 && !useres) return run<1, false>(p, H, W);
+        if (MT == 1 && useres) return run<1, true>(p, H, W);
+        printf("variant not instantiated\n"); exit(1);
+    };
+    const float us_plain = go();
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(pf::g_pp64_dbg), &dbg, sizeof(dbg));      // stamps on from here
+    const float us = go();
+    printf("without stamps: %.1f us\n", us_plain);
     std::vector<unsigned long long> hs(2 * 64 * 8); (void)hipMemcpy(hs.data(), dbg, hs.size() * 8, hipMemcpyDeviceToHost);
     printf("%d x %d x %d x 64, %d chunks of 16, MT %d, residual %d: %.1f us.  workgroup 0, cycles: ring refill issue | transform + prefetch | epilogue | barrier | mfma | refill wait | barrier\n", B, H, W, nch, MT, useres, us);
     for (int tm = 0; tm < 2; ++tm)

@@ -1,5 +1,6 @@
-// Stand-alone timing of conv_pp_kernel (pnpflow_amd/csrc/conv_pp.hip) on synthetic tensors, with one ingredient removed at a time
-// (the kernel's PROBE template parameter; results are wrong by construction for PROBE != 0).
+// Stand-alone timing of conv_pp_kernel (pnpflow_amd/csrc/conv_pp.hip) on synthetic tensors, with s_memtime stamps of workgroup 0's phases
+// (compiled in by PP_PROBE_BUILD; the library has none).  The one-ingredient-removed timings of profiles/r04_level0_probes.md came from a
+// PROBE template parameter that existed during round 4 (commit c2787d4) and was removed from the kernel afterwards.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../pnpflow_amd/csrc -o conv_pp_probe conv_pp_probe.hip ; run: ./conv_pp_probe [H W B nch]
 #define PP_PROBE_BUILD 1
 #include "../../pnpflow_amd/csrc/conv_pp.hip"
@@ -7,14 +8,14 @@
 #include <vector>
 using namespace pf;
 
-template <int N9, bool RES, int PROBE, int TEAMS = 2>
+template <int N9, bool RES, int TEAMS = 2>
 static float run(const PPParams& p0, int H, int W) {
-    auto kern = conv_pp_kernel<1, N9, 0, RES, PROBE, TEAMS>;
+    auto kern = conv_pp_kernel<1, N9, 0, RES, TEAMS>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     PPParams p = p0;
     int lx = 0; while ((16 << lx) < W) ++lx;
     int ly = 0; while ((8 << ly) < H) ++ly;
-    p.lx = lx; p.ly = ly; p.rot = getenv("ROT") ? atoi(getenv("ROT")) : 0;
+    p.lx = lx; p.ly = ly; p.rot = getenv("ROT") ? atoi(getenv("ROT")) : 5;
     const size_t lds = (size_t)N9 * 36864 + TEAMS * pp_patch_bytes(1);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(TEAMS == 2 ? 256 : 512), dim3(256 * TEAMS), lds, 0, p);
@@ -43,33 +44,23 @@ int main(int argc, char** argv) {
     for (int i = 0; i < nch; ++i) { p.ch[i] = PPChunk{}; p.ch[i].src = i == 0 ? in : in2; p.ch[i].wimg = wimg; p.ch[i].cstride = 32; p.ch[i].coff = 0; p.ch[i].xform = 2; p.ch[i].gn_c0 = 32 * i; p.ch[i].seg = i; }
     p.n9 = nch; p.n1 = 0; p.B = B; p.H = H; p.W = W; p.out = out; p.addvec = addv; p.addvec_bs = 32;
     p.res_scale = 1.f; p.stats_out = stats; p.out_scale = 1.f; p.coef = coef; p.coef_stride = 1024; p.scale = scale;
-    if (getenv("STAMPS")) {
-        unsigned long long* dbg; (void)hipMalloc(&dbg, 2 * 64 * 8 * 8); (void)hipMemset(dbg, 0, 2 * 64 * 8 * 8);
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(pf::g_pp_dbg), &dbg, sizeof(dbg));
-        p.residual = atoi(getenv("STAMPS")) > 1 ? res : nullptr;
-        const float us = p.residual ? run<1, true, 16>(p, H, W) : run<1, false, 16>(p, H, W);
+    unsigned long long* dbg; (void)hipMalloc(&dbg, 2 * 64 * 8 * 8); (void)hipMemset(dbg, 0, 2 * 64 * 8 * 8);
+    p.residual = nullptr;
+    if (nch == 1) {
+        printf("%d x %d x %d x 32, 1 chunk: one 8-wave workgroup per CU %7.1f us | two 4-wave workgroups per CU %7.1f us | with residual %7.1f / %7.1f us\n", B, H, W,
+               run<1, false, 2>(p, H, W), run<1, false, 1>(p, H, W), (p.residual = res, run<1, true, 2>(p, H, W)), run<1, true, 1>(p, H, W));
+        p.residual = getenv("STAMPS") && atoi(getenv("STAMPS")) > 1 ? res : nullptr;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(pf::g_pp_dbg), &dbg, sizeof(dbg));      // stamps on from here
+        const float us = p.residual ? run<1, true, 2>(p, H, W) : run<1, false, 2>(p, H, W);
         std::vector<unsigned long long> hs(2 * 64 * 8); (void)hipMemcpy(hs.data(), dbg, hs.size() * 8, hipMemcpyDeviceToHost);
-        printf("stamped run: %.1f us.  per step of workgroup 0 (cycles since its first stamp): wait | epilogue | transform | issue | barrier | mfma | barrier\n", us);
+        printf("stamped (8-wave workgroup, residual %d): %.1f us.  workgroup 0, cycles per step: - | epilogue | transform | requests | barrier | mfma | barrier\n", p.residual ? 1 : 0, us);
         for (int tm = 0; tm < 2; ++tm)
-            for (int sidx = 8; sidx < 20; ++sidx) {
+            for (int sidx = 8; sidx < 16; ++sidx) {
                 const unsigned long long* q = &hs[(tm * 64 + sidx) * 8];
                 printf("team %d step %2d  start %8llu : %6llu | %6llu | %6llu | %6llu | %6llu | %6llu | %6llu\n", tm, sidx, q[0] - hs[(tm * 64 + 8) * 8], q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[6] - q[5], q[7] - q[6]);
             }
-        return 0;
-    }
-    if (nch == 1) {
-        p.residual = nullptr;
-        printf("%d x %d x %d, 1 chunk, residual 0:  full %7.1f | no MFMA %7.1f | no staging math %7.1f | no MFMA + no math %7.1f | no loads %7.1f | no stores %7.1f | no loads, no stores %7.1f | only barriers + LDS %7.1f  us\n",
-               B, H, W, run<1, false, 0>(p, H, W), run<1, false, 1>(p, H, W), run<1, false, 2>(p, H, W), run<1, false, 3>(p, H, W), run<1, false, 4>(p, H, W), run<1, false, 8>(p, H, W), run<1, false, 12>(p, H, W), run<1, false, 15>(p, H, W));
-        printf("   independent 4-wave workgroups, 2 per CU:  full %7.1f | no MFMA + no math %7.1f | no loads, no stores %7.1f\n", run<1, false, 0, 1>(p, H, W), run<1, false, 3, 1>(p, H, W), run<1, false, 12, 1>(p, H, W));
-        p.residual = res;
-        printf("   independent 4-wave workgroups, 2 per CU, residual:  full %7.1f | no MFMA + no math %7.1f | no loads, no stores %7.1f\n", run<1, true, 0, 1>(p, H, W), run<1, true, 3, 1>(p, H, W), run<1, true, 12, 1>(p, H, W));
-        printf("%d x %d x %d, 1 chunk, residual 1:  full %7.1f | no MFMA %7.1f | no staging math %7.1f | no MFMA + no math %7.1f | no loads %7.1f | no stores %7.1f | no loads, no stores %7.1f | only barriers + LDS %7.1f  us\n",
-               B, H, W, run<1, true, 0>(p, H, W), run<1, true, 1>(p, H, W), run<1, true, 2>(p, H, W), run<1, true, 3>(p, H, W), run<1, true, 4>(p, H, W), run<1, true, 8>(p, H, W), run<1, true, 12>(p, H, W), run<1, true, 15>(p, H, W));
     } else {
-        p.residual = nullptr;
-        printf("%d x %d x %d, 2 chunks, residual 0:  full %7.1f | no MFMA %7.1f | no staging math %7.1f | no MFMA + no math %7.1f | no loads %7.1f | no stores %7.1f | no loads, no stores %7.1f | only barriers + LDS %7.1f  us\n",
-               B, H, W, run<2, false, 0>(p, H, W), run<2, false, 1>(p, H, W), run<2, false, 2>(p, H, W), run<2, false, 3>(p, H, W), run<2, false, 4>(p, H, W), run<2, false, 8>(p, H, W), run<2, false, 12>(p, H, W), run<2, false, 15>(p, H, W));
+        printf("%d x %d x %d x 32, 2 chunks: %7.1f us\n", B, H, W, run<2, false, 2>(p, H, W));
     }
     return 0;
 }

@@ -15,7 +15,7 @@
 //     the residual-free launches only (a residual tile would need another 64 registers).
 // The number of chunks is a run-time value (4 for 64 -> 64, 8 for cat[64, 64] -> 64): the walk is a run-time loop over PAIRS of chunks so
 // that a step's parity (its coefficient set and its ring slot) is compile-time; the chunk descriptor of a step (scalar loads with a
-// run-time index) is fetched during the MFMA phase one step ahead.
+// run-time index) is requested at the end of the VALU phase two steps ahead (behind the barrier, not in front of the fragment waits).
 // What bounds it (r4 stamps, tools/ubench/conv_pp64_probe.hip): per step a wave issues ~330 staging instructions and 108 MFMAs; the
 // staging of one team runs beside the MFMA phase of the other ON THE SAME SIMDs and the two do not overlap freely - the VALU phase takes
 // 2.5 k cycles alone and 4-6 k beside the other team's MFMAs (3.5 k matrix-pipe cycles per phase, 4.7-5.2 k measured).
@@ -354,14 +354,17 @@ __global__ __launch_bounds__(512, 2) void conv_pp64_kernel(const PPParams p) {
         for (int i = 0; i < A9; ++i) { transform_one(C, i); issue_one(N, srN, i); }
         P64_STAMP(2);
         if (close) epilogue(res, tile_of(it - 1));
-        P64_STAMP(3);
-        __syncthreads();
-        P64_STAMP(4);
-        // ---- MFMA phase -----------------------------------------------------------------------------------------------------------------
+        // the descriptor of step + 2 (scalar loads with a run-time chunk index, two levels deep for the operand scale), requested here so that
+        // the round trips pass behind the barrier: scalar loads share their counter with LDS reads, at the head of the MFMA phase they
+        // would have to be drained before the first fragment wait
         {
             const int wrap = c + 2 >= nch ? 1 : 0;
             dn = describe(tile_of(it + wrap), c + 2 - (wrap ? nch : 0));
         }
+        P64_STAMP(3);
+        __syncthreads();
+        P64_STAMP(4);
+        // ---- MFMA phase -----------------------------------------------------------------------------------------------------------------
         // team 1 keeps the weight ring: during this phase it fetches the weights of step + 1 into the other slot (last read by this team one
         // step ago, by team 0 a phase before that); team 0 reads that slot in the NEXT phase, so the refill must have landed when team 1
         // reaches the barrier (everything else the wait covers was requested a whole phase earlier)

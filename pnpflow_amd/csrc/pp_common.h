@@ -42,6 +42,11 @@ __device__ __forceinline__ void split4_pp(const float4& v, unsigned& h01, unsign
         : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23) : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
 }
 
+// streaming (non-temporal) 16-byte accesses for tensors a launch touches once
+typedef float pp_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store4(void* dst, const float4& v) { pp_f4v t_ = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t_, reinterpret_cast<pp_f4v*>(dst)); }
+__device__ __forceinline__ float4 nt_load4(const void* src) { const pp_f4v t_ = __builtin_nontemporal_load(reinterpret_cast<const pp_f4v*>(src)); return make_float4(t_.x, t_.y, t_.z, t_.w); }
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_quad(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));

@@ -148,7 +148,12 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
     };
     Pre pre0, pre1;
     struct Res { float4 rv[MT][4]; float addv; };      // residual + bias (+ time-embedding projection) of one tile
-    Res res0, res1;
+    // residual of a tile: requested RD steps before the epilogue that adds it.  Two steps (as the patches) where a step is short (MT = 1); with
+    // one chunk per tile two residuals are then in flight (two sets, by tile parity).  With more chunks the tile before has been closed when
+    // the request is issued, with MT = 2 one step (~9 k cycles) is distance enough: ONE set
+    constexpr int RD = (NCH == 1 && MT == 2) ? 1 : 2;
+    constexpr int NRES = (NCH == 1 && MT == 1) ? 2 : 1;
+    Res res0, res1;      // (named objects, not an array: hipcc's counted vmcnt waits degrade to vmcnt(4) / vmcnt(0) when the sets are array elements)
 
     auto issue_patch = [&](Pre& S, const PPTile& tl, auto C_) __attribute__((always_inline)) {
         constexpr int C = decltype(C_)::value;
@@ -212,11 +217,12 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
 
     // two accumulators per M-tile (even / odd k16-steps, summed in the epilogue): with one, the 54 MFMAs of a chunk are a single dependent
     // chain and the wave stalls on every issue (r4 counters: SQ_WAIT_INST_ANY 19 % of the wave's cycles)
-    f32x16 acc[MT], acc2[MT];
+    constexpr int NACC = MT == 1 ? 2 : 1;      // (two M-tiles per wave are two independent chains already)
+    f32x16 acc[NACC][MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[mt][r] = 0.f; acc2[mt][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { for (int a = 0; a < NACC; ++a) acc[a][mt][r] = 0.f; }
     // running (sum, sum of squares) of this lane's four output channels over the tiles of image run_b: fp32 per lane (at most 32 tiles x 4
     // pixels between flushes - conv_mfma16 sums 256 pixels per channel in fp32 before its fp64 atomic), reduced across the wave's 8 lanes per
     // channel quad and added to the fp64 statistics when the image changes.  (Reducing and accumulating per TILE - shuffles + an LDS fp64
@@ -238,21 +244,13 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
             ah[mt] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][j][0] + off);
             al[mt] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][j][1] + off);
         }
-        if (s & 1) {
+        const int ai = (s & 1) % NACC;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc2[mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) acc[ai][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[ai][mt], 0, 0, 0);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc2[mt], 0, 0, 0);
+        for (int mt = 0; mt < MT; ++mt) acc[ai][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[ai][mt], 0, 0, 0);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc2[mt], 0, 0, 0);
-        } else {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt], 0, 0, 0);
-        }
+        for (int mt = 0; mt < MT; ++mt) acc[ai][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[ai][mt], 0, 0, 0);
     };
 
     auto flush_stats = [&]() __attribute__((always_inline)) {
@@ -283,7 +281,7 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
         for (int mt = 0; mt < MT; ++mt) {
             float e[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) e[r] = (acc[mt][r] + acc2[mt][r]) * oscale + R.addv;
+            for (int r = 0; r < 16; ++r) e[r] = (NACC == 2 ? acc[0][mt][r] + acc[NACC - 1][mt][r] : acc[0][mt][r]) * oscale + R.addv;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 oct_transpose(e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3], bit3);
@@ -319,7 +317,7 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { acc[mt][r] = 0.f; acc2[mt][r] = 0.f; }
+                for (int r = 0; r < 16; ++r) { for (int a = 0; a < NACC; ++a) acc[a][mt][r] = 0.f; }
         } else {
             if (p.scale != nullptr && p.ch[C - 1].seg != p.ch[C].seg) {
                 // the accumulator changes units: from the previous K-segment's operand scale to this one's (powers of two: exact)
@@ -328,7 +326,7 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) { acc[mt][r] *= ratio; acc2[mt][r] *= ratio; }
+                        for (int r = 0; r < 16; ++r) { for (int a = 0; a < NACC; ++a) acc[a][mt][r] *= ratio; }
                 }
             }
         }
@@ -360,7 +358,7 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
         // ---- VALU phase ---------------------------------------------------------------------------------------------------------------
         PP_STAMP(0);
         PP_STAMP(1);
-        if constexpr (C == 0) epilogue(PAR == 0 ? res1 : res0, tile_of(it - 1), live_of(it - 1) && it > 0);      // the previous tile (parity PAR ^ 1)
+        if constexpr (C == 0) epilogue((NRES == 2 && (PAR ^ 1) == 1) ? res1 : res0, tile_of(it - 1), live_of(it - 1) && it > 0);      // the previous tile (parity PAR ^ 1)
         PP_STAMP(2);
         transform(S, C_);
         PP_STAMP(3);
@@ -368,7 +366,8 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
         constexpr int C2 = (C + 2) % NCH, DT = (C + 2) / NCH;
         issue_patch(S, tile_of(it + DT), ic<C2>{});
         // ... and, when that step opens a tile, the residual of the tile that closes in front of it (tile it + DT - 1, parity PAR + DT - 1)
-        if constexpr (C2 == 0) issue_res(((PAR + DT - 1) & 1) == 0 ? res0 : res1, tile_of(it + DT - 1));
+        constexpr int CR = (C + RD) % NCH, DTR = (C + RD) / NCH;
+        if constexpr (CR == 0) issue_res((NRES == 2 && ((PAR + DTR - 1) & 1) == 1) ? res1 : res0, tile_of(it + DTR - 1));
         PP_STAMP(4);
         __syncthreads();
         // ---- MFMA phase (LDS + matrix pipe only) ----------------------------------------------------------------------------------------
@@ -392,7 +391,7 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
     // ---- the walk --------------------------------------------------------------------------------------------------------------------
     if (ntl <= 0) return;             // (never with the launcher's grid: T >= 8 G)
     issue_patch(pre0, tile_of(0), ic<0>{});                                        // step 0
-    if constexpr (NCH == 1) { issue_patch(pre1, tile_of(1), ic<0>{}); issue_res(res0, tile_of(0)); }   // step 1 = tile 1; tile 0 closes at step 1
+    if constexpr (NCH == 1) { issue_patch(pre1, tile_of(1), ic<0>{}); if constexpr (RD == 2) issue_res(res0, tile_of(0)); }   // step 1 = tile 1; tile 0 closes at step 1
     else issue_patch(pre1, tile_of(0), ic<1>{});
     __syncthreads();                  // weights visible
     if (TEAMS == 2 && team == 1) __syncthreads();
@@ -405,8 +404,8 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
         tile_steps(it + 1, ic<1>{});
     }
     if (it < niter) tile_steps(it, ic<0>{});
-    if (niter & 1) epilogue(res0, tile_of(niter - 1), live_of(niter - 1));
-    else epilogue(res1, tile_of(niter - 1), live_of(niter - 1));
+    if (NRES == 2 && ((niter - 1) & 1)) epilogue(res1, tile_of(niter - 1), live_of(niter - 1));
+    else epilogue(res0, tile_of(niter - 1), live_of(niter - 1));
     flush_stats();
 }
 
@@ -414,7 +413,9 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
 
 static int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
 
-constexpr int PP_MT = 1;      // 8 x 16-pixel team tiles: at 2 waves per SIMD two register sets of raw patch + two of residual + accumulators fit 256 registers
+constexpr int PP_MT = 1;      // 8 x 16-pixel team tiles: at 2 waves per SIMD two register sets of raw patch + the residual + accumulators fit 256 registers.
+                              // (16 x 16 tiles - MT = 2, 11 float4 per prefetch set - spill 57-156 registers with the two-step prefetch and measured
+                              // +30 ... +70 % per launch, r4; they would need conv_pp64's one-step re-request scheme)
 
 // chunk structures instantiated: ResidualBlock conv1 / conv2 of the down path (one 3x3 chunk, with / without the identity residual), conv1 of
 // the up path over cat[h, skip] (two / three 3x3 chunks), conv2 of the up path with the folded 1x1 shortcut (one 3x3 + two / three 1x1 chunks)

@@ -409,11 +409,13 @@ static int ilog2_exact64(int v) { int l = 0; while ((1 << l) < v) ++l; return (1
 bool conv_pp64_supported(const ConvParams& p, int stride, int up, int terms) {
     static const int mode = getenv("PNPFLOW_HIP_PP64") ? atoi(getenv("PNPFLOW_HIP_PP64")) : 1;
     if (mode == 0 || terms != 3 || stride != 1 || up != 0 || p.gnb_x != nullptr) return false;
-    if (p.Cout != 64 || p.out_cstride != 64 || (p.residual != nullptr && p.res_cstride != 64)) return false;
-    if (p.H % 8 || p.W % 16 || p.Hs != p.H || p.Ws != p.W) return false;
-    if (ilog2_exact64(p.H / 8) < 0 || ilog2_exact64(p.W / 16) < 0) return false;
-    // the persistent grid pays its prologue and pipeline fill over >= 8 tiles per team
-    if ((long)p.B * (p.H / 8) * (p.W / 16) < 8L * 512) return false;
+    // launches with an identity residual stay on conv_mfma16: the 64 x 64 wave tile + the residual tile do not fit 256 registers, and with
+    // 32 x 64 wave tiles (MT = 1: 6 LDS fragment reads per 6 MFMAs) this kernel is slower than conv_mfma16 (r4: 375 vs 358 us, 80 x 128^2)
+    if (p.Cout != 64 || p.out_cstride != 64 || p.residual != nullptr) return false;
+    if (p.H % 16 || p.W % 16 || p.Hs != p.H || p.Ws != p.W) return false;
+    if (ilog2_exact64(p.H / 16) < 0 || ilog2_exact64(p.W / 16) < 0) return false;
+    // the persistent grid pays its prologue and pipeline fill over >= 4 tiles of 16 x 16 pixels per team
+    if ((long)p.B * (p.H / 16) * (p.W / 16) < 4L * 512) return false;
     int nch = 0;
     for (int i = 0; i < p.nseg; ++i) {
         const ConvSeg& s = p.seg[i];
@@ -421,40 +423,23 @@ bool conv_pp64_supported(const ConvParams& p, int stride, int up, int terms) {
         nch += s.C / 16;
     }
     if (nch < 2 || nch > PP_MAXCH || (nch & 1)) return false;
-    // launches with an identity residual stay on conv_mfma16: the 64 x 64 wave tile + the residual tile do not fit 256 registers, and with
-    // 32 x 64 wave tiles (MT = 1: 6 LDS fragment reads per 6 MFMAs) this kernel is slower than conv_mfma16 (r4: 375 vs 358 us, 80 x 128^2)
-    static const int res_env = getenv("PNPFLOW_HIP_PP64_RES") ? atoi(getenv("PNPFLOW_HIP_PP64_RES")) : 0;
-    if (p.residual != nullptr && !res_env) return false;
     return p.gn_C > 0 && p.coef != nullptr;
 }
 
-// 16 x 16-pixel team tiles (two M-tiles x two N-tiles per wave: 8 LDS fragment reads per 12 MFMAs, the matrix pipe is the bound of the
-// MFMA phase) where a team gets at least four of them; 8 x 16 tiles (6 reads per 6 MFMAs: LDS-bound) otherwise
-static int pp64_mt(const PPParams& p) {
-    static const int mt_env = getenv("PNPFLOW_HIP_PP64_MT") ? atoi(getenv("PNPFLOW_HIP_PP64_MT")) : 0;
-    if (mt_env == 1 || mt_env == 2) return (mt_env == 2 && p.H % 16 == 0 && ilog2_exact64(p.H / 16) >= 0) ? 2 : 1;
-    return (p.H % 16 == 0 && ilog2_exact64(p.H / 16) >= 0 && (long)p.B * (p.H / 16) * (p.W / 16) >= 4L * 512) ? 2 : 1;
-}
-
-template <int MT, bool RES>
-static hipError_t launch_pp64_t(const PPParams& p0, hipStream_t s) {
+// (the kernel is written for MT = 1 / 2 and with / without residual; the library launches the one shape that wins: 16 x 16-pixel team tiles,
+// no residual)
+hipError_t launch_conv_pp64(const PPParams& p0, hipStream_t s) {
+    if (p0.n9 < 2 || (p0.n9 & 1) || p0.n1 != 0 || p0.cout != 64 || p0.residual != nullptr) return hipErrorInvalidValue;
     static unsigned long long attr_set = 0ull;
-    auto kern = conv_pp64_kernel<MT, RES>;
+    auto kern = conv_pp64_kernel<2, false>;
     { hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(kern), attr_set, 160 * 1024); if (e != hipSuccess) return e; }
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
     PPParams p = p0;
-    p.lx = ilog2_exact64(p.W / 16); p.ly = ilog2_exact64(p.H / (8 * MT));
+    p.lx = ilog2_exact64(p.W / 16); p.ly = ilog2_exact64(p.H / 16);
     p.rot = 5;
-    hipLaunchKernelGGL(kern, dim3((cus / 8) * 8), dim3(512), p64_lds(MT), s, p);
+    hipLaunchKernelGGL(kern, dim3((cus / 8) * 8), dim3(512), p64_lds(2), s, p);
     return hipGetLastError();
-}
-
-hipError_t launch_conv_pp64(const PPParams& p, hipStream_t s) {
-    if (p.n9 < 2 || (p.n9 & 1) || p.n1 != 0 || p.cout != 64) return hipErrorInvalidValue;
-    const bool res = p.residual != nullptr;
-    if (pp64_mt(p) == 2 && !res) return launch_pp64_t<2, false>(p, s);
-    return res ? launch_pp64_t<1, true>(p, s) : launch_pp64_t<1, false>(p, s);
 }
 
 }  // namespace pf

@@ -20,13 +20,12 @@ if sys.argv[1] == "cmp":
     sys.exit(0 if ok else 1)
 
 import torch
-from oracle import pnpflow_oracle as O
+from tools.synthetic_weights import synthetic_state_dict      # product-side recipe: these drivers produce judged measurements and do not touch oracle/
 from pnpflow_amd.models import UNet
 net, B, prec, out = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
 c = NETS[net]
-cfg = O.unet_config(3, c["dim"], c["ch"], c["ch_mult"], c["nrb"], c["attn"])
 m = UNet(3, c["dim"], c["ch"], ch_mult=c["ch_mult"], num_res_blocks=c["nrb"], attn_resolutions=c["attn"])
-m.load_state_dict(O.synthetic_state_dict(cfg, 0)); m.set_precision(prec)
+m.load_state_dict(synthetic_state_dict(m, 0)); m.set_precision(prec)
 g = torch.Generator().manual_seed(7)
 x = torch.randn(B, 3, c["dim"], c["dim"], generator=g).cuda(); t = torch.linspace(0.05, 0.95, B).cuda()
 v = m(x, t); torch.cuda.synchronize()

@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
     constexpr int NRES = (NCH == 1 && MT == 1) ? 2 : 1;
     Res res0, res1;      // (named objects, not an array: hipcc's counted vmcnt waits degrade to vmcnt(4) / vmcnt(0) when the sets are array elements)
 
+    // (the prologue's requests: the first two steps' patches)
     auto issue_patch = [&](Pre& S, const PPTile& tl, auto C_) __attribute__((always_inline)) {
         constexpr int C = decltype(C_)::value;
         const long bpix = ((long)tl.b * p.H + tl.oy0) * p.W + tl.ox0;
@@ -191,27 +192,52 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
         *reinterpret_cast<uint2*>(smem + (addr ^ 64u)) = l;                       // the lo piece q + 4 sits at slot (q ^ s) ^ 4
     };
 
-    auto transform = [&](const Pre& S, auto C_) __attribute__((always_inline)) {
-        constexpr int C = decltype(C_)::value;
-        if constexpr (C < N9) {
-            const bool silu = p.ch[C].xform == 2;
+    // staging of step (it, C) from set S interleaved with the requests of step + 2 into the same set: every register is re-requested the
+    // moment it has been staged, so the VALU work of the staging runs while the vector-memory queue accepts the requests (issued as one
+    // burst behind the staging they stalled for 1.5-2.7 k cycles, r4 stamps; interleaved: -0.6 ... -3 % per launch, bit-identical); the
+    // set's scalars and coefficients are replaced last
+    auto stage_and_request = [&](Pre& S, auto C_, const PPTile& t2, auto C2_) __attribute__((always_inline)) {
+        constexpr int C = decltype(C_)::value, C2 = decltype(C2_)::value;
+        constexpr int NT_ = C < N9 ? PP_A9 : TH / 2, NL_ = C2 < N9 ? PP_A9 : TH / 2;
+        const long bpix = ((long)t2.b * p.H + t2.oy0) * p.W + t2.ox0;
+        const int cstride = p.ch[C2].cstride;
+        const unsigned cs4 = (unsigned)cstride * 4u, q16 = (unsigned)qi * 16u;
+        const char* base = reinterpret_cast<const char*>(p.ch[C2].src + (bpix - (C2 < N9 ? p.W + 1 : 0)) * cstride + p.ch[C2].coff);
+        unsigned inval2 = 0;
+        if constexpr (C2 < N9) {
 #pragma unroll
-            for (int i = 0; i < PP_A9; ++i) {
-                float4 v = S.ra[i];
-                v.x = v.x * S.csc.x + S.csh.x; v.y = v.y * S.csc.y + S.csh.y; v.z = v.z * S.csc.z + S.csh.z; v.w = v.w * S.csc.w + S.csh.w;
-                if (silu) silu4_pp(v);
-                const float f = ((S.inval >> i) & 1u) ? 0.0f : S.ascale;
-                v.x *= f; v.y *= f; v.z *= f; v.w *= f;
-                // (the last float4 exists for the first LASTN threads only)
-                if (i < PP_A9 - 1 || t < LASTN) split_store(v, ldsw9 + (unsigned)(i * 4096) + (((pk9[i] >> 16) & 7u) << 4));
-            }
-        } else {
+            for (int i = 0; i < PP_A9; ++i) inval2 |= (((pk9[i] >> 20) & (unsigned)t2.edge) != 0u ? 1u : 0u) << i;
+        }
+        const bool silu = C < N9 ? p.ch[C].xform == 2 : false;
 #pragma unroll
-            for (int i = 0; i < TH / 2; ++i) {
+        for (int i = 0; i < (NT_ > NL_ ? NT_ : NL_); ++i) {
+            if (i < NT_) {
                 float4 v = S.ra[i];
-                v.x *= S.ascale; v.y *= S.ascale; v.z *= S.ascale; v.w *= S.ascale;
-                split_store(v, ldsw1 + (unsigned)(2 * i * PP_PW * 128));
+                if constexpr (C < N9) {
+                    v.x = v.x * S.csc.x + S.csh.x; v.y = v.y * S.csc.y + S.csh.y; v.z = v.z * S.csc.z + S.csh.z; v.w = v.w * S.csc.w + S.csh.w;
+                    if (silu) silu4_pp(v);
+                    const float f = ((S.inval >> i) & 1u) ? 0.0f : S.ascale;
+                    v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+                    if (i < PP_A9 - 1 || t < LASTN) split_store(v, ldsw9 + (unsigned)(i * 4096) + (((pk9[i] >> 16) & 7u) << 4));
+                } else {
+                    v.x *= S.ascale; v.y *= S.ascale; v.z *= S.ascale; v.w *= S.ascale;
+                    split_store(v, ldsw1 + (unsigned)(2 * i * PP_PW * 128));
+                }
             }
+            if (i < NL_) {
+                if constexpr (C2 < N9) {
+                    const unsigned px = ((inval2 >> i) & 1u) ? (unsigned)pix_safe : (pk9[i] & 0xffffu);
+                    S.ra[i] = *reinterpret_cast<const float4*>(base + (__umul24(px, cs4) + q16));
+                } else {
+                    S.ra[i] = *reinterpret_cast<const float4*>(base + (__umul24((unsigned)(pixoff1 + 2 * i * p.W), cs4) + q16));
+                }
+            }
+        }
+        S.inval = inval2;
+        S.ascale = p.scale != nullptr ? scale_c[8 * t2.b + p.ch[C2].seg] : 1.0f;
+        if constexpr (C2 < N9) {
+            const char* cb = reinterpret_cast<const char*>(p.coef + (size_t)t2.b * 2 * p.coef_stride + p.ch[C2].gn_c0);
+            S.csc = *reinterpret_cast<const float4*>(cb + q16); S.csh = *reinterpret_cast<const float4*>(cb + (unsigned)(p.coef_stride * 4) + q16);
         }
     };
 
@@ -360,11 +386,10 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
         PP_STAMP(1);
         if constexpr (C == 0) epilogue((NRES == 2 && (PAR ^ 1) == 1) ? res1 : res0, tile_of(it - 1), live_of(it - 1) && it > 0);      // the previous tile (parity PAR ^ 1)
         PP_STAMP(2);
-        transform(S, C_);
-        PP_STAMP(3);
-        // requests, two steps ahead: the patch of step (it, C) + 2 into the set just staged ...
+        // staging + requests, two steps ahead: the patch of step (it, C) + 2 into the set being staged ...
         constexpr int C2 = (C + 2) % NCH, DT = (C + 2) / NCH;
-        issue_patch(S, tile_of(it + DT), ic<C2>{});
+        stage_and_request(S, C_, tile_of(it + DT), ic<C2>{});
+        PP_STAMP(3);
         // ... and, when that step opens a tile, the residual of the tile that closes in front of it (tile it + DT - 1, parity PAR + DT - 1)
         constexpr int CR = (C + RD) % NCH, DTR = (C + RD) / NCH;
         if constexpr (CR == 0) issue_res((NRES == 2 && ((PAR + DTR - 1) & 1) == 1) ? res1 : res0, tile_of(it + DTR - 1));

@@ -1586,11 +1586,12 @@ def test_conv_pp_path_is_selected_on_the_32_channel_level_and_fp32_equivalent(hi
     fp32 rounding (same products, two interleaved fp32 accumulation chains instead of one: 2e-6 of max|v|), at 128^2 and at 256^2."""
     import csv, subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for net, B in (("celeba128", 160), ("afhq256", 40)):
+    # (B = 129: 16 512 tiles over 512 workgroups - ragged ranges, rotated starts that wrap inside an image boundary)
+    for net, B in (("celeba128", 160), ("afhq256", 40), ("celeba128", 129)):
         outs = {}
         for pp in ("0", "1"):
             env = dict(os.environ, PNPFLOW_HIP_PP=pp)
-            f = str(tmp_path / f"v_{net}_pp{pp}.npy")
+            f = str(tmp_path / f"v_{net}_{B}_pp{pp}.npy")
             r = subprocess.run([sys.executable, "tools/gpu_dma_check.py", "run", net, str(B), "1", f], cwd=repo, env=env, capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
             outs[pp] = np.load(f)
@@ -1625,11 +1626,12 @@ def test_conv_pp64_path_is_selected_on_the_64_channel_level_and_fp32_equivalent(
     order: 2e-6 of max|v|), at 128^2 and at 256^2."""
     import csv, subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for net, B in (("celeba128", 160), ("afhq256", 40)):
+    # (B = 129: 2 064 tiles over 256 workgroups - ragged ranges, odd tile counts per team, a team whose last tile is not live)
+    for net, B in (("celeba128", 160), ("afhq256", 40), ("celeba128", 129)):
         outs = {}
         for pp in ("0", "1"):
             env = dict(os.environ, PNPFLOW_HIP_PP64=pp)
-            f = str(tmp_path / f"v_{net}_pp64_{pp}.npy")
+            f = str(tmp_path / f"v_{net}_{B}_pp64_{pp}.npy")
             r = subprocess.run([sys.executable, "tools/gpu_dma_check.py", "run", net, str(B), "1", f], cwd=repo, env=env, capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
             outs[pp] = np.load(f)

@@ -485,8 +485,7 @@ static hipError_t launch_pp_tt(const PPParams& p0, hipStream_t s) {
     const int grid = (cus / 8) * 8 * (TEAMS == 1 ? 2 : 1);
     PPParams p = p0;
     p.lx = ilog2_exact(p.W / 16); p.ly = ilog2_exact(p.H / (8 * PP_MT));
-    static const int rot_env = getenv("PNPFLOW_HIP_PP_ROT") ? atoi(getenv("PNPFLOW_HIP_PP_ROT")) : 5;
-    p.rot = rot_env;
+    p.rot = 5;
     const size_t lds = (size_t)N9 * 36864 + (size_t)N1 * 4096 + TEAMS * pp_patch_bytes(PP_MT);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * TEAMS), lds, s, p);
     return hipGetLastError();
@@ -494,10 +493,9 @@ static hipError_t launch_pp_tt(const PPParams& p0, hipStream_t s) {
 
 template <int N9, int N1, bool RES>
 static hipError_t launch_pp_t(const PPParams& p, hipStream_t s) {
-    static const int teams_env = getenv("PNPFLOW_HIP_PP_TEAMS") ? atoi(getenv("PNPFLOW_HIP_PP_TEAMS")) : 0;
     constexpr size_t one = (size_t)N9 * 36864 + (size_t)N1 * 4096 + pp_patch_bytes(PP_MT);
-    if constexpr (2 * one <= 160 * 1024) { if (teams_env != 2) return launch_pp_tt<N9, N1, RES, 1>(p, s); }
-    return launch_pp_tt<N9, N1, RES, 2>(p, s);
+    if constexpr (2 * one <= 160 * 1024) return launch_pp_tt<N9, N1, RES, 1>(p, s);
+    else return launch_pp_tt<N9, N1, RES, 2>(p, s);
 }
 
 hipError_t launch_conv_pp(const PPParams& p, hipStream_t s) {

@@ -508,7 +508,7 @@ bool conv_dma_supported(const ConvParams& p, int stride, int up, int terms) {
     // prepped per output pixel).  Same-box layer table: 2304 (16^2 x 256, one or two 3x3 segments) and the upsampling convs (operand
     // at quarter resolution) win, 1152 (32^2 x 128) and the launches that drag 1-tap shortcut segments along lose; the pure 1x1
     // launches win when Cout >= 3 C (q,k,v stacked), not at Cout = C.
-    static const double min_ratio = getenv("PNPFLOW_HIP_DMA_RATIO") ? atof(getenv("PNPFLOW_HIP_DMA_RATIO")) : 2000.0;
+    constexpr double min_ratio = 2000.0;      // (frozen in round 5: it was an environment knob while the layer table was measured)
     double macs = 0.0, elts = 0.0; bool all1 = true;
     for (int i = 0; i < p.nseg; ++i) { macs += (double)p.seg[i].taps * p.seg[i].C * p.Cout; elts += p.seg[i].C; all1 &= p.seg[i].taps == 1; }
     if (up) elts *= 0.25;

@@ -458,7 +458,10 @@ bool conv_pp_supported(const ConvParams& p, int stride, int up, int terms) {
     if (ilog2_exact(p.H / TH) < 0 || ilog2_exact(p.W / 16) < 0) return false;
     // a persistent grid pays its prologue (weights -> LDS per workgroup, two-step pipeline fill) over >= 32 tiles per team: measured at 256^2,
     // B = 8 / 16 / 32 / 80 -> +11 % / +1.5 % / -1.4 % / -3 % on the whole forward; smaller launches stay on conv_mfma16
-    if ((long)p.B * (p.H / TH) * (p.W / 16) < 32L * 512) return false;
+    // (teams of the launch = 2 per CU; 32 x 512 tiles on the 256 CUs of an MI355X)
+    const int grid = persistent_grid();
+    if (grid < 8 || (long)p.B * (p.H / TH) * (p.W / 16) < 32L * 2 * grid) return false;
+    if (p.W > 2048) return false;      // patch pixel offsets py * W + px are packed into 16 bits (pk9[])
     int n9 = 0, n1 = 0;
     for (int i = 0; i < p.nseg; ++i) {
         const ConvSeg& s = p.seg[i];
@@ -480,9 +483,8 @@ static hipError_t launch_pp_tt(const PPParams& p0, hipStream_t s) {
     static unsigned long long attr_set = 0ull;
     auto kern = conv_pp_kernel<PP_MT, N9, N1, RES, TEAMS>;
     { hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(kern), attr_set, 160 * 1024); if (e != hipSuccess) return e; }
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
-    const int grid = (cus / 8) * 8 * (TEAMS == 1 ? 2 : 1);
+    const int grid = persistent_grid() * (TEAMS == 1 ? 2 : 1);
+    if (grid <= 0) return hipErrorInvalidConfiguration;
     PPParams p = p0;
     p.lx = ilog2_exact(p.W / 16); p.ly = ilog2_exact(p.H / (8 * PP_MT));
     p.rot = 5;

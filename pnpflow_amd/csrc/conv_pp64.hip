@@ -415,7 +415,9 @@ bool conv_pp64_supported(const ConvParams& p, int stride, int up, int terms) {
     if (p.H % 16 || p.W % 16 || p.Hs != p.H || p.Ws != p.W) return false;
     if (ilog2_exact64(p.H / 16) < 0 || ilog2_exact64(p.W / 16) < 0) return false;
     // the persistent grid pays its prologue and pipeline fill over >= 4 tiles of 16 x 16 pixels per team
-    if ((long)p.B * (p.H / 16) * (p.W / 16) < 4L * 512) return false;
+    const int grid = persistent_grid();
+    if (grid < 8 || (long)p.B * (p.H / 16) * (p.W / 16) < 4L * 2 * grid) return false;
+    if (p.W > 2048) return false;      // patch pixel offsets py * W + px are packed into 16 bits (pk[])
     int nch = 0;
     for (int i = 0; i < p.nseg; ++i) {
         const ConvSeg& s = p.seg[i];
@@ -433,12 +435,12 @@ hipError_t launch_conv_pp64(const PPParams& p0, hipStream_t s) {
     static unsigned long long attr_set = 0ull;
     auto kern = conv_pp64_kernel<2, false>;
     { hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(kern), attr_set, 160 * 1024); if (e != hipSuccess) return e; }
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+    const int grid = persistent_grid();
+    if (grid <= 0) return hipErrorInvalidConfiguration;
     PPParams p = p0;
     p.lx = ilog2_exact64(p.W / 16); p.ly = ilog2_exact64(p.H / 16);
     p.rot = 5;
-    hipLaunchKernelGGL(kern, dim3((cus / 8) * 8), dim3(512), p64_lds(2), s, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), p64_lds(2), s, p);
     return hipGetLastError();
 }
 

@@ -18,6 +18,21 @@ inline hipError_t set_max_dynamic_lds_once(const void* kernel, unsigned long lon
     return e;
 }
 
+// Compute units of the current device, queried once per device (the persistent kernels size their grids and their launch thresholds
+// by it; 0 when the query fails - the persistent kernels are then refused)
+inline int device_cu_count() {
+    static int cache[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 64 && cache[dev] > 0) return cache[dev];
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 0) v = 0;
+    if (dev >= 0 && dev < 64) cache[dev] = v;
+    return v;
+}
+// workgroups of a persistent launch: one per CU, a multiple of the 8 XCDs (the kernels map blockIdx & 7 to the XCD)
+inline int persistent_grid() { return (device_cu_count() / 8) * 8; }
+
 // One K-segment of the implicit GEMM: a source activation tensor (NHWC) plus the
 // slice of the weights that multiplies it.
 struct ConvSeg {
@@ -142,7 +157,7 @@ size_t conv_dma_a16_bytes(int B, int C, int Hs, int Ws, int terms);
 // conv_pp.hip: persistent two-team kernel of the full-resolution 32-channel level.  A launch is a list of 32-channel K-chunks (9-tap chunks
 // with GroupNorm(+SiLU) staging first, then raw 1-tap chunks of a folded 1x1 shortcut), each with its own LDS weight image
 // [k16-step = tap * 2 + j][hi | lo][k-half][Cout = 32][8 halfs] (values x 2^8, split like packed_conv16).
-constexpr int PP_MAXCH = 12;     // conv_pp: <= 4 chunks of 32 channels; conv_pp64: <= 12 chunks of 16 channels
+constexpr int PP_MAXCH = 24;     // conv_pp: <= 4 chunks of 32 channels; conv_pp64: <= 12 chunks of 16 channels; conv_pp128: <= 24 (cat[256, 128] -> 128)
 struct PPChunk {
     const float* src;     // NHWC source tensor of the chunk's K-segment
     const void* wimg;     // weight image of this chunk in global memory: taps * 4 KiB (conv_pp64: 36 KiB per 16-channel chunk, both N-tiles)
@@ -155,7 +170,7 @@ struct PPChunk {
 struct PPParams {
     PPChunk ch[PP_MAXCH]; // n9 nine-tap chunks, then n1 one-tap chunks (conv_pp is instantiated per (n9, n1, residual); conv_pp64 walks n9 at run time)
     int n9, n1;
-    int cout;                             // 32: conv_pp.hip, 64: conv_pp64.hip
+    int cout;                             // 32: conv_pp.hip, 64: conv_pp64.hip, 128: conv_pp128.hip
     int B, H, W, lx, ly;                  // tiles per row / column = 1 << lx / 1 << ly (8 x 16-pixel tiles)
     int rot;                              // workgroup g starts (g * rot) % (tiles of its range) tiles into its range (set by the launcher)
     float* out; const float* addvec; int addvec_bs; const float* residual; float res_scale; double* stats_out; float out_scale;
@@ -165,6 +180,8 @@ bool conv_pp_supported(const ConvParams& p, int stride, int up, int terms);
 hipError_t launch_conv_pp(const PPParams& p, hipStream_t s);
 bool conv_pp64_supported(const ConvParams& p, int stride, int up, int terms);
 hipError_t launch_conv_pp64(const PPParams& p, hipStream_t s);
+bool conv_pp128_supported(const ConvParams& p, int stride, int up, int terms);
+hipError_t launch_conv_pp128(const PPParams& p, hipStream_t s);
 
 hipError_t launch_conv(const ConvParams& p, int stride, int up, hipStream_t s);
 hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t s, int terms = 3);   // split-fp16 MFMA variant (terms 3) / single fp16 MFMA (terms 1)

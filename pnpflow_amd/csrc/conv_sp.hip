@@ -1,0 +1,517 @@
+// Persistent software-pipelined implicit-GEMM 3x3 convolution, ONE wave per SIMD (256-thread workgroups, one per CU, 512 registers per
+// lane), split-fp16 MFMA, fp32-equivalent.  Reference: the convolutions of ResidualBlock (pnpflow/models.py:58-113).
+//
+// Why another structure.  conv_pp64 / conv_pp128 put two teams of four waves on a CU and alternate a VALU phase (staging: GroupNorm +
+// SiLU + fp16 hi / lo split of the next patch) of one team with the MFMA phase of the other.  The two waves of a SIMD share its VALU
+// issue: every staging instruction of the partner costs the MFMA wave ~3 cycles (MI355X_MICROARCH.md "Two waves per SIMD"; round-5
+// stamps of conv_pp128: 4.5-5.6 k cycles per MFMA phase of 3.46 k matrix-pipe cycles, whoever issues the LDS-DMA refills), and every
+// phase boundary is a workgroup barrier.  A wave that is ALONE on its SIMD hides up to five single-issue instructions in the 32-cycle
+// shadow of each of its own MFMAs for nothing.  So here a wave does everything itself, in one instruction stream per 16-channel chunk:
+//   * MFMAs of chunk v from LDS fragments (A: the XOR-swizzled fp16 hi / lo patch of conv_pp64; B: the chunk's weight image, lane-linear);
+//   * the staging of chunk v + 1 (from raw fp32 registers requested a chunk earlier) into the OTHER patch buffer, and the requests of
+//     chunk v + 2 into the registers it frees;
+//   * the LDS-DMA refill of the weights, half a chunk ahead: taps 0..4 of a chunk live in slot X (40 KiB), taps 5..8 in slot Y (32 KiB);
+//     while X is read Y is refilled and vice versa - two workgroup barriers per chunk, each placed BEFORE the MFMAs of the last tap of a
+//     half (its fragments are in registers by then), so that the first fragments of the next half are requested under those MFMAs;
+//   * with 512 registers a wave owns MT x NT accumulator tiles of 32 x 32 = 128 accumulator registers (64 pixels x 128 channels at
+//     Cout = 128): 12 LDS fragment reads per 24 MFMAs.
+// Workgroup tile: 8 MT rows x 16 pixels x 32 NT channels (wave w: rows 2 MT w .. 2 MT w + 2 MT - 1).  LDS: X | Y | patch 0 | patch 1.
+// vmcnt is counted by hand around the LDS-DMA pieces (memory operations return in order): pieces are issued right behind a barrier,
+// BEFORE the three patch requests of that half-chunk, and waited for with vmcnt(3) in front of the next barrier.
+#include <cstdlib>
+#include "pp_common.h"
+
+namespace pf {
+
+constexpr int SP_PITCH = 20, SP_PW = 18;
+constexpr int sp_rows(int MT) { return 8 * MT; }                                   // tile rows
+constexpr int sp_npix(int MT) { return (sp_rows(MT) + 2) * SP_PW; }
+constexpr int sp_patch(int MT) { return (sp_rows(MT) + 2) * SP_PITCH * 64; }      // MT 2: 23 040 B
+constexpr int sp_a9(int MT) { return (sp_npix(MT) * 4 + 255) / 256; }             // float4 per lane and chunk (MT 2: 6)
+constexpr int sp_tap(int NT) { return 2 * NT * 1024; }                             // bytes of one tap: (hi | lo) x NT x 1 KiB
+constexpr int sp_x(int NT) { return 5 * sp_tap(NT); }                              // slot X: taps 0..4
+constexpr int sp_y(int NT) { return 4 * sp_tap(NT); }                              // slot Y: taps 5..8
+constexpr int sp_lds(int MT, int NT) { return sp_x(NT) + sp_y(NT) + 2 * sp_patch(MT); }
+
+__device__ __forceinline__ void glds16_sp(unsigned voff, const char* sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+#ifdef PP_PROBE_BUILD
+__device__ unsigned long long* g_sp_dbg = nullptr;
+#define SP_STAMP(k) do { if (stamp_buf != nullptr && blockIdx.x == 0 && tid == 0 && stamp_n < 64) stamp_buf[stamp_n * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SP_STAMP(k) do { } while (0)
+#endif
+
+template <int MT, int NT, bool RES>
+__global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
+    constexpr int TH = sp_rows(MT), NPIX = sp_npix(MT), A9 = sp_a9(MT), PATCH = sp_patch(MT);
+    constexpr int TAPB = sp_tap(NT), XB = sp_x(NT), COUT = 32 * NT, OB = COUT * 4;        // OB: bytes of an output pixel
+    constexpr int AH = (A9 + 1) / 2;                 // float4 staged in the first half of a chunk (the rest in the second)
+    static_assert(A9 - AH <= AH && AH <= 3, "hand-counted vmcnt");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wq = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    constexpr unsigned PATCH0 = (unsigned)(XB + sp_y(NT));
+    const pp_float_cptr scale_c = (pp_float_cptr)(uintptr_t)p.scale;
+    const int nch = p.n9;
+
+    // ---- per-lane constants of the staging (conv_pp64.hip) -------------------------------------------------------------------------------
+    const int qi = tid & 3, p0 = tid >> 2;
+    unsigned pk[A9], ldsw[A9];
+#pragma unroll
+    for (int i = 0; i < A9; ++i) {
+        const int pp = min(p0 + 64 * i, NPIX - 1);
+        const int py = pp / SP_PW, px = pp - py * SP_PW;
+        pk[i] = (unsigned)(py * p.W + px) | ((py == 0 ? 1u : 0u) << 20) | ((py == TH + 1 ? 1u : 0u) << 21) | ((px == 0 ? 1u : 0u) << 22) |
+                ((px == SP_PW - 1 ? 1u : 0u) << 23);
+        ldsw[i] = PATCH0 + (unsigned)((py * SP_PITCH + px) * 64) + (unsigned)((((qi >> 1) ^ ((px >> 2) & 3)) << 4) + (qi & 1) * 8);
+    }
+    const int pix_safe = p.W + 1;
+
+    // A-fragment addresses inside patch 0: lane = pixel (row prow of the M-tile's two rows, column pcol), k-half hi; [kx][term]
+    const int prow = l31 >> 4, pcol = l31 & 15;
+    unsigned a_addr[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const unsigned base = PATCH0 + (unsigned)(((wq * 2 * MT + prow) * SP_PITCH + pcol + kx) * 64);
+        const unsigned s = (unsigned)(((pcol + kx) >> 2) & 3);
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) a_addr[kx][tm] = base + ((((unsigned)(hi + 2 * tm)) ^ s) << 4);
+    }
+    const unsigned b_lane = (unsigned)lane * 16u;
+    const unsigned dma_lane = (unsigned)(wq * 1024 + lane * 16);
+
+    // epilogue geometry (conv_pp64.hip)
+    const bool bit3 = (lane & 8) != 0;
+    const int em = lane & 7;
+    const int ch_of_col = 4 * (l31 & 7) + (l31 >> 3);
+    const unsigned e_lane = (unsigned)((4 * hi + ((lane >> 3) & 3)) * OB + em * 16);
+
+    // ---- this workgroup's tiles: XCD-contiguous ranges, a rotated start ------------------------------------------------------------------
+    const int G = gridDim.x;
+    const int rg = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int T = p.B << (p.lx + p.ly);
+    const int t_begin = (int)((long)rg * T / G), t_end = (int)((long)(rg + 1) * T / G);
+    const int ntl = t_end - t_begin;
+    const int rot = ntl > 0 ? (int)(((long)rg * p.rot) % ntl) : 0;
+    auto tile_of = [&](int it) __attribute__((always_inline)) -> PPTile {
+        const int idx = min(it, ntl - 1);
+        const int wrapped = idx + rot >= ntl ? idx + rot - ntl : idx + rot;
+        const int tl = t_begin + wrapped;
+        PPTile r;
+        const int tx = tl & ((1 << p.lx) - 1), ty = (tl >> p.lx) & ((1 << p.ly) - 1);
+        r.b = tl >> (p.lx + p.ly); r.oy0 = ty * TH; r.ox0 = tx * 16;
+        r.edge = (ty == 0 ? 1 : 0) | (ty == (1 << p.ly) - 1 ? 2 : 0) | (tx == 0 ? 4 : 0) | (tx == (1 << p.lx) - 1 ? 8 : 0);
+        return r;
+    };
+
+    // ---- staging state --------------------------------------------------------------------------------------------------------------------
+    float4 ra[A9];
+    struct Coef { float4 csc, csh; float ascale; unsigned inval; };
+    Coef cf0, cf1;
+    struct Src { const char* base; unsigned cs4; };
+    const unsigned q16 = (unsigned)qi * 16u;
+    struct Desc { const char* base; const char* cb; unsigned cs4; int edge; float ascale; };
+    auto describe = [&](const PPTile& tl, int c) __attribute__((always_inline)) -> Desc {
+        // (32-bit index arithmetic: conv_sp_supported bounds B H W cstride below 2^31 - the 64-bit products of the first version were a
+        // serial chain of ~60 scalar instructions per chunk)
+        const int pix = (tl.b * p.H + tl.oy0) * p.W + tl.ox0 - p.W - 1;
+        const int cstride = p.ch[c].cstride;
+        Desc d;
+        d.ascale = p.scale != nullptr ? scale_c[8 * tl.b + p.ch[c].seg] : 1.0f;
+        d.edge = tl.edge;
+        d.cb = reinterpret_cast<const char*>(p.coef + (tl.b * 2 * p.coef_stride + p.ch[c].gn_c0));
+        d.base = reinterpret_cast<const char*>(p.ch[c].src + (pix * cstride + p.ch[c].coff));
+        d.cs4 = (unsigned)cstride * 4u;
+        return d;
+    };
+    auto prep = [&](Coef& N, const Desc& d) __attribute__((always_inline)) -> Src {
+        N.ascale = d.ascale;
+        unsigned inval = 0;
+#pragma unroll
+        for (int i = 0; i < A9; ++i) inval |= (((pk[i] >> 20) & (unsigned)d.edge) != 0u ? 1u : 0u) << i;
+        N.inval = inval;
+        N.csc = *reinterpret_cast<const float4*>(d.cb + q16); N.csh = *reinterpret_cast<const float4*>(d.cb + (unsigned)(p.coef_stride * 4) + q16);
+        Src r; r.base = d.base; r.cs4 = d.cs4;
+        return r;
+    };
+    auto issue_one = [&](const Coef& N, const Src& sr, int i) __attribute__((always_inline)) {
+        const unsigned px = ((N.inval >> i) & 1u) ? (unsigned)pix_safe : (pk[i] & 0xffffu);
+        ra[i] = *reinterpret_cast<const float4*>(sr.base + (__umul24(px, sr.cs4) + q16));
+    };
+    // GroupNorm + SiLU + operand scale + fp16 hi / lo split of float4 number i -> patch at byte offset pofs.  Plain C++ (no asm blocks): the
+    // ~60 instructions are spread by the scheduler over the MFMA shadows of a tap (sched_group_barrier pattern below); the values are
+    // those of conv_mfma16's staging (silu_pp; hi = RNE16(x), lo = RNE16(x - hi)).  Every thread stores: the threads past the end of the
+    // patch (A9 * 256 > 4 NPIX) hold the clamped last pixel and write ITS values to ITS address.  The launches this kernel takes are
+    // GroupNorm + SiLU on every chunk (conv_sp_supported).
+    auto transform_one = [&](const Coef& S, int i, unsigned pofs) __attribute__((always_inline)) {
+        float4 v = ra[i];
+        v.x = silu_pp(v.x * S.csc.x + S.csh.x); v.y = silu_pp(v.y * S.csc.y + S.csh.y);
+        v.z = silu_pp(v.z * S.csc.z + S.csh.z); v.w = silu_pp(v.w * S.csc.w + S.csh.w);
+        const float f = ((S.inval >> i) & 1u) ? 0.0f : S.ascale;
+        v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+        f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        f16x4 l = {(_Float16)(v.x - (float)h[0]), (_Float16)(v.y - (float)h[1]), (_Float16)(v.z - (float)h[2]), (_Float16)(v.w - (float)h[3])};
+        const unsigned addr = ldsw[i] + pofs;
+        *reinterpret_cast<f16x4*>(smem + addr) = h;
+        *reinterpret_cast<f16x4*>(smem + (addr ^ 32u)) = l;
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    float run1[4 * NT], run2[4 * NT];
+#pragma unroll
+    for (int j = 0; j < 4 * NT; ++j) { run1[j] = 0.f; run2[j] = 0.f; }
+    int run_b = -1, run_n = 0;
+
+    auto flush_stats = [&]() __attribute__((always_inline)) {
+        if (p.stats_out == nullptr || run_b < 0) return;
+#pragma unroll
+        for (int j = 0; j < 4 * NT; ++j) {
+            double a = (double)run1[j], q = (double)run2[j];
+            a += __shfl_xor(a, 8); q += __shfl_xor(q, 8);
+            a += __shfl_xor(a, 16); q += __shfl_xor(q, 16);
+            a += __shfl_xor(a, 32); q += __shfl_xor(q, 32);
+            if (lane < 8) {
+                double* dst = p.stats_out + ((size_t)run_b * COUT + (j >> 2) * 32 + em * 4 + (j & 3)) * 2;
+                unsafeAtomicAdd(dst, a); unsafeAtomicAdd(dst + 1, q);
+            }
+            run1[j] = 0.f; run2[j] = 0.f;
+        }
+        run_n = 0;
+    };
+
+    auto tile_offs = [&](int mt, int nt, int g) __attribute__((always_inline)) -> size_t {
+        return (size_t)((mt * 2 + (g >> 1)) * p.W) * OB + (size_t)((g & 1) * 8 * OB + nt * 128) + e_lane;
+    };
+    // closes a tile: bias (+ time-embedding projection), residual, transpose, streamed stores, statistics.  The residual of accumulator
+    // tile (mt, nt + 1) is requested before tile (mt, nt) is processed.
+    // (the bias and the output scale of a tile are fetched when the tile is OPENED - tile_inputs - and ride along: at the end of a tile a
+    // wave that is alone on its SIMD has nothing to cover a memory round trip with)
+    float addv[NT]; float oscale = 0.f;
+    auto tile_inputs = [&](const PPTile& tl) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) addv[nt] = p.addvec != nullptr ? p.addvec[(size_t)tl.b * p.addvec_bs + nt * 32 + ch_of_col] : 0.f;
+        const float inv_last = p.scale != nullptr ? scale_c[8 * tl.b + 4 + p.ch[nch - 1].seg] : 1.0f;
+        oscale = p.out_scale * (1.0f / 256.0f) * inv_last;
+    };
+    auto epilogue = [&](const PPTile& tl) __attribute__((always_inline)) {
+        if (tl.b != run_b || run_n >= 32) { flush_stats(); run_b = tl.b; }
+        ++run_n;
+        const size_t pix0 = ((size_t)tl.b * p.H + tl.oy0 + wq * 2 * MT) * p.W + tl.ox0;
+        char* obase = reinterpret_cast<char*>(p.out + pix0 * COUT);
+        const char* rbase = RES ? reinterpret_cast<const char*>(p.residual + pix0 * COUT) : nullptr;
+        float4 rv[2][4];
+        if constexpr (RES) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rv[0][g] = nt_load4(rbase + tile_offs(0, 0, g));
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int k = mt * NT + nt;
+                if constexpr (RES) {
+                    if (k + 1 < MT * NT) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) rv[(k + 1) & 1][g] = nt_load4(rbase + tile_offs((k + 1) / NT, (k + 1) % NT, g));
+                    }
+                }
+                float e[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e[r] = acc[mt][nt][r] * oscale + addv[nt];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    oct_transpose(e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3], bit3);
+                    float4 v = make_float4(e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3]);
+                    if constexpr (RES) {
+                        const float rsc = p.res_scale; const float4 r4 = rv[k & 1][g];
+                        v.x = fmaf(r4.x, rsc, v.x); v.y = fmaf(r4.y, rsc, v.y); v.z = fmaf(r4.z, rsc, v.z); v.w = fmaf(r4.w, rsc, v.w);
+                    }
+                    *reinterpret_cast<float4*>(obase + tile_offs(mt, nt, g)) = v;
+                    run1[nt * 4 + 0] += v.x; run1[nt * 4 + 1] += v.y; run1[nt * 4 + 2] += v.z; run1[nt * 4 + 3] += v.w;
+                    run2[nt * 4 + 0] += v.x * v.x; run2[nt * 4 + 1] += v.y * v.y; run2[nt * 4 + 2] += v.z * v.z; run2[nt * 4 + 3] += v.w * v.w;
+                }
+            }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    };
+
+    // ---- fragments: two named sets (the fragments of tap + 1 are requested under the MFMAs of tap) -----------------------------------------
+    f16x8 fa[2][MT][2], fb[2][NT][2];
+    // tap of the chunk whose patch sits at byte offset pofs (0 / PATCH): A from the patch, B from slot X (taps 0..4) / Y (taps 5..8); in the
+    // order the MFMA groups of mma_tap need them
+    auto load_tap = [&](int set, int tap, unsigned pofs) __attribute__((always_inline)) {
+        const int ky = tap / 3, kx = tap % 3;
+        const unsigned wb = (unsigned)(tap < 5 ? tap * TAPB : XB + (tap - 5) * TAPB) + b_lane;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) fa[set][mt][1] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][1] + (unsigned)((mt * 2 + ky) * SP_PITCH * 64) + pofs);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) fb[set][nt][0] = *reinterpret_cast<const f16x8*>(smem + wb + (unsigned)(nt * 1024));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) fa[set][mt][0] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][0] + (unsigned)((mt * 2 + ky) * SP_PITCH * 64) + pofs);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) fb[set][nt][1] = *reinterpret_cast<const f16x8*>(smem + wb + (unsigned)(NT * 1024 + nt * 1024));
+    };
+    // group g of a tap's 3 MT groups of NT MFMAs: term g / MT (a_lo w_hi, a_hi w_lo, a_hi w_hi), M-tile g % MT - an accumulator recurs every
+    // MT NT MFMAs
+    auto mma_group = [&](int set, int g) __attribute__((always_inline)) {
+        const int term = g / MT, mt = g % MT;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][mt][term == 0 ? 1 : 0], fb[set][nt][term == 1 ? 1 : 0], acc[mt][nt], 0, 0, 0);
+    };
+    auto mma_tap = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 3 * MT; ++g) mma_group(set, g);
+    };
+    // a tap whose side work is plain C++ (staging, requests, scalar work): the scheduler places it into the MFMA shadows by this pattern -
+    // per MFMA at most one LDS read, two plain VALU, one transcendental and two SALU (a wave alone on its SIMD hides ~5 issue slots per
+    // 32-cycle MFMA; the first version let 5-8 instructions into each of the first nine shadows and none into the rest: 920-1000 cycles
+    // per tap of 768 matrix-pipe cycles); the LDS writes and the request in the last quarter
+    auto tap_pattern = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 3 * MT * NT; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (k < 2 * (MT + NT)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (k < 2 * (MT + NT)) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
+            if (k >= 3 * MT * NT - 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            if (k == 3 * MT * NT - 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+    };
+    // a tap that carries LDS-DMA refill pieces (asm statements: pinned by hand, ONE piece per MFMA shadow): `nrounds` x 4 KiB from tap t0 of
+    // the chunk image `src` on.  Wave w fetches the w-th quarter of the range, contiguous: four pieces share one scalar base and one M0
+    // (the instruction offset 0 / 1024 / 2048 / 3072 moves the global AND the LDS address), so a piece is one instruction plus a scalar
+    // bump every fourth - the first version (M0 saved / set / restored and a 64-bit base add per piece) cost ~30 cycles per piece beyond
+    // the MFMA it sat behind
+    auto mma_tap_refill = [&](int set, const char* src, int t0, int nrounds) __attribute__((always_inline)) {
+        const unsigned dst0 = (unsigned)(t0 < 5 ? t0 * TAPB : XB + (t0 - 5) * TAPB) + (unsigned)(wq * nrounds * 1024);
+        const char* sb = src + t0 * TAPB + wq * nrounds * 1024;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
+#pragma unroll
+        for (int g = 0; g < 3 * MT; ++g) {
+            const int term = g / MT, mt = g % MT;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][mt][term == 0 ? 1 : 0], fb[set][nt][term == 1 ? 1 : 0], acc[mt][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const int j = g * NT + nt;
+                if (j < nrounds) {
+                    if ((j & 3) == 0) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(dst0 + (unsigned)(j * 1024)) : "memory");
+                    if ((j & 3) == 0) asm volatile("global_load_lds_dwordx4 %0, %1" :: "v"(b_lane), "s"(sb + j * 1024) : "memory");
+                    if ((j & 3) == 1) asm volatile("global_load_lds_dwordx4 %0, %1 offset:1024" :: "v"(b_lane), "s"(sb + (j - 1) * 1024) : "memory");
+                    if ((j & 3) == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" :: "v"(b_lane), "s"(sb + (j - 2) * 1024) : "memory");
+                    if ((j & 3) == 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(b_lane), "s"(sb + (j - 3) * 1024) : "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_mov_b32 m0, %0" :: "s"(keep));
+    };
+
+    int stamp_n = 0; (void)stamp_n;
+#ifdef PP_PROBE_BUILD
+    unsigned long long* const stamp_buf = g_sp_dbg;
+#endif
+    // first chunks of K-segments 1 and 2 (the accumulator changes units there): found once, so that the chunk head has no scalar loads
+    int seg_c1 = -1, seg_c2 = -1;
+    for (int c = 1; c < nch; ++c)
+        if (p.ch[c].seg != p.ch[c - 1].seg) { if (seg_c1 < 0) seg_c1 = c; else seg_c2 = c; }
+    const char* wimg_next = reinterpret_cast<const char*>(p.ch[1].wimg);      // weight image of the chunk behind the current one
+    Desc dn;            // descriptor of the chunk whose coefficients are fetched next (three ahead of the one being multiplied)
+    Src sr;             // source of the requests of the current chunk (the chunk two ahead), prepared during the previous chunk
+    // ---- one chunk: MFMAs of chunk (it, c) from patch SI; staging of the next chunk into patch SI ^ 1 (taps 0-3, 5, 6); requests of the
+    // chunk after that; refills of slot X under tap 4 and of slot Y under tap 8; descriptor / coefficients of the chunk three ahead under
+    // taps 6 / 7.  On entry: the fragments of tap 0 are in set SI, slots X and Y hold this chunk's weights (Y possibly still landing:
+    // waited for at the first barrier), ra[] holds (or is receiving) the raw patch of the next chunk, C = its coefficients, N / sr = the
+    // coefficients / source of the chunk two ahead.
+    auto chunk = [&](int it, int c, auto SI_, bool last_chunk) __attribute__((always_inline)) {
+        constexpr int SI = decltype(SI_)::value;
+        constexpr unsigned PCUR = SI ? PATCH : 0, PNXT = SI ? 0 : PATCH;
+        Coef& C = SI == 0 ? cf1 : cf0;      // coefficients of the chunk being staged (the next one)
+        Coef& N = SI == 0 ? cf0 : cf1;      // coefficients of the chunk being requested (two ahead); C of the next chunk
+        // (behind the last chunk of the launch the refills / fragment requests of a "next" chunk still run - into free slots, from valid
+        // addresses, never multiplied - so that the chunk body has no branches; the kernel drains vmcnt before it ends)
+        const char* wnext = wimg_next;
+        (void)last_chunk;
+        SP_STAMP(0);
+        static_assert(A9 == 6, "the staging of a chunk is six float4 per lane: taps 0-3, 5, 6 (hand-counted vmcnt below)");
+        // (nine taps per chunk: the fragment set of tap t is (t + SI) & 1)
+        // ---- taps 0..3: staging of float4 0..3 ----------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_tap((tap + 1 + SI) & 1, tap + 1, PCUR);
+            transform_one(C, tap, PNXT); issue_one(N, sr, tap);
+            mma_tap((tap + SI) & 1);
+            tap_pattern();
+            __builtin_amdgcn_sched_barrier(0);
+            SP_STAMP(1 + tap);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // tap 4: its fragments are in registers -> slot X is free; slot Y (taps 5..8, requested under tap 8 of the previous chunk) must have
+        // landed: behind its pieces only the four requests of taps 0..3 were issued
+        if (c == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(4 + NT + 4 * MT * NT) : "memory");      // (+ the stores of the tile closed in front and the bias loads of this one)
+        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        SP_STAMP(5);
+        load_tap((5 + SI) & 1, 5, PCUR);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tap_refill((4 + SI) & 1, wnext, 0, 5 * TAPB / 4096);
+        SP_STAMP(6);
+        // ---- taps 5, 6: staging of float4 4, 5; tap 6 also fetches the descriptor of the chunk three ahead; tap 7 its coefficients -----------
+#pragma unroll
+        for (int tap = 5; tap < 8; ++tap) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_tap((tap + 1 + SI) & 1, tap + 1, PCUR);
+            if (tap < 7) { transform_one(C, tap - 1, PNXT); issue_one(N, sr, tap - 1); }
+            if (tap == 6) {
+                const int wrap = c + 3 >= nch ? 1 : 0;
+                dn = describe(tile_of(it + wrap), c + 3 - (wrap ? nch : 0));
+                const int c2 = c + 2 >= nch ? c + 2 - nch : c + 2;
+                wimg_next = reinterpret_cast<const char*>(p.ch[c2].wimg);      // the next chunk's `wnext`
+            }
+            if (tap == 7) sr = prep(C, dn);      // (C: every float4 of the next chunk has been staged; it becomes N of the next chunk)
+            mma_tap((tap + SI) & 1);
+            tap_pattern();
+            __builtin_amdgcn_sched_barrier(0);
+            SP_STAMP(2 + tap);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // tap 8: its fragments are in registers -> slot Y and patch SI are free; slot X (next chunk's taps 0..4) must have landed - behind
+        // its pieces: the requests of taps 5, 6 and the two coefficient loads of tap 7 - and the next chunk's patch must be complete
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        SP_STAMP(10);
+        load_tap((9 + SI) & 1, 0, PNXT);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tap_refill((8 + SI) & 1, wnext, 5, 4 * TAPB / 4096);
+        SP_STAMP(11);
+        SP_STAMP(12);
+        ++stamp_n;
+    };
+
+    // ---- prologue ----------------------------------------------------------------------------------------------------------------------------
+    if (ntl <= 0) return;
+    {
+        // chunk 0: requested, staged into patch 0; chunk 1: requested; chunk 2: coefficients fetched, source prepared
+        const Src s0 = prep(cf0, describe(tile_of(0), 0));
+#pragma unroll
+        for (int i = 0; i < A9; ++i) issue_one(cf0, s0, i);
+        {
+            const char* w0 = reinterpret_cast<const char*>(p.ch[0].wimg);
+#pragma unroll
+            for (int j = 0; j < 9 * TAPB / 4096; ++j) glds16_sp(dma_lane, w0 + j * 4096, (unsigned)(j * 4096) + (unsigned)(wq * 1024));      // X | Y are contiguous
+        }
+#pragma unroll
+        for (int i = 0; i < A9; ++i) transform_one(cf0, i, 0);
+        const Src s1 = prep(cf1, describe(tile_of(0), 1));
+#pragma unroll
+        for (int i = 0; i < A9; ++i) issue_one(cf1, s1, i);
+        sr = prep(cf0, describe(tile_of(0), 2));
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        load_tap(0, 0, 0);
+    }
+    // (every K-segment has an even number of chunks: a chunk's parity - its patch buffer, coefficient set and fragment sets - is compile-time.
+    // The chunk loop runs per K-segment so that the change of the accumulator's units at a segment switch sits between two loops: a branch
+    // inside the chunk pair would end its basic block, and hipcc sinks the descriptor / coefficient arithmetic of taps 6 / 7 to its first
+    // use behind that branch - the head of the next chunk, where nothing covers it: ~1 k cycles per chunk)
+    const int seg_lo[4] = {0, seg_c1 > 0 ? seg_c1 : nch, seg_c2 > 0 ? seg_c2 : nch, nch};
+#pragma unroll 1
+    for (int it = 0; it < ntl; ++it) {
+        tile_inputs(tile_of(it));
+#pragma unroll 1
+        for (int sg = 0; sg < 3; ++sg) {
+            const int lo = seg_lo[sg], hi = seg_lo[sg + 1];
+            if (lo >= hi) continue;
+            if (sg > 0 && p.scale != nullptr) {
+                // the accumulator changes units: from the previous K-segment's operand scale to this one's (powers of two: exact)
+                const PPTile tl = tile_of(it);
+                const float ratio = scale_c[8 * tl.b + p.ch[lo].seg] * scale_c[8 * tl.b + 4 + p.ch[lo - 1].seg];
+                if (ratio != 1.0f) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= ratio;
+                }
+            }
+#pragma unroll 1
+            for (int c = lo; c < hi; c += 2) {
+                chunk(it, c, ic<0>{}, false);
+                chunk(it, c + 1, ic<1>{}, false);
+            }
+        }
+        // (behind the chunk loops, not under a condition inside the chunk body: hipcc hoisted the 128 accumulator reads of a conditional
+        // epilogue above the branch - ~1 k cycles in EVERY chunk)
+        epilogue(tile_of(it));
+    }
+    flush_stats();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the refills issued behind the last chunk
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------------
+
+static int ilog2_exact_sp(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
+
+bool conv_sp_supported(const ConvParams& p, int stride, int up, int terms) {
+    static const int mode = getenv("PNPFLOW_HIP_SP") ? atoi(getenv("PNPFLOW_HIP_SP")) : 1;      // test-only A/B switch
+    if (mode == 0 || terms != 3 || stride != 1 || up != 0 || p.gnb_x != nullptr) return false;
+    if (p.Cout != 128 || p.out_cstride != 128 || (p.residual != nullptr && p.res_cstride != 128)) return false;
+    constexpr int TH = sp_rows(2);
+    if (p.H % TH || p.W % 16 || p.Hs != p.H || p.Ws != p.W || p.W > 2048) return false;
+    if (ilog2_exact_sp(p.H / TH) < 0 || ilog2_exact_sp(p.W / 16) < 0) return false;
+    // the persistent grid pays its prologue and pipeline fill over >= 4 tiles per workgroup
+    const int grid = persistent_grid();
+    if (grid < 8 || (long)p.B * (p.H / TH) * (p.W / 16) < 4L * grid) return false;
+    int nch = 0;
+    for (int i = 0; i < p.nseg; ++i) {
+        const ConvSeg& s = p.seg[i];
+        if ((double)p.B * p.H * p.W * s.cstride >= 2147483648.0) return false;      // 32-bit element offsets (describe)
+        if (s.w_mode != 0 || s.w16 == nullptr || s.C % 32 || s.taps != 9 || s.xform != 2) return false;      // GroupNorm + SiLU 3x3 segments of an even number of 16-channel chunks
+        nch += s.C / 16;
+    }
+    if (nch < 4 || nch > PP_MAXCH || (nch & 1)) return false;
+    return p.gn_C > 0 && p.coef != nullptr;
+}
+
+hipError_t launch_conv_sp(const PPParams& p0, hipStream_t s) {
+    if (p0.n9 < 4 || (p0.n9 & 1) || p0.n1 != 0 || p0.cout != 128) return hipErrorInvalidValue;
+    static unsigned long long attr_set[2] = {0ull, 0ull};
+    const bool res = p0.residual != nullptr;
+    const void* kern = res ? reinterpret_cast<const void*>(conv_sp_kernel<2, 4, true>) : reinterpret_cast<const void*>(conv_sp_kernel<2, 4, false>);
+    { hipError_t e = set_max_dynamic_lds_once(kern, attr_set[res ? 1 : 0], 160 * 1024); if (e != hipSuccess) return e; }
+    const int grid = persistent_grid();
+    if (grid <= 0) return hipErrorInvalidConfiguration;
+    PPParams p = p0;
+    p.lx = ilog2_exact_sp(p.W / 16); p.ly = ilog2_exact_sp(p.H / sp_rows(2));
+    p.rot = 5;
+    if (res) hipLaunchKernelGGL((conv_sp_kernel<2, 4, true>), dim3(grid), dim3(256), sp_lds(2, 4), s, p);
+    else hipLaunchKernelGGL((conv_sp_kernel<2, 4, false>), dim3(grid), dim3(256), sp_lds(2, 4), s, p);
+    return hipGetLastError();
+}
+
+}  // namespace pf

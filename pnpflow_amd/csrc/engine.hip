@@ -593,11 +593,12 @@ static bool attach_dma(Builder& bd, ConvParams& p, int stride, int up, std::vect
 }
 
 // conv_pp.hip (persistent two-team kernel of the 32-channel level): the launch becomes a device-resident list of 32-channel K-chunks
-static bool attach_pp(Builder& bd, const ConvParams& p, int stride, int up, PPParams& q) {
+static int attach_pp(Builder& bd, const ConvParams& p, int stride, int up, PPParams& q) {      // 0: no; 1: conv_pp / conv_pp64 / conv_pp128; 2: conv_sp
     pf_engine* e = bd.e;
-    if (e->precision != 1) return false;
+    if (e->precision != 1) return 0;
+    const bool sp = p.Cout == 128 && conv_sp_supported(p, stride, up, 3);
     const bool wide = p.Cout == 64 || p.Cout == 128;      // conv_pp64.hip / conv_pp128.hip: 16-channel chunks, weights streamed through an LDS ring
-    if (!(p.Cout == 128 ? conv_pp128_supported(p, stride, up, 3) : wide ? conv_pp64_supported(p, stride, up, 3) : conv_pp_supported(p, stride, up, 3))) return false;
+    if (!sp && !(p.Cout == 128 ? conv_pp128_supported(p, stride, up, 3) : wide ? conv_pp64_supported(p, stride, up, 3) : conv_pp_supported(p, stride, up, 3))) return 0;
     q = PPParams{};
     q.cout = wide ? p.Cout : 32;
     const int kc = wide ? 16 : 32;
@@ -605,27 +606,27 @@ static bool attach_pp(Builder& bd, const ConvParams& p, int stride, int up, PPPa
     for (int i = 0; i < p.nseg; ++i) {
         const ConvSeg& sg = p.seg[i];
         auto it = e->w16_src.find(sg.w16);
-        if (it == e->w16_src.end()) return false;
+        if (it == e->w16_src.end()) return 0;
         for (int cc = 0; cc < sg.C / kc; ++cc) {
             PPChunk& k = q.ch[n++];
             k.src = sg.src; k.cstride = sg.cstride; k.coff = sg.coff + cc * kc; k.xform = sg.xform;
             k.gn_c0 = sg.gn_off + cc * kc; k.seg = i;
             k.wimg = p.Cout == 128 ? packed_conv_pp128(e, it->second.name, it->second.lo + cc * kc)
                      : wide ? packed_conv_pp64(e, it->second.name, it->second.lo + cc * kc) : packed_conv_pp(e, it->second.name, it->second.lo + cc * kc);
-            if (!k.wimg) return false;
+            if (!k.wimg) return 0;
             (sg.taps == 9 ? q.n9 : q.n1) += 1;
         }
     }
     q.B = p.B; q.H = p.H; q.W = p.W;
     q.out = p.out; q.addvec = p.addvec; q.addvec_bs = p.addvec_bs; q.residual = p.residual; q.res_scale = p.res_scale;
     q.stats_out = p.stats_out; q.out_scale = p.out_scale; q.coef = p.coef; q.coef_stride = p.coef_stride; q.scale = p.scale;
-    return true;
+    return sp ? 2 : 1;
 }
 
 static void push_conv(Builder& bd, const ConvParams& p0, int stride = 1, int up = 0) {
     ConvParams p = with_coef(bd, p0, bd.plan->ops);
     Op op{}; op.kind = OP_CONV;
-    op.use_pp = attach_pp(bd, p, stride, up, op.ppp) ? 1 : 0;
+    op.use_pp = attach_pp(bd, p, stride, up, op.ppp);
     op.dma = (!op.use_pp && attach_dma(bd, p, stride, up, bd.plan->ops)) ? 1 : 0;
     op.cp = p; op.stride = stride; op.up = up; op.flops = conv_flops(p);
     bd.plan->gemm_flops += op.flops;
@@ -1332,6 +1333,7 @@ static int run_backward(pf_engine* e, Plan* plan, const float* vec, float* g, hi
 }
 
 static hipError_t dispatch_conv(pf_engine* e, const Op& op, hipStream_t s) {
+    if (op.use_pp == 2 && e->precision == 1) return launch_conv_sp(op.ppp, s);
     if (op.use_pp && e->precision == 1) return op.ppp.cout == 128 ? launch_conv_pp128(op.ppp, s) : op.ppp.cout == 64 ? launch_conv_pp64(op.ppp, s) : launch_conv_pp(op.ppp, s);
     if (op.dma) return launch_conv_dma(op.cp, op.up, s, e->precision == 2 ? 1 : 3);
     if (e->precision != 0) {
@@ -2043,7 +2045,7 @@ int pf_engine_profile_read(pf_engine* e, int64_t* launches, double* ms_conv_gemm
             double bytes = (double)op.cp.B * op.cp.H * op.cp.W * op.cp.Cout * 4.0 * (op.cp.residual ? 2.0 : 1.0);
             for (int j = 0; j < op.cp.nseg; ++j) bytes += (double)op.cp.B * op.cp.Hs * op.cp.Ws * op.cp.seg[j].C * 4.0;
             fprintf(dump, "%zu,%d,%d,%d,%zu,%d,%d,%d,%d,%.4f,%.2f,%.2f,%d,%.3f", i, op.cp.H, op.cp.W, op.cp.Cout, K, op.cp.nseg, op.cp.seg[0].taps,
-                    op.stride, op.up, op.flops / 1e9, ms * 1e3, op.flops / (ms * 1e-3) / 1e12, op.use_pp ? (op.ppp.cout == 128 ? 4 : op.ppp.cout == 64 ? 3 : 2) : op.dma, bytes / 1e6);
+                    op.stride, op.up, op.flops / 1e9, ms * 1e3, op.flops / (ms * 1e-3) / 1e12, op.use_pp == 2 ? 5 : op.use_pp ? (op.ppp.cout == 128 ? 4 : op.ppp.cout == 64 ? 3 : 2) : op.dma, bytes / 1e6);
             fprintf(dump, "\n");
         }
     }

@@ -481,6 +481,34 @@ static const void* packed_conv_pp128(pf_engine* e, const std::string& wname, int
     return upload(e, key, raw);
 }
 
+// LDS weight image of ONE 16-channel 3x3 K-chunk for conv_sp32.hip (Cout = 32): [tap][hi | lo][k-half][column][8 halfs] = 9 x 2 KiB; input
+// channel of (k-half, i) = lo + k-half * 8 + i, output channel of column n = 4 (n & 7) + (n >> 3); same x 2^8 pre-scale and split as packed_conv16
+static const void* packed_conv_sp32(pf_engine* e, const std::string& wname, int lo) {
+    const std::string key = wname + "#sp32_" + std::to_string(lo);
+    auto it = e->dev.find(key);
+    if (it != e->dev.end()) return it->second;
+    const HostTensor& t = W(e, wname);
+    const int O = (int)t.shape[0], I = (int)t.shape[1], kk = (int)(t.shape[2] * t.shape[3]);
+    if (O != 32 || kk != 9) return nullptr;
+    std::vector<_Float16> out((size_t)9 * 2 * 512, (_Float16)0.f);
+    for (int tap = 0; tap < 9; ++tap)
+        for (int kh = 0; kh < 2; ++kh)
+            for (int n = 0; n < 32; ++n)
+                for (int i = 0; i < 8; ++i) {
+                    const int c = lo + kh * 8 + i;
+                    const int oc = 4 * (n & 7) + (n >> 3);
+                    const float w = t.data[((size_t)oc * I + c) * 9 + tap] * 256.0f;
+                    const _Float16 h = (_Float16)w;
+                    const _Float16 l = (_Float16)(w - (float)h);
+                    const size_t inner = ((size_t)kh * 32 + n) * 8 + i;
+                    out[((size_t)tap * 2 + 0) * 512 + inner] = h;
+                    out[((size_t)tap * 2 + 1) * 512 + inner] = l;
+                }
+    std::vector<float> raw(out.size() / 2);
+    memcpy(raw.data(), out.data(), out.size() * sizeof(_Float16));
+    return upload(e, key, raw);
+}
+
 static void fill_packed_seg(ConvSeg& s, const float* w, int taps, int Cout) {
     (void)taps; (void)Cout;
     s.w = w; s.w_mode = 0; s.w_bs = 0; s.w_cs = 0; s.w_ts = 0; s.w_ns = 0; s.w_ks = 0; s.w16 = nullptr;
@@ -597,11 +625,12 @@ static int attach_pp(Builder& bd, const ConvParams& p, int stride, int up, PPPar
     pf_engine* e = bd.e;
     if (e->precision != 1) return 0;
     const bool sp = p.Cout == 128 && conv_sp_supported(p, stride, up, 3);
+    const bool sp32 = p.Cout == 32 && conv_sp32_supported(p, stride, up, 3);
     const bool wide = p.Cout == 64 || p.Cout == 128;      // conv_pp64.hip / conv_pp128.hip: 16-channel chunks, weights streamed through an LDS ring
-    if (!sp && !(p.Cout == 128 ? conv_pp128_supported(p, stride, up, 3) : wide ? conv_pp64_supported(p, stride, up, 3) : conv_pp_supported(p, stride, up, 3))) return 0;
+    if (!sp && !sp32 && !(p.Cout == 128 ? conv_pp128_supported(p, stride, up, 3) : wide ? conv_pp64_supported(p, stride, up, 3) : conv_pp_supported(p, stride, up, 3))) return 0;
     q = PPParams{};
     q.cout = wide ? p.Cout : 32;
-    const int kc = wide ? 16 : 32;
+    const int kc = (wide || sp32) ? 16 : 32;
     int n = 0;
     for (int i = 0; i < p.nseg; ++i) {
         const ConvSeg& sg = p.seg[i];
@@ -611,7 +640,8 @@ static int attach_pp(Builder& bd, const ConvParams& p, int stride, int up, PPPar
             PPChunk& k = q.ch[n++];
             k.src = sg.src; k.cstride = sg.cstride; k.coff = sg.coff + cc * kc; k.xform = sg.xform;
             k.gn_c0 = sg.gn_off + cc * kc; k.seg = i;
-            k.wimg = p.Cout == 128 ? packed_conv_pp128(e, it->second.name, it->second.lo + cc * kc)
+            k.wimg = sp32 ? packed_conv_sp32(e, it->second.name, it->second.lo + cc * kc)
+                     : p.Cout == 128 ? packed_conv_pp128(e, it->second.name, it->second.lo + cc * kc)
                      : wide ? packed_conv_pp64(e, it->second.name, it->second.lo + cc * kc) : packed_conv_pp(e, it->second.name, it->second.lo + cc * kc);
             if (!k.wimg) return 0;
             (sg.taps == 9 ? q.n9 : q.n1) += 1;
@@ -620,7 +650,7 @@ static int attach_pp(Builder& bd, const ConvParams& p, int stride, int up, PPPar
     q.B = p.B; q.H = p.H; q.W = p.W;
     q.out = p.out; q.addvec = p.addvec; q.addvec_bs = p.addvec_bs; q.residual = p.residual; q.res_scale = p.res_scale;
     q.stats_out = p.stats_out; q.out_scale = p.out_scale; q.coef = p.coef; q.coef_stride = p.coef_stride; q.scale = p.scale;
-    return sp ? 2 : 1;
+    return sp ? 2 : sp32 ? 3 : 1;
 }
 
 static void push_conv(Builder& bd, const ConvParams& p0, int stride = 1, int up = 0) {
@@ -1334,6 +1364,7 @@ static int run_backward(pf_engine* e, Plan* plan, const float* vec, float* g, hi
 
 static hipError_t dispatch_conv(pf_engine* e, const Op& op, hipStream_t s) {
     if (op.use_pp == 2 && e->precision == 1) return launch_conv_sp(op.ppp, s);
+    if (op.use_pp == 3 && e->precision == 1) return launch_conv_sp32(op.ppp, s);
     if (op.use_pp && e->precision == 1) return op.ppp.cout == 128 ? launch_conv_pp128(op.ppp, s) : op.ppp.cout == 64 ? launch_conv_pp64(op.ppp, s) : launch_conv_pp(op.ppp, s);
     if (op.dma) return launch_conv_dma(op.cp, op.up, s, e->precision == 2 ? 1 : 3);
     if (e->precision != 0) {
@@ -2045,7 +2076,7 @@ int pf_engine_profile_read(pf_engine* e, int64_t* launches, double* ms_conv_gemm
             double bytes = (double)op.cp.B * op.cp.H * op.cp.W * op.cp.Cout * 4.0 * (op.cp.residual ? 2.0 : 1.0);
             for (int j = 0; j < op.cp.nseg; ++j) bytes += (double)op.cp.B * op.cp.Hs * op.cp.Ws * op.cp.seg[j].C * 4.0;
             fprintf(dump, "%zu,%d,%d,%d,%zu,%d,%d,%d,%d,%.4f,%.2f,%.2f,%d,%.3f", i, op.cp.H, op.cp.W, op.cp.Cout, K, op.cp.nseg, op.cp.seg[0].taps,
-                    op.stride, op.up, op.flops / 1e9, ms * 1e3, op.flops / (ms * 1e-3) / 1e12, op.use_pp == 2 ? 5 : op.use_pp ? (op.ppp.cout == 128 ? 4 : op.ppp.cout == 64 ? 3 : 2) : op.dma, bytes / 1e6);
+                    op.stride, op.up, op.flops / 1e9, ms * 1e3, op.flops / (ms * 1e-3) / 1e12, op.use_pp == 2 ? 5 : op.use_pp == 3 ? 6 : op.use_pp ? (op.ppp.cout == 128 ? 4 : op.ppp.cout == 64 ? 3 : 2) : op.dma, bytes / 1e6);
             fprintf(dump, "\n");
         }
     }

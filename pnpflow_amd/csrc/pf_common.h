@@ -180,6 +180,8 @@ bool conv_pp_supported(const ConvParams& p, int stride, int up, int terms);
 hipError_t launch_conv_pp(const PPParams& p, hipStream_t s);
 bool conv_pp64_supported(const ConvParams& p, int stride, int up, int terms);
 hipError_t launch_conv_pp64(const PPParams& p, hipStream_t s);
+bool conv_sp32_supported(const ConvParams& p, int stride, int up, int terms);    // conv_sp32.hip: the same at the 32-channel level (weights resident, epilogue overlapped)
+hipError_t launch_conv_sp32(const PPParams& p, hipStream_t s);
 bool conv_sp_supported(const ConvParams& p, int stride, int up, int terms);      // conv_sp.hip: one wave per SIMD, software-pipelined (Cout = 128)
 hipError_t launch_conv_sp(const PPParams& p, hipStream_t s);
 bool conv_pp128_supported(const ConvParams& p, int stride, int up, int terms);

@@ -1258,13 +1258,13 @@ def biglong_cases():
 
 
 # U-Net batches at which the launcher hands the 32- / 64- / 128-channel levels to the persistent kernels (conv_pp.hip >= 16 384 tiles of
-# 8 x 16 px, conv_pp64.hip >= 2 048 tiles of 16 x 16 px, conv_pp128.hip >= 2 048 tiles of 8 x 16 px): the batches bench.py times
+# 8 x 16 px, conv_pp64.hip >= 2 048 tiles of 16 x 16 px, conv_sp.hip >= 1 024 tiles of 16 x 16 px): the batches bench.py times
 PRODUCTION_B = {"c2": 32, "c3": 64, "c4": 16, "c2_256": 32}
 
 
 def _profile_paths(m, unet_batch, S, tmp_path, name):
     """which kernel every conv launch of the plan for `unet_batch` images takes: the 'dma' column of the engine's per-launch CSV
-    (0 conv_mfma16, 1 conv_dma, 2 conv_pp, 3 conv_pp64, 4 conv_pp128)"""
+    (0 conv_mfma16, 1 conv_dma, 2 conv_pp, 3 conv_pp64, 4 conv_pp128, 5 conv_sp, 6 conv_sp32)"""
     import csv
     x = det_normal((1, 3, S, S), 5).cuda().expand(unet_batch, -1, -1, -1).contiguous(); t = torch.full((unet_batch,), 0.3).cuda()
     m(x, t)
@@ -1275,7 +1275,7 @@ def _profile_paths(m, unet_batch, S, tmp_path, name):
     finally:
         os.environ.pop("PNPFLOW_HIP_PROFILE_CSV", None)
     rows = list(csv.DictReader(open(path)))
-    return {k: sum(1 for r in rows if int(r["dma"]) == k) for k in range(5)}
+    return {k: sum(1 for r in rows if int(r["dma"]) == k) for k in range(7)}
 
 
 @pytest.mark.parametrize("tag", ["c2", "c3", "c4", "c2_256"])
@@ -1312,9 +1312,9 @@ def test_full_length_recursion_on_the_baseline_nets(hip, golden, tmp_path, tag, 
         solver.noise = None
         if B > 1 and precision == 1:
             paths = _profile_paths(m, B * ns, S, tmp_path, f"layers_{tag}.csv")
-            assert paths[2] >= 26 and paths[3] >= 13, paths          # conv_pp on the 32-channel level, conv_pp64 on the 64-channel level
-            if os.environ.get("PNPFLOW_HIP_PP128", "1") == "1" and S == 256:
-                assert paths[4] >= 10, paths                         # conv_pp128 on the 128-channel level (>= 4 tiles per team at 64^2)
+            assert paths[2] + paths[6] >= 26 and paths[3] >= 13, paths          # conv_pp / conv_sp32 on the 32-channel level, conv_pp64 on the 64-channel level
+            if S == 256:
+                assert paths[4] + paths[5] >= 10, paths              # conv_sp / conv_pp128 on the 128-channel level (>= 4 tiles per workgroup at 64^2)
     finally:
         m.set_precision(1)
     clean = det_image((1, Cc, S, S), 31)

@@ -171,6 +171,45 @@ def measured_traffic(workload, kernel_class=None):
         return None, None
 
 
+def live_traffic(dim, unet_batch, kernel_class):
+    """HBM bytes per launch of `kernel_class`, measured IN THIS RUN when rocprofv3 is on the box: two child processes (separate
+    `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes with the kernel trace only, as MI355X_MICROARCH.md prescribes; FETCH doubled for
+    gfx950, KiB units) over two forwards of the same net at the same U-Net batch (tools/gpu_forward_only.py).  -> (bytes, source) or
+    (None, None) - the caller then falls back to the committed profiles/traffic.json, labelled as not measured in this run."""
+    import shutil, sqlite3, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.isfile("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, None
+    name = kernel_class.split(" ")[0].split("<")[0]
+    tile = kernel_class.split(" ")[0].split("<")[1].rstrip(">") if "<" in kernel_class.split(" ")[0] else None
+    tot = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="pf_pmc_", dir="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp")
+            env.pop("PNPFLOW_HIP_PROFILE_CSV", None)
+            subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "r", "--", sys.executable,
+                            os.path.join(ROOT, "tools", "gpu_forward_only.py"), str(dim), str(unet_batch), "2"],
+                           cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+            if not dbs:
+                return None, None
+            cur = sqlite3.connect(dbs[0]).cursor()
+            s_, n_ = 0.0, 0
+            for kn, val, cnt in cur.execute("select kernel_name, sum(value), count(*) from counters_collection where counter_name = ? group by kernel_name", (counter,)):
+                k0 = str(kn).replace(" ", "")
+                if name in k0 and (tile is None or ("<" + tile + ",") in k0):
+                    s_ += float(val); n_ += int(cnt)
+            shutil.rmtree(d, ignore_errors=True)
+            if n_ == 0:
+                return None, None
+            tot[counter] = s_ * 1024.0 / n_
+        return 2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"], ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes in this bench run (2 forwards of "
+                f"tools/gpu_forward_only.py {dim} {unet_batch}); 2 x FETCH_SIZE + WRITE_SIZE, KiB units; launch-weighted mean over the instantiations of the class")
+    except Exception:          # noqa: BLE001   (a profiler hiccup must not take the measured line with it)
+        return None, None
+
+
 class Runner:
     """One BASELINE workload on this rank: model, solver, resident synthetic batch, `step(i)` = one full restoration."""
 
@@ -256,7 +295,7 @@ def streaming_ceiling(tensor_bytes, passes):
         return STREAM_CEILING_GBS, False, {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
 
-def conv_roofline(r, precision, workload):
+def conv_roofline(r, precision, workload, measure_traffic=False):
     """Roofline of the conv family (every 3x3 / 1x1 conv of the U-Net), from HIP-event timing of every conv launch over a profiled
     slice of the SAME workload at the SAME U-Net batch (eager launches; graph replay hides the per-kernel boundaries; a conv_dma
     launch is timed together with its prep pass).  Two views:
@@ -281,18 +320,42 @@ def conv_roofline(r, precision, workload):
     os.environ.pop("PNPFLOW_HIP_PROFILE_CSV", None)
     rows = list(csv.DictReader(open(tmp.name))); os.unlink(tmp.name)
     ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0      # ALGORITHMIC (fp32-equivalent) TFLOP/s of the conv-GEMM launches
-    # kernel classes: the launcher picks the tile by Cout (<= 32: <2,1,4,1>; <= 64: <4,1,2,2>; else <4,1,1,4> or conv_dma)
+    # kernel classes: the engine's per-launch CSV says which kernel a launch took ("dma" column); conv_mfma16's tile follows Cout
+    PERSISTENT = {2: "conv_pp_kernel (Cout 32, persistent two-team)", 3: "conv_pp64_kernel (Cout 64, persistent two-team)",
+                  4: "conv_pp128_kernel (Cout 128, persistent two-team)", 5: "conv_sp_kernel (Cout 128, persistent, one wave per SIMD)",
+                  6: "conv_sp32_kernel (Cout 32, persistent, one wave per SIMD)"}
     cls = {}
     for w in rows:
-        key = "conv_pp_kernel (Cout 32, persistent)" if int(w["dma"]) == 2 else "conv_pp64_kernel (Cout 64, persistent)" if int(w["dma"]) == 3 else "conv_dma_kernel (+ prep_split)" if int(w["dma"]) else ("conv_mfma16_kernel<2,1,4,1> (Cout 32)" if int(w["Cout"]) <= 32 else
-               "conv_mfma16_kernel<4,1,2,2> (Cout 64)" if int(w["Cout"]) <= 64 else "conv_mfma16_kernel<4,1,1,4> (Cout >= 128)")
+        k = int(w["dma"])
+        key = PERSISTENT[k] if k in PERSISTENT else "conv_dma_kernel (+ prep_split)" if k == 1 else (
+            "conv_mfma16_kernel<2,1,4,1> (Cout 32)" if int(w["Cout"]) <= 32 else
+            "conv_mfma16_kernel<4,1,2,2> (Cout 64)" if int(w["Cout"]) <= 64 else "conv_mfma16_kernel<4,1,1,4> (Cout >= 128)")
         c = cls.setdefault(key, dict(us=0.0, mb=0.0, n=0, gflop=0.0))
         c["us"] += float(w["us"]); c["mb"] += float(w["alg_mb"]); c["n"] += 1; c["gflop"] += float(w["gflop"])
     tot_us = sum(c["us"] for c in cls.values()) or 1.0
-    dom = max(cls, key=lambda k: cls[k]["us"])
-    d = cls[dom]
-    traffic, src = measured_traffic(workload, dom) if (precision == 1 and rep == 5) else (None, None)
     dtype_peak = 157.3 if precision == 0 else 2500.0
+    terms = 3 if precision == 1 else 1
+    # every class against ITS OWN roof: the higher of its HBM floor (algorithmic bytes at 8 TB/s) and its MFMA floor (executed flops
+    # at the dense peak of the dtype) decides the bound; frac = achieved / peak of that bound
+    for c in cls.values():
+        c["hbm_floor_us"] = c["mb"] * 1e6 / 8e12 * 1e6 / c["n"]
+        c["mfma_floor_us"] = terms * c["gflop"] * 1e9 / (dtype_peak * 1e12) * 1e6 / c["n"]
+        c["bound"] = "hbm" if c["hbm_floor_us"] >= c["mfma_floor_us"] else "mfma"
+        c["gbs"] = c["mb"] * 1e6 / (c["us"] * 1e-6) / 1e9
+        c["tfl"] = c["gflop"] * 1e9 / (c["us"] * 1e-6) / 1e12
+        c["frac"] = c["gbs"] / 8000.0 if c["bound"] == "hbm" else c["tfl"] / dtype_peak
+    # the dominant class, deterministically: the largest share of the conv time; classes within one percentage point of it tie, and a
+    # tie goes to the HBM-bound class, then to the name (round 4: at 128^2 two classes tie and `bound` flipped from run to run)
+    top = max(c["us"] for c in cls.values())
+    tied = [k for k in cls if cls[k]["us"] >= top - 0.01 * tot_us]
+    dom = sorted(tied, key=lambda k: (cls[k]["bound"] != "hbm", k))[0]
+    d = cls[dom]
+    traffic, src, traffic_live = (None, None, False)
+    if precision == 1 and rep == 5:
+        traffic, src = live_traffic(r.wl["dim"], r.wl["B"] * rep, dom) if measure_traffic else (None, None)
+        traffic_live = traffic is not None
+        if traffic is None:
+            traffic, src = measured_traffic(workload, dom)
     fam = dict(bound="mfma", achieved=round(ach, 2), peak=dtype_peak, unit="TFLOP/s", frac=round(ach / dtype_peak, 4),
                launches=int(launches // n_fw), avg_launch_us=round(ms * 1e3 / max(1, launches), 2),
                algorithmic_gflop_per_launch=round(flops / max(1, launches) / 1e9, 4),
@@ -300,11 +363,8 @@ def conv_roofline(r, precision, workload):
                       "(register-staged) - f16 32x32x16 MFMA implicit GEMM, " + {0: "exact fp32 MFMA (conv_mfma_kernel)", 1: "3 MFMAs per product (fp32-equivalent split)", 2: "1 MFMA per product (hi-only operands)"}[precision])
     if precision == 1:
         fam.update(mfma_tflops_executed=round(3 * ach, 2), frac_executed=round(3 * ach / dtype_peak, 4))
-    gbs = d["mb"] * 1e6 / (d["us"] * 1e-6) / 1e9
-    tfl = d["gflop"] * 1e9 / (d["us"] * 1e-6) / 1e12
-    hbm_floor_us = d["mb"] * 1e6 / 8e12 * 1e6 / d["n"]
-    mfma_floor_us = (3 if precision == 1 else 1) * d["gflop"] * 1e9 / (dtype_peak * 1e12) * 1e6 / d["n"]
-    hbm_bound = hbm_floor_us >= mfma_floor_us
+    gbs, tfl, hbm_floor_us, mfma_floor_us = d["gbs"], d["tfl"], d["hbm_floor_us"], d["mfma_floor_us"]
+    hbm_bound = d["bound"] == "hbm"
     tensor_bytes = r.wl["B"] * rep * r.wl["dim"] ** 2 * 32 * 4          # one full-resolution 32-channel activation at the U-Net batch
     passes = d["mb"] * 1e6 / d["n"] / tensor_bytes if "Cout 32" in dom else 3.0
     torch.cuda.synchronize()
@@ -312,7 +372,7 @@ def conv_roofline(r, precision, workload):
     roof = dict(bound="hbm" if hbm_bound else "mfma",
                 achieved=round(gbs, 1) if hbm_bound else round(tfl, 2), peak=8000.0 if hbm_bound else dtype_peak,
                 unit="GB/s" if hbm_bound else "TFLOP/s", frac=round(gbs / 8000.0, 4) if hbm_bound else round(tfl / dtype_peak, 4),
-                traffic=traffic, traffic_source=src, traffic_measured_this_run=False if traffic is not None else None, kernel=dom, share_of_conv_time=round(d["us"] / tot_us, 4),
+                traffic=traffic, traffic_source=src, traffic_measured_this_run=traffic_live if traffic is not None else None, kernel=dom, share_of_conv_time=round(d["us"] / tot_us, 4),
                 launches=d["n"] // n_fw, avg_launch_us=round(d["us"] / d["n"], 2), algorithmic_mb_per_launch=round(d["mb"] / d["n"], 2),
                 hbm_floor_us_at_8tbs=round(hbm_floor_us, 1), mfma_floor_us=round(mfma_floor_us, 1), unet_batch=r.wl["B"] * rep,
                 # what a pure streaming kernel reaches on tensors of this size with the same read / write mix, measured in THIS run
@@ -320,8 +380,9 @@ def conv_roofline(r, precision, workload):
                 streaming_ceiling={"measured_this_run": ceil_measured, "probe": "tools/ubench/stream_mix quick", "tensor_bytes": tensor_bytes,
                                    "tensor_passes_per_launch": round(passes, 2), "detail": ceil_detail, "guide_float4_copy_gbs": GUIDE_COPY_GBS,
                                    "frac_of_guide_copy": round(gbs / GUIDE_COPY_GBS, 4) if hbm_bound else None},
-                classes={k: dict(share=round(v["us"] / tot_us, 4), avg_us=round(v["us"] / v["n"], 1), algorithmic_gbs=round(v["mb"] * 1e6 / (v["us"] * 1e-6) / 1e9, 1),
-                                 algorithmic_tflops=round(v["gflop"] * 1e9 / (v["us"] * 1e-6) / 1e12, 1)) for k, v in cls.items()},
+                classes={k: dict(share=round(v["us"] / tot_us, 4), avg_us=round(v["us"] / v["n"], 1), bound=v["bound"], frac=round(v["frac"], 4),
+                                 algorithmic_gbs=round(v["gbs"], 1), algorithmic_tflops=round(v["tfl"], 1),
+                                 executed_mfma_frac=round(terms * v["tfl"] / dtype_peak, 4)) for k, v in sorted(cls.items(), key=lambda kv: -kv[1]["us"])},
                 mfma_family=fam)
     return roof
 
@@ -580,7 +641,7 @@ def main():
                        "hipgraph": bool(getattr(r.solver, "use_graph", False)), "unet_batch": r.unet_batch(),
                        "parallelism": f"dp{world} (contiguous shards of the global batch, no data-path collective)"},
             "psnr_db": round(psnr_mean, 4),
-            "roofline": conv_roofline(r, a.precision, a.workload),
+            "roofline": conv_roofline(r, a.precision, a.workload, measure_traffic=(world == 1 and not a.no_extra)),
         }
         fpi = r.flops_per_image()
         if fpi:

@@ -1715,6 +1715,47 @@ def test_conv_pp64_path_is_selected_on_the_64_channel_level_and_fp32_equivalent(
     assert sorted(set(int(r["K"]) for r in pp_rows)) == [288, 576, 864, 1152, 1728]
 
 
+def _ab_forwards(tmp_path, cases, env_off, env_on, tag):
+    """whole forwards with a kernel family switched off / on through its test-only environment switch (tools/gpu_dma_check.py in child
+    processes): the outputs must agree to fp32 rounding (the same products in another summation order)"""
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for net, B in cases:
+        outs = {}
+        for name, extra in (("off", env_off), ("on", env_on)):
+            f = str(tmp_path / f"v_{net}_{B}_{tag}_{name}.npy")
+            r = subprocess.run([sys.executable, "tools/gpu_dma_check.py", "run", net, str(B), "1", f], cwd=repo, env=dict(os.environ, **extra),
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs[name] = np.load(f)
+        ref = np.abs(outs["off"]).max()
+        assert np.isfinite(outs["on"]).all() and np.abs(outs["off"] - outs["on"]).max() <= 2e-6 * ref, (tag, net, B, np.abs(outs["off"] - outs["on"]).max(), ref)
+
+
+def test_conv_sp_and_conv_pp128_take_the_128_channel_level_and_are_fp32_equivalent(hip, tmp_path):
+    """Round 5: the GroupNorm + SiLU 3x3 convs of the 128-channel level (ResidualBlock conv1, conv1 over cat[h, skip], conv2 with the
+    identity residual: models.py:58-113 at level width 128; 18 of the level's 26 launches) run on conv_sp.hip (one wave per SIMD, software-
+    pipelined, half-chunk LDS-DMA weight slots) and, with PNPFLOW_HIP_SP=0, on conv_pp128.hip (two teams, 16-slot per-tap weight ring,
+    LDS-counter hand-over); with both off they stay on conv_mfma16_kernel.  All three forwards agree to fp32 rounding, at the headline
+    U-Net batch shape and at a ragged one (81 images: 1 296 tiles over 256 workgroups)."""
+    off = dict(PNPFLOW_HIP_SP="0", PNPFLOW_HIP_PP128="0")
+    _ab_forwards(tmp_path, (("afhq256", 80), ("afhq256", 81)), off, dict(PNPFLOW_HIP_SP="1"), "sp")
+    _ab_forwards(tmp_path, (("afhq256", 80), ("afhq256", 81)), off, dict(PNPFLOW_HIP_SP="0", PNPFLOW_HIP_PP128="1"), "pp128")
+    if os.environ.get("PNPFLOW_HIP_SP") not in (None, "1"):
+        return
+    m, cfg, sd = model_for("afhq256")
+    paths = _profile_paths(m, 80, 256, tmp_path, "layers_sp.csv")
+    assert paths[5] == 18 and paths[4] == 0, paths          # 5 + 5 + 5 + 1 + 1 + 1 launches of K = 1152 (conv1), 1152 (conv2 + residual), 2304, 576, 1728, 3456
+
+
+def test_conv_sp32_is_fp32_equivalent(hip, tmp_path):
+    """conv_sp32.hip (the one-wave-per-SIMD structure at the 32-channel level: weights resident in LDS, tap-row steps, the epilogue of a
+    tile riding in the next tile's MFMA shadows) is parity-green but not selected by default (it does not beat conv_pp there: DESIGN
+    4.18); PNPFLOW_HIP_SP32=1 selects it for the GroupNorm + SiLU 3x3 launches of the level - conv1 / conv2 (+ residual) of the down
+    path, conv1 over cat[h, skip] - and the forward agrees with the default one to fp32 rounding (ragged ranges included)."""
+    _ab_forwards(tmp_path, (("afhq256", 40), ("celeba128", 129)), dict(PNPFLOW_HIP_SP32="0"), dict(PNPFLOW_HIP_SP32="1"), "sp32")
+
+
 # ---------------------------------------------------------------------------------------------
 # third-party pins (tools/pin_thirdparty.py; VERDICT r3 item 6): run when the fixtures exist, otherwise skipped as "parity unpinned"
 # ---------------------------------------------------------------------------------------------

@@ -32,6 +32,14 @@ constexpr int sp_tap(int NT) { return 2 * NT * 1024; }                          
 constexpr int sp_x(int NT) { return 5 * sp_tap(NT); }                              // slot X: taps 0..4
 constexpr int sp_y(int NT) { return 4 * sp_tap(NT); }                              // slot Y: taps 5..8
 constexpr int sp_lds(int MT, int NT) { return sp_x(NT) + sp_y(NT) + 2 * sp_patch(MT); }
+// the A9 float4 of the next chunk are staged under the seven taps that carry no refill (0-3, 5-7), front-loaded: with A9 = 6 one under
+// each of taps 0-3, 5, 6; with A9 = 10 two under taps 0-2 and one under taps 3, 5, 6, 7
+constexpr int sp_stage_n(int A9, int tap) {            // float4 staged under `tap`
+    const int slot = tap < 4 ? tap : tap < 8 ? tap - 1 : 7;      // taps 0-3 -> slots 0-3, taps 5-7 -> slots 4-6
+    if (tap == 4 || tap == 8) return 0;
+    return A9 / 7 + (slot < A9 % 7 ? 1 : 0);
+}
+constexpr int sp_stage_0(int A9, int tap) { int n = 0; for (int t = 0; t < tap; ++t) n += sp_stage_n(A9, t); return n; }      // first float4 staged under `tap`
 
 __device__ __forceinline__ void glds16_sp(unsigned voff, const char* sbase, unsigned lds_dst) {
     unsigned keep;
@@ -50,8 +58,9 @@ template <int MT, int NT, bool RES>
 __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
     constexpr int TH = sp_rows(MT), NPIX = sp_npix(MT), A9 = sp_a9(MT), PATCH = sp_patch(MT);
     constexpr int TAPB = sp_tap(NT), XB = sp_x(NT), COUT = 32 * NT, OB = COUT * 4;        // OB: bytes of an output pixel
-    constexpr int AH = (A9 + 1) / 2;                 // float4 staged in the first half of a chunk (the rest in the second)
-    static_assert(A9 - AH <= AH && AH <= 3, "hand-counted vmcnt");
+    // hand-counted vmcnt: the patch requests issued behind a refill and in front of the barrier that publishes it
+    constexpr int REQ1 = sp_stage_0(A9, 4), REQ2 = A9 - REQ1 + 2;      // taps 0-3; taps 5-7 + the two coefficient loads of tap 7
+    static_assert(sp_stage_0(A9, 9) == A9 && REQ1 + NT + 4 * MT * NT < 64, "staging distribution / vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wq = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -288,8 +297,8 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
         for (int k = 0; k < 3 * MT * NT; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             if (k < 2 * (MT + NT)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if (k < 2 * (MT + NT)) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-            else __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            if (k < 2 * (MT + NT)) __builtin_amdgcn_sched_group_barrier(0x002, A9 > 7 ? 2 : 1, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x002, A9 > 7 ? 5 : 3, 0);
             __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
             if (k >= 3 * MT * NT - 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
@@ -353,14 +362,14 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
         const char* wnext = wimg_next;
         (void)last_chunk;
         SP_STAMP(0);
-        static_assert(A9 == 6, "the staging of a chunk is six float4 per lane: taps 0-3, 5, 6 (hand-counted vmcnt below)");
         // (nine taps per chunk: the fragment set of tap t is (t + SI) & 1)
-        // ---- taps 0..3: staging of float4 0..3 ----------------------------------------------------------------------------------------------
+        // ---- taps 0..3 (+ their share of the staging) ----------------------------------------------------------------------------------------
 #pragma unroll
         for (int tap = 0; tap < 4; ++tap) {
             __builtin_amdgcn_sched_barrier(0);
             load_tap((tap + 1 + SI) & 1, tap + 1, PCUR);
-            transform_one(C, tap, PNXT); issue_one(N, sr, tap);
+#pragma unroll
+            for (int i = sp_stage_0(A9, tap); i < sp_stage_0(A9, tap) + sp_stage_n(A9, tap); ++i) { transform_one(C, i, PNXT); issue_one(N, sr, i); }
             mma_tap((tap + SI) & 1);
             tap_pattern();
             __builtin_amdgcn_sched_barrier(0);
@@ -368,9 +377,9 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
         }
         __builtin_amdgcn_sched_barrier(0);
         // tap 4: its fragments are in registers -> slot X is free; slot Y (taps 5..8, requested under tap 8 of the previous chunk) must have
-        // landed: behind its pieces only the four requests of taps 0..3 were issued
-        if (c == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(4 + NT + 4 * MT * NT) : "memory");      // (+ the stores of the tile closed in front and the bias loads of this one)
-        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        // landed: behind its pieces only the requests of taps 0..3 were issued
+        if (c == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(REQ1 + NT + 4 * MT * NT) : "memory");      // (+ the stores of the tile closed in front and the bias loads of this one)
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(REQ1) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         SP_STAMP(5);
@@ -383,10 +392,13 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
         for (int tap = 5; tap < 8; ++tap) {
             __builtin_amdgcn_sched_barrier(0);
             load_tap((tap + 1 + SI) & 1, tap + 1, PCUR);
-            if (tap < 7) { transform_one(C, tap - 1, PNXT); issue_one(N, sr, tap - 1); }
+#pragma unroll
+            for (int i = sp_stage_0(A9, tap); i < sp_stage_0(A9, tap) + sp_stage_n(A9, tap); ++i) { transform_one(C, i, PNXT); issue_one(N, sr, i); }
             if (tap == 6) {
-                const int wrap = c + 3 >= nch ? 1 : 0;
-                dn = describe(tile_of(it + wrap), c + 3 - (wrap ? nch : 0));
+                int q = c + 3, wrap = 0;                             // (two chunks per tile: three ahead may be two tiles ahead)
+                if (q >= nch) { q -= nch; wrap = 1; }
+                if (q >= nch) { q -= nch; wrap = 2; }
+                dn = describe(tile_of(it + wrap), q);
                 const int c2 = c + 2 >= nch ? c + 2 - nch : c + 2;
                 wimg_next = reinterpret_cast<const char*>(p.ch[c2].wimg);      // the next chunk's `wnext`
             }
@@ -398,8 +410,8 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
         }
         __builtin_amdgcn_sched_barrier(0);
         // tap 8: its fragments are in registers -> slot Y and patch SI are free; slot X (next chunk's taps 0..4) must have landed - behind
-        // its pieces: the requests of taps 5, 6 and the two coefficient loads of tap 7 - and the next chunk's patch must be complete
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        // its pieces: the requests of taps 5-7 and the two coefficient loads of tap 7 - and the next chunk's patch must be complete
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(REQ2) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         SP_STAMP(10);
@@ -425,10 +437,10 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
         }
 #pragma unroll
         for (int i = 0; i < A9; ++i) transform_one(cf0, i, 0);
-        const Src s1 = prep(cf1, describe(tile_of(0), 1));
+        const Src s1 = prep(cf1, describe(tile_of(0), 1));      // (nch >= 2)
 #pragma unroll
         for (int i = 0; i < A9; ++i) issue_one(cf1, s1, i);
-        sr = prep(cf0, describe(tile_of(0), 2));
+        sr = prep(cf0, describe(tile_of(2 >= nch ? 1 : 0), 2 >= nch ? 2 - nch : 2));
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -478,10 +490,11 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
 static int ilog2_exact_sp(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
 
 bool conv_sp_supported(const ConvParams& p, int stride, int up, int terms) {
-    static const int mode = getenv("PNPFLOW_HIP_SP") ? atoi(getenv("PNPFLOW_HIP_SP")) : 1;      // test-only A/B switch
+    static const int mode = getenv("PNPFLOW_HIP_SP") ? atoi(getenv("PNPFLOW_HIP_SP")) : 1;      // test-only A/B switch: 0 off, 1 on, 2 the 128-channel level only
     if (mode == 0 || terms != 3 || stride != 1 || up != 0 || p.gnb_x != nullptr) return false;
-    if (p.Cout != 128 || p.out_cstride != 128 || (p.residual != nullptr && p.res_cstride != 128)) return false;
-    constexpr int TH = sp_rows(2);
+    if (p.Cout != 128 && !(p.Cout == 64 && mode == 1)) return false;
+    if (p.out_cstride != p.Cout || (p.residual != nullptr && p.res_cstride != p.Cout)) return false;
+    const int TH = p.Cout == 128 ? sp_rows(2) : sp_rows(4);      // 16 x 16-pixel workgroup tiles at 128 channels, 32 x 16 at 64
     if (p.H % TH || p.W % 16 || p.Hs != p.H || p.Ws != p.W || p.W > 2048) return false;
     if (ilog2_exact_sp(p.H / TH) < 0 || ilog2_exact_sp(p.W / 16) < 0) return false;
     // the persistent grid pays its prologue and pipeline fill over >= 4 tiles per workgroup
@@ -494,24 +507,31 @@ bool conv_sp_supported(const ConvParams& p, int stride, int up, int terms) {
         if (s.w_mode != 0 || s.w16 == nullptr || s.C % 32 || s.taps != 9 || s.xform != 2) return false;      // GroupNorm + SiLU 3x3 segments of an even number of 16-channel chunks
         nch += s.C / 16;
     }
-    if (nch < 4 || nch > PP_MAXCH || (nch & 1)) return false;
+    if (nch < 2 || nch > PP_MAXCH || (nch & 1)) return false;
     return p.gn_C > 0 && p.coef != nullptr;
 }
 
-hipError_t launch_conv_sp(const PPParams& p0, hipStream_t s) {
-    if (p0.n9 < 4 || (p0.n9 & 1) || p0.n1 != 0 || p0.cout != 128) return hipErrorInvalidValue;
+template <int MT, int NT>
+static hipError_t launch_sp_t(const PPParams& p0, hipStream_t s) {
     static unsigned long long attr_set[2] = {0ull, 0ull};
     const bool res = p0.residual != nullptr;
-    const void* kern = res ? reinterpret_cast<const void*>(conv_sp_kernel<2, 4, true>) : reinterpret_cast<const void*>(conv_sp_kernel<2, 4, false>);
+    const void* kern = res ? reinterpret_cast<const void*>(conv_sp_kernel<MT, NT, true>) : reinterpret_cast<const void*>(conv_sp_kernel<MT, NT, false>);
     { hipError_t e = set_max_dynamic_lds_once(kern, attr_set[res ? 1 : 0], 160 * 1024); if (e != hipSuccess) return e; }
     const int grid = persistent_grid();
     if (grid <= 0) return hipErrorInvalidConfiguration;
     PPParams p = p0;
-    p.lx = ilog2_exact_sp(p.W / 16); p.ly = ilog2_exact_sp(p.H / sp_rows(2));
+    p.lx = ilog2_exact_sp(p.W / 16); p.ly = ilog2_exact_sp(p.H / sp_rows(MT));
     p.rot = 5;
-    if (res) hipLaunchKernelGGL((conv_sp_kernel<2, 4, true>), dim3(grid), dim3(256), sp_lds(2, 4), s, p);
-    else hipLaunchKernelGGL((conv_sp_kernel<2, 4, false>), dim3(grid), dim3(256), sp_lds(2, 4), s, p);
+    if (res) hipLaunchKernelGGL((conv_sp_kernel<MT, NT, true>), dim3(grid), dim3(256), sp_lds(MT, NT), s, p);
+    else hipLaunchKernelGGL((conv_sp_kernel<MT, NT, false>), dim3(grid), dim3(256), sp_lds(MT, NT), s, p);
     return hipGetLastError();
+}
+
+hipError_t launch_conv_sp(const PPParams& p0, hipStream_t s) {
+    if (p0.n9 < 2 || (p0.n9 & 1) || p0.n1 != 0) return hipErrorInvalidValue;
+    if (p0.cout == 128) return launch_sp_t<2, 4>(p0, s);
+    if (p0.cout == 64) return launch_sp_t<4, 2>(p0, s);
+    return hipErrorInvalidValue;
 }
 
 }  // namespace pf

@@ -624,7 +624,7 @@ static bool attach_dma(Builder& bd, ConvParams& p, int stride, int up, std::vect
 static int attach_pp(Builder& bd, const ConvParams& p, int stride, int up, PPParams& q) {      // 0: no; 1: conv_pp / conv_pp64 / conv_pp128; 2: conv_sp
     pf_engine* e = bd.e;
     if (e->precision != 1) return 0;
-    const bool sp = p.Cout == 128 && conv_sp_supported(p, stride, up, 3);
+    const bool sp = (p.Cout == 128 || p.Cout == 64) && conv_sp_supported(p, stride, up, 3);
     const bool sp32 = p.Cout == 32 && conv_sp32_supported(p, stride, up, 3);
     const bool wide = p.Cout == 64 || p.Cout == 128;      // conv_pp64.hip / conv_pp128.hip: 16-channel chunks, weights streamed through an LDS ring
     if (!sp && !sp32 && !(p.Cout == 128 ? conv_pp128_supported(p, stride, up, 3) : wide ? conv_pp64_supported(p, stride, up, 3) : conv_pp_supported(p, stride, up, 3))) return 0;

@@ -1262,7 +1262,7 @@ def biglong_cases():
 PRODUCTION_B = {"c2": 32, "c3": 64, "c4": 16, "c2_256": 32}
 
 
-def _profile_paths(m, unet_batch, S, tmp_path, name):
+def _profile_rows(m, unet_batch, S, tmp_path, name):
     """which kernel every conv launch of the plan for `unet_batch` images takes: the 'dma' column of the engine's per-launch CSV
     (0 conv_mfma16, 1 conv_dma, 2 conv_pp, 3 conv_pp64, 4 conv_pp128, 5 conv_sp, 6 conv_sp32)"""
     import csv
@@ -1274,7 +1274,11 @@ def _profile_paths(m, unet_batch, S, tmp_path, name):
         m.profile(True); m(x, t); m.profile_read(); m.profile(False)
     finally:
         os.environ.pop("PNPFLOW_HIP_PROFILE_CSV", None)
-    rows = list(csv.DictReader(open(path)))
+    return list(csv.DictReader(open(path)))
+
+
+def _profile_paths(m, unet_batch, S, tmp_path, name):
+    rows = _profile_rows(m, unet_batch, S, tmp_path, name)
     return {k: sum(1 for r in rows if int(r["dma"]) == k) for k in range(7)}
 
 
@@ -1312,9 +1316,10 @@ def test_full_length_recursion_on_the_baseline_nets(hip, golden, tmp_path, tag, 
         solver.noise = None
         if B > 1 and precision == 1:
             paths = _profile_paths(m, B * ns, S, tmp_path, f"layers_{tag}.csv")
-            assert paths[2] + paths[6] >= 26 and paths[3] >= 13, paths          # conv_pp / conv_sp32 on the 32-channel level, conv_pp64 on the 64-channel level
-            if S == 256:
-                assert paths[4] + paths[5] >= 10, paths              # conv_sp / conv_pp128 on the 128-channel level (>= 4 tiles per workgroup at 64^2)
+            assert paths[2] + paths[6] >= 26, paths          # conv_pp / conv_sp32 on the 32-channel level
+            # conv_sp (or conv_pp64) on >= 13 launches of the 64-channel level; at 256^2 conv_sp / conv_pp128 also on >= 10 launches of the
+            # 128-channel level (>= 4 tiles per workgroup at 64^2)
+            assert paths[3] + paths[4] + paths[5] >= 13 + (10 if S == 256 else 0), paths
     finally:
         m.set_precision(1)
     clean = det_image((1, Cc, S, S), 31)
@@ -1690,7 +1695,7 @@ def test_conv_pp64_path_is_selected_on_the_64_channel_level_and_fp32_equivalent(
     for net, B in (("celeba128", 160), ("afhq256", 40), ("celeba128", 129)):
         outs = {}
         for pp in ("0", "1"):
-            env = dict(os.environ, PNPFLOW_HIP_PP64=pp)
+            env = dict(os.environ, PNPFLOW_HIP_PP64=pp, PNPFLOW_HIP_SP="2")      # (conv_sp confined to the 128-channel level: round 5 gave it the 64-channel level by default)
             f = str(tmp_path / f"v_{net}_{B}_pp64_{pp}.npy")
             r = subprocess.run([sys.executable, "tools/gpu_dma_check.py", "run", net, str(B), "1", f], cwd=repo, env=env, capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
@@ -1699,15 +1704,11 @@ def test_conv_pp64_path_is_selected_on_the_64_channel_level_and_fp32_equivalent(
         assert np.isfinite(outs["1"]).all() and np.abs(outs["0"] - outs["1"]).max() <= 2e-6 * ref, (net, np.abs(outs["0"] - outs["1"]).max(), ref)
     if os.environ.get("PNPFLOW_HIP_PP64") not in (None, "1"):
         return
-    m, cfg, sd = model_for("celeba128")
-    x = det_normal((160, 3, 128, 128), 5).cuda(); t = torch.full((160,), 0.3).cuda()
-    m(x, t)
+    # selection with conv_sp confined to the 128-channel level (a child process: the switches are read once per process)
     path = str(tmp_path / "layers_pp64.csv")
-    os.environ["PNPFLOW_HIP_PROFILE_CSV"] = path
-    try:
-        m.profile(True); m(x, t); m.profile_read(); m.profile(False)
-    finally:
-        os.environ.pop("PNPFLOW_HIP_PROFILE_CSV", None)
+    r = subprocess.run([sys.executable, "tools/gpu_layer_profile.py", "128", "160", path], cwd=repo, env=dict(os.environ, PNPFLOW_HIP_SP="2"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
     rows = list(csv.DictReader(open(path)))
     pp_rows = [r for r in rows if int(r["dma"]) == 3]
     assert len(pp_rows) == 13, len(pp_rows)          # 1 + 5 + 1 + 5 + 1 launches of K = 288 / 576 / 864 / 1152 / 1728
@@ -1744,8 +1745,15 @@ def test_conv_sp_and_conv_pp128_take_the_128_channel_level_and_are_fp32_equivale
     if os.environ.get("PNPFLOW_HIP_SP") not in (None, "1"):
         return
     m, cfg, sd = model_for("afhq256")
-    paths = _profile_paths(m, 80, 256, tmp_path, "layers_sp.csv")
-    assert paths[5] == 18 and paths[4] == 0, paths          # 5 + 5 + 5 + 1 + 1 + 1 launches of K = 1152 (conv1), 1152 (conv2 + residual), 2304, 576, 1728, 3456
+    rows = _profile_rows(m, 80, 256, tmp_path, "layers_sp.csv")
+    sp = [r for r in rows if int(r["dma"]) == 5]
+    assert not [r for r in rows if int(r["dma"]) in (3, 4)], "conv_pp64 / conv_pp128 selected beside conv_sp"
+    # 128-channel level: 5 + 5 + 5 + 1 + 1 + 1 launches of K = 1152 (conv1), 1152 (conv2 + residual), 2304, 576, 1728, 3456
+    assert sorted(int(r["K"]) for r in sp if int(r["Cout"]) == 128) == sorted([1152] * 10 + [2304] * 5 + [576, 1728, 3456])
+    # 64-channel level (the round's last kernel commit): conv1, conv2 + identity residual (K = 576 x 10), conv1 over cat[h, skip]
+    # (K = 1152 x 5, 864, 1728), the first block's conv1 (K = 288); the launches with a folded 1x1 shortcut stay on conv_mfma16_kernel
+    assert sorted(int(r["K"]) for r in sp if int(r["Cout"]) == 64) == sorted([576] * 10 + [1152] * 5 + [288, 864, 1728])
+    assert all(int(r["stride"]) == 1 and int(r["up"]) == 0 and int(r["H"]) == (64 if int(r["Cout"]) == 128 else 128) for r in sp)
 
 
 def test_conv_sp32_is_fp32_equivalent(hip, tmp_path):

@@ -16,6 +16,11 @@
 //   * with 512 registers a wave owns MT x NT accumulator tiles of 32 x 32 = 128 accumulator registers (64 pixels x 128 channels at
 //     Cout = 128): 12 LDS fragment reads per 24 MFMAs.
 // Workgroup tile: 8 MT rows x 16 pixels x 32 NT channels (wave w: rows 2 MT w .. 2 MT w + 2 MT - 1).  LDS: X | Y | patch 0 | patch 1.
+// No scalar-memory loads inside the chunk loop: an s_load in flight turns every LDS wait hipcc inserts into lgkmcnt(0) (scalar loads return
+// out of order), i.e. a wave waits for the fragment reads it has just issued for the NEXT tap before it may start the current one
+// (round-5 stamps: +500 cycles under tap 6, +200 under taps 4 / 8 of 770).  The per-chunk descriptors (source, weight image, channel
+// stride / offset, GroupNorm offset, K-segment) therefore sit in a 32-byte-per-chunk LDS table written once per workgroup, and the
+// operand scale of a chunk is fetched with the chunk's GroupNorm coefficients as a vector load.
 // vmcnt is counted by hand around the LDS-DMA pieces (memory operations return in order): pieces are issued right behind a barrier,
 // BEFORE the three patch requests of that half-chunk, and waited for with vmcnt(3) in front of the next barrier.
 #include <cstdlib>
@@ -31,7 +36,8 @@ constexpr int sp_a9(int MT) { return (sp_npix(MT) * 4 + 255) / 256; }           
 constexpr int sp_tap(int NT) { return 2 * NT * 1024; }                             // bytes of one tap: (hi | lo) x NT x 1 KiB
 constexpr int sp_x(int NT) { return 5 * sp_tap(NT); }                              // slot X: taps 0..4
 constexpr int sp_y(int NT) { return 4 * sp_tap(NT); }                              // slot Y: taps 5..8
-constexpr int sp_lds(int MT, int NT) { return sp_x(NT) + sp_y(NT) + 2 * sp_patch(MT); }
+constexpr int SP_TAB = PP_MAXCH * 32;                                               // chunk table: 32 B per chunk (see the kernel's prologue)
+constexpr int sp_lds(int MT, int NT) { return sp_x(NT) + sp_y(NT) + 2 * sp_patch(MT) + SP_TAB; }
 // the A9 float4 of the next chunk are staged under the seven taps that carry no refill (0-3, 5-7), front-loaded: with A9 = 6 one under
 // each of taps 0-3, 5, 6; with A9 = 10 two under taps 0-2 and one under taps 3, 5, 6, 7
 constexpr int sp_stage_n(int A9, int tap) {            // float4 staged under `tap`
@@ -59,13 +65,13 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
     constexpr int TH = sp_rows(MT), NPIX = sp_npix(MT), A9 = sp_a9(MT), PATCH = sp_patch(MT);
     constexpr int TAPB = sp_tap(NT), XB = sp_x(NT), COUT = 32 * NT, OB = COUT * 4;        // OB: bytes of an output pixel
     // hand-counted vmcnt: the patch requests issued behind a refill and in front of the barrier that publishes it
-    constexpr int REQ1 = sp_stage_0(A9, 4), REQ2 = A9 - REQ1 + 2;      // taps 0-3; taps 5-7 + the two coefficient loads of tap 7
+    constexpr int REQ1 = sp_stage_0(A9, 4), REQ2 = A9 - REQ1 + 3;      // taps 0-3; taps 5-7 + the three coefficient loads of tap 7 (scale, shift, operand scale)
     static_assert(sp_stage_0(A9, 9) == A9 && REQ1 + NT + 4 * MT * NT < 64, "staging distribution / vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wq = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    constexpr unsigned PATCH0 = (unsigned)(XB + sp_y(NT));
+    constexpr unsigned PATCH0 = (unsigned)(XB + sp_y(NT)), TAB = PATCH0 + 2u * (unsigned)PATCH;
     const pp_float_cptr scale_c = (pp_float_cptr)(uintptr_t)p.scale;
     const int nch = p.n9;
 
@@ -121,26 +127,40 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
 
     // ---- staging state --------------------------------------------------------------------------------------------------------------------
     float4 ra[A9];
+    unsigned zero_v;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));
     struct Coef { float4 csc, csh; float ascale; unsigned inval; };
     Coef cf0, cf1;
-    struct Src { const char* base; unsigned cs4; };
+    typedef const __attribute__((address_space(1))) char* gptr;      // (pointers rebuilt from table words must carry the global address space: a generic pointer makes every request a flat_load, which counts in lgkmcnt as well)
+    struct Src { gptr base; unsigned cs4; };
     const unsigned q16 = (unsigned)qi * 16u;
-    struct Desc { const char* base; const char* cb; unsigned cs4; int edge; float ascale; };
-    auto describe = [&](const PPTile& tl, int c) __attribute__((always_inline)) -> Desc {
+    struct Desc { gptr base; const char* cb; unsigned cs4; int edge; unsigned sofs; };
+    struct Ent { uint4 a, b; };      // table entry of a chunk: a = (source pointer, weight image pointer), b = (cstride, coff, gn_c0, seg)
+    auto fetch = [&](int c) __attribute__((always_inline)) -> Ent {      // (a wave-uniform LDS read; the values reach scalar registers in describe)
+        Ent e;
+        e.a = *reinterpret_cast<const uint4*>(smem + TAB + (unsigned)c * 32u); e.b = *reinterpret_cast<const uint4*>(smem + TAB + (unsigned)c * 32u + 16u);
+        return e;
+    };
+    auto sptr = [&](unsigned lo, unsigned hi) __attribute__((always_inline)) -> gptr {
+        return (gptr)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)lo));
+    };
+    auto describe = [&](const PPTile& tl, const Ent& e) __attribute__((always_inline)) -> Desc {
         // (32-bit index arithmetic: conv_sp_supported bounds B H W cstride below 2^31 - the 64-bit products of the first version were a
         // serial chain of ~60 scalar instructions per chunk)
         const int pix = (tl.b * p.H + tl.oy0) * p.W + tl.ox0 - p.W - 1;
-        const int cstride = p.ch[c].cstride;
+        const int cstride = __builtin_amdgcn_readfirstlane((int)e.b.x), coff = __builtin_amdgcn_readfirstlane((int)e.b.y);
+        const int gn_c0 = __builtin_amdgcn_readfirstlane((int)e.b.z), seg = __builtin_amdgcn_readfirstlane((int)e.b.w);
         Desc d;
-        d.ascale = p.scale != nullptr ? scale_c[8 * tl.b + p.ch[c].seg] : 1.0f;
+        d.sofs = (unsigned)(8 * tl.b + seg) * 4u;
         d.edge = tl.edge;
-        d.cb = reinterpret_cast<const char*>(p.coef + (tl.b * 2 * p.coef_stride + p.ch[c].gn_c0));
-        d.base = reinterpret_cast<const char*>(p.ch[c].src + (pix * cstride + p.ch[c].coff));
+        d.cb = reinterpret_cast<const char*>(p.coef + (tl.b * 2 * p.coef_stride + gn_c0));
+        d.base = sptr(e.a.x, e.a.y) + (long)(pix * cstride + coff) * 4;
         d.cs4 = (unsigned)cstride * 4u;
         return d;
     };
     auto prep = [&](Coef& N, const Desc& d) __attribute__((always_inline)) -> Src {
-        N.ascale = d.ascale;
+        // (the operand scale as a VECTOR load - zero_v is a register hipcc cannot fold: a uniform address would become an s_load)
+        N.ascale = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.scale) + d.sofs + zero_v);
         unsigned inval = 0;
 #pragma unroll
         for (int i = 0; i < A9; ++i) inval |= (((pk[i] >> 20) & (unsigned)d.edge) != 0u ? 1u : 0u) << i;
@@ -151,7 +171,8 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
     };
     auto issue_one = [&](const Coef& N, const Src& sr, int i) __attribute__((always_inline)) {
         const unsigned px = ((N.inval >> i) & 1u) ? (unsigned)pix_safe : (pk[i] & 0xffffu);
-        ra[i] = *reinterpret_cast<const float4*>(sr.base + (__umul24(px, sr.cs4) + q16));
+        const pp_f4v t_ = *reinterpret_cast<const __attribute__((address_space(1))) pp_f4v*>(sr.base + (__umul24(px, sr.cs4) + q16));
+        ra[i] = make_float4(t_.x, t_.y, t_.z, t_.w);
     };
     // GroupNorm + SiLU + operand scale + fp16 hi / lo split of float4 number i -> patch at byte offset pofs.  Plain C++ (no asm blocks): the
     // ~60 instructions are spread by the scheduler over the MFMA shadows of a tap (sched_group_barrier pattern below); the values are
@@ -207,12 +228,18 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
     // tile (mt, nt + 1) is requested before tile (mt, nt) is processed.
     // (the bias and the output scale of a tile are fetched when the tile is OPENED - tile_inputs - and ride along: at the end of a tile a
     // wave that is alone on its SIMD has nothing to cover a memory round trip with)
+    // K-segment ids of the (up to three) segments' first chunks and of the last chunk: found once (kernel-argument reads)
+    int seg_c1 = -1, seg_c2 = -1;
+    for (int c = 1; c < nch; ++c)
+        if (p.ch[c].seg != p.ch[c - 1].seg) { if (seg_c1 < 0) seg_c1 = c; else seg_c2 = c; }
+    const int seg_id[4] = {p.ch[0].seg, p.ch[seg_c1 > 0 ? seg_c1 : 0].seg, p.ch[seg_c2 > 0 ? seg_c2 : 0].seg, p.ch[nch - 1].seg};
     float addv[NT]; float oscale = 0.f;
     auto tile_inputs = [&](const PPTile& tl) __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) addv[nt] = p.addvec != nullptr ? p.addvec[(size_t)tl.b * p.addvec_bs + nt * 32 + ch_of_col] : 0.f;
-        const float inv_last = p.scale != nullptr ? scale_c[8 * tl.b + 4 + p.ch[nch - 1].seg] : 1.0f;
+        const float inv_last = scale_c[8 * tl.b + 4 + seg_id[3]];
         oscale = p.out_scale * (1.0f / 256.0f) * inv_last;
+        asm volatile("" : "+v"(oscale));      // (consumed HERE: no scalar load may stay in flight into the chunk loop)
     };
     auto epilogue = [&](const PPTile& tl) __attribute__((always_inline)) {
         if (tl.b != run_b || run_n >= 32) { flush_stats(); run_b = tl.b; }
@@ -310,9 +337,9 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
     // (the instruction offset 0 / 1024 / 2048 / 3072 moves the global AND the LDS address), so a piece is one instruction plus a scalar
     // bump every fourth - the first version (M0 saved / set / restored and a 64-bit base add per piece) cost ~30 cycles per piece beyond
     // the MFMA it sat behind
-    auto mma_tap_refill = [&](int set, const char* src, int t0, int nrounds) __attribute__((always_inline)) {
+    auto mma_tap_refill = [&](int set, const __attribute__((address_space(1))) char* src, int t0, int nrounds) __attribute__((always_inline)) {
         const unsigned dst0 = (unsigned)(t0 < 5 ? t0 * TAPB : XB + (t0 - 5) * TAPB) + (unsigned)(wq * nrounds * 1024);
-        const char* sb = src + t0 * TAPB + wq * nrounds * 1024;
+        const __attribute__((address_space(1))) char* sb = src + t0 * TAPB + wq * nrounds * 1024;
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
 #pragma unroll
@@ -340,11 +367,8 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
 #ifdef PP_PROBE_BUILD
     unsigned long long* const stamp_buf = g_sp_dbg;
 #endif
-    // first chunks of K-segments 1 and 2 (the accumulator changes units there): found once, so that the chunk head has no scalar loads
-    int seg_c1 = -1, seg_c2 = -1;
-    for (int c = 1; c < nch; ++c)
-        if (p.ch[c].seg != p.ch[c - 1].seg) { if (seg_c1 < 0) seg_c1 = c; else seg_c2 = c; }
-    const char* wimg_next = reinterpret_cast<const char*>(p.ch[1].wimg);      // weight image of the chunk behind the current one
+    // (seg_c1 / seg_c2: first chunks of K-segments 1 and 2 - the accumulator changes units there)
+    gptr wimg_next = (gptr)(uintptr_t)p.ch[1].wimg;      // weight image of the chunk behind the current one
     Desc dn;            // descriptor of the chunk whose coefficients are fetched next (three ahead of the one being multiplied)
     Src sr;             // source of the requests of the current chunk (the chunk two ahead), prepared during the previous chunk
     // ---- one chunk: MFMAs of chunk (it, c) from patch SI; staging of the next chunk into patch SI ^ 1 (taps 0-3, 5, 6); requests of the
@@ -359,7 +383,7 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
         Coef& N = SI == 0 ? cf0 : cf1;      // coefficients of the chunk being requested (two ahead); C of the next chunk
         // (behind the last chunk of the launch the refills / fragment requests of a "next" chunk still run - into free slots, from valid
         // addresses, never multiplied - so that the chunk body has no branches; the kernel drains vmcnt before it ends)
-        const char* wnext = wimg_next;
+        const gptr wnext = wimg_next;
         (void)last_chunk;
         SP_STAMP(0);
         // (nine taps per chunk: the fragment set of tap t is (t + SI) & 1)
@@ -380,6 +404,13 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
         // landed: behind its pieces only the requests of taps 0..3 were issued
         if (c == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(REQ1 + NT + 4 * MT * NT) : "memory");      // (+ the stores of the tile closed in front and the bias loads of this one)
         else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(REQ1) : "memory");
+        // hipcc does not see the LDS-DMA pieces: its own counted wait in front of the first use of a raw patch register would be short by the
+        // pieces issued in between, i.e. it would wait for pieces that have just been issued (stamps: ~400 cycles at the loop's back edge).
+        // The raw registers staged before the next hand wait are complete HERE (they are older than the REQ1 youngest requests): touching
+        // them here makes hipcc place its wait where it costs nothing
+#pragma unroll
+        for (int i = REQ1; i < A9; ++i) asm volatile("" :: "v"(ra[i].x));
+        SP_STAMP(13);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         SP_STAMP(5);
@@ -391,16 +422,18 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
 #pragma unroll
         for (int tap = 5; tap < 8; ++tap) {
             __builtin_amdgcn_sched_barrier(0);
+            int q = c + 3, wrap = 0;                             // (two chunks per tile: three ahead may be two tiles ahead)
+            if (q >= nch) { q -= nch; wrap = 1; }
+            if (q >= nch) { q -= nch; wrap = 2; }
+            const int c2 = c + 2 >= nch ? c + 2 - nch : c + 2;
+            Ent eq, e2;
+            if (tap == 6) { eq = fetch(q); e2 = fetch(c2); }      // in FRONT of the fragment reads: their values are waited for with a counted lgkmcnt
             load_tap((tap + 1 + SI) & 1, tap + 1, PCUR);
 #pragma unroll
             for (int i = sp_stage_0(A9, tap); i < sp_stage_0(A9, tap) + sp_stage_n(A9, tap); ++i) { transform_one(C, i, PNXT); issue_one(N, sr, i); }
             if (tap == 6) {
-                int q = c + 3, wrap = 0;                             // (two chunks per tile: three ahead may be two tiles ahead)
-                if (q >= nch) { q -= nch; wrap = 1; }
-                if (q >= nch) { q -= nch; wrap = 2; }
-                dn = describe(tile_of(it + wrap), q);
-                const int c2 = c + 2 >= nch ? c + 2 - nch : c + 2;
-                wimg_next = reinterpret_cast<const char*>(p.ch[c2].wimg);      // the next chunk's `wnext`
+                dn = describe(tile_of(it + wrap), eq);
+                wimg_next = sptr(e2.a.z, e2.a.w);      // the next chunk's `wnext`
             }
             if (tap == 7) sr = prep(C, dn);      // (C: every float4 of the next chunk has been staged; it becomes N of the next chunk)
             mma_tap((tap + SI) & 1);
@@ -412,6 +445,9 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
         // tap 8: its fragments are in registers -> slot Y and patch SI are free; slot X (next chunk's taps 0..4) must have landed - behind
         // its pieces: the requests of taps 5-7 and the two coefficient loads of tap 7 - and the next chunk's patch must be complete
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(REQ2) : "memory");
+#pragma unroll
+        for (int i = 0; i < REQ1; ++i) asm volatile("" :: "v"(ra[i].x));      // (as above: the requests of taps 0-3 are older than the REQ2 youngest loads)
+        SP_STAMP(14);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         SP_STAMP(10);
@@ -425,9 +461,18 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
 
     // ---- prologue ----------------------------------------------------------------------------------------------------------------------------
     if (ntl <= 0) return;
+    // chunk table -> LDS (uniform scalar loads of the kernel argument, once per workgroup)
+    for (int c = 0; c < nch; ++c) {
+        if (tid == 0) {
+            const unsigned long long sp_ = (unsigned long long)(uintptr_t)p.ch[c].src, wp_ = (unsigned long long)(uintptr_t)p.ch[c].wimg;
+            *reinterpret_cast<uint4*>(smem + TAB + (unsigned)c * 32u) = make_uint4((unsigned)sp_, (unsigned)(sp_ >> 32), (unsigned)wp_, (unsigned)(wp_ >> 32));
+            *reinterpret_cast<uint4*>(smem + TAB + (unsigned)c * 32u + 16u) = make_uint4((unsigned)p.ch[c].cstride, (unsigned)p.ch[c].coff, (unsigned)p.ch[c].gn_c0, (unsigned)p.ch[c].seg);
+        }
+    }
+    __syncthreads();
     {
         // chunk 0: requested, staged into patch 0; chunk 1: requested; chunk 2: coefficients fetched, source prepared
-        const Src s0 = prep(cf0, describe(tile_of(0), 0));
+        const Src s0 = prep(cf0, describe(tile_of(0), fetch(0)));
 #pragma unroll
         for (int i = 0; i < A9; ++i) issue_one(cf0, s0, i);
         {
@@ -437,10 +482,10 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
         }
 #pragma unroll
         for (int i = 0; i < A9; ++i) transform_one(cf0, i, 0);
-        const Src s1 = prep(cf1, describe(tile_of(0), 1));      // (nch >= 2)
+        const Src s1 = prep(cf1, describe(tile_of(0), fetch(1)));      // (nch >= 2)
 #pragma unroll
         for (int i = 0; i < A9; ++i) issue_one(cf1, s1, i);
-        sr = prep(cf0, describe(tile_of(2 >= nch ? 1 : 0), 2 >= nch ? 2 - nch : 2));
+        sr = prep(cf0, describe(tile_of(2 >= nch ? 1 : 0), fetch(2 >= nch ? 2 - nch : 2)));
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -458,10 +503,10 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
         for (int sg = 0; sg < 3; ++sg) {
             const int lo = seg_lo[sg], hi = seg_lo[sg + 1];
             if (lo >= hi) continue;
-            if (sg > 0 && p.scale != nullptr) {
+            if (sg > 0) {
                 // the accumulator changes units: from the previous K-segment's operand scale to this one's (powers of two: exact)
                 const PPTile tl = tile_of(it);
-                const float ratio = scale_c[8 * tl.b + p.ch[lo].seg] * scale_c[8 * tl.b + 4 + p.ch[lo - 1].seg];
+                const float ratio = scale_c[8 * tl.b + seg_id[sg]] * scale_c[8 * tl.b + 4 + seg_id[sg - 1]];
                 if (ratio != 1.0f) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
@@ -508,7 +553,7 @@ bool conv_sp_supported(const ConvParams& p, int stride, int up, int terms) {
         nch += s.C / 16;
     }
     if (nch < 2 || nch > PP_MAXCH || (nch & 1)) return false;
-    return p.gn_C > 0 && p.coef != nullptr;
+    return p.gn_C > 0 && p.coef != nullptr && p.scale != nullptr;      // (with_coef: every GroupNorm-ed split-fp16 launch carries operand scales)
 }
 
 template <int MT, int NT>

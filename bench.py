@@ -321,9 +321,7 @@ def conv_roofline(r, precision, workload, measure_traffic=False):
     rows = list(csv.DictReader(open(tmp.name))); os.unlink(tmp.name)
     ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0      # ALGORITHMIC (fp32-equivalent) TFLOP/s of the conv-GEMM launches
     # kernel classes: the engine's per-launch CSV says which kernel a launch took ("dma" column); conv_mfma16's tile follows Cout
-    PERSISTENT = {2: "conv_pp_kernel (Cout 32, persistent two-team)", 3: "conv_pp64_kernel (Cout 64, persistent two-team)",
-                  4: "conv_pp128_kernel (Cout 128, persistent two-team)", 5: "conv_sp_kernel (Cout 128, persistent, one wave per SIMD)",
-                  6: "conv_sp32_kernel (Cout 32, persistent, one wave per SIMD)"}
+    PERSISTENT = {2: "conv_pp_kernel (Cout 32, persistent two-team)", 5: "conv_sp_kernel (Cout 64 / 128, persistent, one wave per SIMD)"}
     cls = {}
     for w in rows:
         k = int(w["dma"])

@@ -1,13 +1,14 @@
 // Persistent software-pipelined implicit-GEMM 3x3 convolution, ONE wave per SIMD (256-thread workgroups, one per CU, 512 registers per
 // lane), split-fp16 MFMA, fp32-equivalent.  Reference: the convolutions of ResidualBlock (pnpflow/models.py:58-113).
 //
-// Why another structure.  conv_pp64 / conv_pp128 put two teams of four waves on a CU and alternate a VALU phase (staging: GroupNorm +
-// SiLU + fp16 hi / lo split of the next patch) of one team with the MFMA phase of the other.  The two waves of a SIMD share its VALU
+// Why another structure.  The two-team kernels of these levels (conv_pp64.hip in round 4, conv_pp128.hip early in round 5: retired, see
+// docs/HISTORY.md) put two teams of four waves on a CU and alternate a VALU phase (staging: GroupNorm + SiLU + fp16 hi / lo split of the
+// next patch) of one team with the MFMA phase of the other.  The two waves of a SIMD share its VALU
 // issue: every staging instruction of the partner costs the MFMA wave ~3 cycles (MI355X_MICROARCH.md "Two waves per SIMD"; round-5
 // stamps of conv_pp128: 4.5-5.6 k cycles per MFMA phase of 3.46 k matrix-pipe cycles, whoever issues the LDS-DMA refills), and every
 // phase boundary is a workgroup barrier.  A wave that is ALONE on its SIMD hides up to five single-issue instructions in the 32-cycle
 // shadow of each of its own MFMAs for nothing.  So here a wave does everything itself, in one instruction stream per 16-channel chunk:
-//   * MFMAs of chunk v from LDS fragments (A: the XOR-swizzled fp16 hi / lo patch of conv_pp64; B: the chunk's weight image, lane-linear);
+//   * MFMAs of chunk v from LDS fragments (A: an XOR-swizzled fp16 hi / lo patch; B: the chunk's weight image, lane-linear);
 //   * the staging of chunk v + 1 (from raw fp32 registers requested a chunk earlier) into the OTHER patch buffer, and the requests of
 //     chunk v + 2 into the registers it frees;
 //   * the LDS-DMA refill of the weights, half a chunk ahead: taps 0..4 of a chunk live in slot X (40 KiB), taps 5..8 in slot Y (32 KiB);
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
     const pp_float_cptr scale_c = (pp_float_cptr)(uintptr_t)p.scale;
     const int nch = p.n9;
 
-    // ---- per-lane constants of the staging (conv_pp64.hip) -------------------------------------------------------------------------------
+    // ---- per-lane constants of the staging ----------------------------------------------------------------------------------------------
     const int qi = tid & 3, p0 = tid >> 2;
     unsigned pk[A9], ldsw[A9];
 #pragma unroll
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
     const unsigned b_lane = (unsigned)lane * 16u;
     const unsigned dma_lane = (unsigned)(wq * 1024 + lane * 16);
 
-    // epilogue geometry (conv_pp64.hip)
+    // epilogue geometry (the lane transpose of pp_common.h)
     const bool bit3 = (lane & 8) != 0;
     const int em = lane & 7;
     const int ch_of_col = 4 * (l31 & 7) + (l31 >> 3);

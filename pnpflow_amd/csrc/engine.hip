@@ -45,7 +45,7 @@ struct Op {
     OpKind kind;
     ConvParams cp; int stride = 1, up = 0;
     int dma = 0;                                    // OP_CONV: 1 = conv_dma.hip (its operands were written by the OP_PREP in front of it)
-    int use_pp = 0; PPParams ppp{};                 // OP_CONV: 1 = conv_pp.hip / conv_pp64.hip (persistent two-team kernels of the 32- / 64-channel levels; ppp.cout says which)
+    int use_pp = 0; PPParams ppp{};                 // OP_CONV: 1 = conv_pp.hip (persistent two-team kernel of the 32-channel level), 2 = conv_sp.hip (64- / 128-channel levels)
     PrepParams pp{};
     EdgeConvParams ep;
     TembParams tp;
@@ -422,10 +422,10 @@ static const void* packed_conv_pp(pf_engine* e, const std::string& wname, int lo
     return upload(e, key, raw);
 }
 
-// LDS weight image of ONE 16-channel K-chunk for conv_pp64.hip (Cout = 64, 3x3): [tap][hi | lo][N-tile][k-half][column][8 halfs], input channel
+// LDS weight image of ONE 16-channel K-chunk for conv_sp.hip at Cout = 64 (3x3): [tap][hi | lo][N-tile][k-half][column][8 halfs], input channel
 // of (k-half, i) = lo + k-half * 8 + i, output channel of (N-tile, column n) = 32 N-tile + 4 (n & 7) + (n >> 3); same x 2^8 pre-scale and split
-static const void* packed_conv_pp64(pf_engine* e, const std::string& wname, int lo) {
-    const std::string key = wname + "#pp64_" + std::to_string(lo);
+static const void* packed_conv_sp64(pf_engine* e, const std::string& wname, int lo) {
+    const std::string key = wname + "#sp64_" + std::to_string(lo);
     auto it = e->dev.find(key);
     if (it != e->dev.end()) return it->second;
     const HostTensor& t = W(e, wname);
@@ -451,11 +451,11 @@ static const void* packed_conv_pp64(pf_engine* e, const std::string& wname, int 
     return upload(e, key, raw);
 }
 
-// LDS weight image of ONE 16-channel K-chunk for conv_pp128.hip (Cout = 128, 3x3): [tap][hi | lo][N-tile 0..3][k-half][column][8 halfs] = 9 tap
+// LDS weight image of ONE 16-channel K-chunk for conv_sp.hip at Cout = 128 (3x3): [tap][hi | lo][N-tile 0..3][k-half][column][8 halfs] = 9 tap
 // slots of 8 KiB; input channel of (k-half, i) = lo + k-half * 8 + i, output channel of (N-tile, column n) = 32 N-tile + 4 (n & 7) + (n >> 3);
 // same x 2^8 pre-scale and split as packed_conv16
-static const void* packed_conv_pp128(pf_engine* e, const std::string& wname, int lo) {
-    const std::string key = wname + "#pp128_" + std::to_string(lo);
+static const void* packed_conv_sp128(pf_engine* e, const std::string& wname, int lo) {
+    const std::string key = wname + "#sp128_" + std::to_string(lo);
     auto it = e->dev.find(key);
     if (it != e->dev.end()) return it->second;
     const HostTensor& t = W(e, wname);
@@ -476,34 +476,6 @@ static const void* packed_conv_pp128(pf_engine* e, const std::string& wname, int
                         out[(((size_t)tap * 2 + 0) * 4 + nt) * 512 + inner] = h;
                         out[(((size_t)tap * 2 + 1) * 4 + nt) * 512 + inner] = l;
                     }
-    std::vector<float> raw(out.size() / 2);
-    memcpy(raw.data(), out.data(), out.size() * sizeof(_Float16));
-    return upload(e, key, raw);
-}
-
-// LDS weight image of ONE 16-channel 3x3 K-chunk for conv_sp32.hip (Cout = 32): [tap][hi | lo][k-half][column][8 halfs] = 9 x 2 KiB; input
-// channel of (k-half, i) = lo + k-half * 8 + i, output channel of column n = 4 (n & 7) + (n >> 3); same x 2^8 pre-scale and split as packed_conv16
-static const void* packed_conv_sp32(pf_engine* e, const std::string& wname, int lo) {
-    const std::string key = wname + "#sp32_" + std::to_string(lo);
-    auto it = e->dev.find(key);
-    if (it != e->dev.end()) return it->second;
-    const HostTensor& t = W(e, wname);
-    const int O = (int)t.shape[0], I = (int)t.shape[1], kk = (int)(t.shape[2] * t.shape[3]);
-    if (O != 32 || kk != 9) return nullptr;
-    std::vector<_Float16> out((size_t)9 * 2 * 512, (_Float16)0.f);
-    for (int tap = 0; tap < 9; ++tap)
-        for (int kh = 0; kh < 2; ++kh)
-            for (int n = 0; n < 32; ++n)
-                for (int i = 0; i < 8; ++i) {
-                    const int c = lo + kh * 8 + i;
-                    const int oc = 4 * (n & 7) + (n >> 3);
-                    const float w = t.data[((size_t)oc * I + c) * 9 + tap] * 256.0f;
-                    const _Float16 h = (_Float16)w;
-                    const _Float16 l = (_Float16)(w - (float)h);
-                    const size_t inner = ((size_t)kh * 32 + n) * 8 + i;
-                    out[((size_t)tap * 2 + 0) * 512 + inner] = h;
-                    out[((size_t)tap * 2 + 1) * 512 + inner] = l;
-                }
     std::vector<float> raw(out.size() / 2);
     memcpy(raw.data(), out.data(), out.size() * sizeof(_Float16));
     return upload(e, key, raw);
@@ -620,17 +592,16 @@ static bool attach_dma(Builder& bd, ConvParams& p, int stride, int up, std::vect
     return true;
 }
 
-// conv_pp.hip (persistent two-team kernel of the 32-channel level): the launch becomes a device-resident list of 32-channel K-chunks
-static int attach_pp(Builder& bd, const ConvParams& p, int stride, int up, PPParams& q) {      // 0: no; 1: conv_pp / conv_pp64 / conv_pp128; 2: conv_sp
+// conv_pp.hip (persistent two-team kernel of the 32-channel level: 32-channel K-chunks) / conv_sp.hip (one wave per SIMD, the 64- and 128-channel
+// levels: 16-channel K-chunks, weights streamed through LDS slots): the launch becomes a list of K-chunks in the kernel argument
+static int attach_pp(Builder& bd, const ConvParams& p, int stride, int up, PPParams& q) {      // 0: no; 1: conv_pp; 2: conv_sp
     pf_engine* e = bd.e;
     if (e->precision != 1) return 0;
     const bool sp = (p.Cout == 128 || p.Cout == 64) && conv_sp_supported(p, stride, up, 3);
-    const bool sp32 = p.Cout == 32 && conv_sp32_supported(p, stride, up, 3);
-    const bool wide = p.Cout == 64 || p.Cout == 128;      // conv_pp64.hip / conv_pp128.hip: 16-channel chunks, weights streamed through an LDS ring
-    if (!sp && !sp32 && !(p.Cout == 128 ? conv_pp128_supported(p, stride, up, 3) : wide ? conv_pp64_supported(p, stride, up, 3) : conv_pp_supported(p, stride, up, 3))) return 0;
+    if (!sp && !(p.Cout == 32 && conv_pp_supported(p, stride, up, 3))) return 0;
     q = PPParams{};
-    q.cout = wide ? p.Cout : 32;
-    const int kc = (wide || sp32) ? 16 : 32;
+    q.cout = p.Cout;
+    const int kc = sp ? 16 : 32;
     int n = 0;
     for (int i = 0; i < p.nseg; ++i) {
         const ConvSeg& sg = p.seg[i];
@@ -640,9 +611,8 @@ static int attach_pp(Builder& bd, const ConvParams& p, int stride, int up, PPPar
             PPChunk& k = q.ch[n++];
             k.src = sg.src; k.cstride = sg.cstride; k.coff = sg.coff + cc * kc; k.xform = sg.xform;
             k.gn_c0 = sg.gn_off + cc * kc; k.seg = i;
-            k.wimg = sp32 ? packed_conv_sp32(e, it->second.name, it->second.lo + cc * kc)
-                     : p.Cout == 128 ? packed_conv_pp128(e, it->second.name, it->second.lo + cc * kc)
-                     : wide ? packed_conv_pp64(e, it->second.name, it->second.lo + cc * kc) : packed_conv_pp(e, it->second.name, it->second.lo + cc * kc);
+            k.wimg = !sp ? packed_conv_pp(e, it->second.name, it->second.lo + cc * kc)
+                     : p.Cout == 128 ? packed_conv_sp128(e, it->second.name, it->second.lo + cc * kc) : packed_conv_sp64(e, it->second.name, it->second.lo + cc * kc);
             if (!k.wimg) return 0;
             (sg.taps == 9 ? q.n9 : q.n1) += 1;
         }
@@ -650,7 +620,7 @@ static int attach_pp(Builder& bd, const ConvParams& p, int stride, int up, PPPar
     q.B = p.B; q.H = p.H; q.W = p.W;
     q.out = p.out; q.addvec = p.addvec; q.addvec_bs = p.addvec_bs; q.residual = p.residual; q.res_scale = p.res_scale;
     q.stats_out = p.stats_out; q.out_scale = p.out_scale; q.coef = p.coef; q.coef_stride = p.coef_stride; q.scale = p.scale;
-    return sp ? 2 : sp32 ? 3 : 1;
+    return sp ? 2 : 1;
 }
 
 static void push_conv(Builder& bd, const ConvParams& p0, int stride = 1, int up = 0) {
@@ -945,6 +915,22 @@ static int unet_walk(pf_engine* e, Builder& bd, Plan* plan) {
         op.ep.stats = h.stats; op.ep.gamma = upload(e, "end_conv.0.weight", W(e, "end_conv.0.weight").data);
         op.ep.beta = upload(e, "end_conv.0.bias", W(e, "end_conv.0.bias").data);
         op.ep.gn_cpg = ch / 32; op.ep.gn_eps = 1e-6f;
+        if (ch == 32 && e->precision != 0) {
+            // end_conv2_kernel's B fragments: MFMA k of (step s, half hh, j) = channel 16 hh + 8 s + j, column n = tap * Cimg + co (zero beyond
+            // 9 Cimg), x 2^8 and split like every packed conv weight
+            std::vector<_Float16> wm((size_t)2 * 2 * 64 * 8, (_Float16)0.f);
+            for (int sk = 0; sk < 2; ++sk) for (int ln = 0; ln < 64; ++ln) for (int j = 0; j < 8; ++j) {
+                const int n = ln & 31, hh = ln >> 5, cc = 16 * hh + 8 * sk + j;
+                if (n >= 9 * co_n) continue;
+                const int tap = n / co_n, co = n % co_n;
+                const float wv = w.data[((size_t)co * ch + cc) * 9 + tap] * 256.0f;
+                const _Float16 hi = (_Float16)wv, lo = (_Float16)(wv - (float)hi);
+                wm[(((size_t)sk * 2 + 0) * 64 + ln) * 8 + j] = hi; wm[(((size_t)sk * 2 + 1) * 64 + ln) * 8 + j] = lo;
+            }
+            std::vector<float> raw(wm.size() / 2);
+            memcpy(raw.data(), wm.data(), wm.size() * sizeof(_Float16));
+            op.ep.w16 = upload(e, "end_conv.mfma16", raw);
+        }
         plan->ops.push_back(op);
         plan->t_last = h;
     }
@@ -1364,8 +1350,7 @@ static int run_backward(pf_engine* e, Plan* plan, const float* vec, float* g, hi
 
 static hipError_t dispatch_conv(pf_engine* e, const Op& op, hipStream_t s) {
     if (op.use_pp == 2 && e->precision == 1) return launch_conv_sp(op.ppp, s);
-    if (op.use_pp == 3 && e->precision == 1) return launch_conv_sp32(op.ppp, s);
-    if (op.use_pp && e->precision == 1) return op.ppp.cout == 128 ? launch_conv_pp128(op.ppp, s) : op.ppp.cout == 64 ? launch_conv_pp64(op.ppp, s) : launch_conv_pp(op.ppp, s);
+    if (op.use_pp && e->precision == 1) return launch_conv_pp(op.ppp, s);
     if (op.dma) return launch_conv_dma(op.cp, op.up, s, e->precision == 2 ? 1 : 3);
     if (e->precision != 0) {
         bool ok16 = true;
@@ -2076,7 +2061,7 @@ int pf_engine_profile_read(pf_engine* e, int64_t* launches, double* ms_conv_gemm
             double bytes = (double)op.cp.B * op.cp.H * op.cp.W * op.cp.Cout * 4.0 * (op.cp.residual ? 2.0 : 1.0);
             for (int j = 0; j < op.cp.nseg; ++j) bytes += (double)op.cp.B * op.cp.Hs * op.cp.Ws * op.cp.seg[j].C * 4.0;
             fprintf(dump, "%zu,%d,%d,%d,%zu,%d,%d,%d,%d,%.4f,%.2f,%.2f,%d,%.3f", i, op.cp.H, op.cp.W, op.cp.Cout, K, op.cp.nseg, op.cp.seg[0].taps,
-                    op.stride, op.up, op.flops / 1e9, ms * 1e3, op.flops / (ms * 1e-3) / 1e12, op.use_pp == 2 ? 5 : op.use_pp == 3 ? 6 : op.use_pp ? (op.ppp.cout == 128 ? 4 : op.ppp.cout == 64 ? 3 : 2) : op.dma, bytes / 1e6);
+                    op.stride, op.up, op.flops / 1e9, ms * 1e3, op.flops / (ms * 1e-3) / 1e12, op.use_pp == 2 ? 5 : op.use_pp ? 2 : op.dma, bytes / 1e6);
             fprintf(dump, "\n");
         }
     }

@@ -109,6 +109,7 @@ struct EdgeConvParams {
     // end conv only: GroupNorm+SiLU of the input
     const double* stats; const float* gamma; const float* beta; int gn_cpg; float gn_eps;
     double* stats_out;    // begin conv: per-channel stats of the output
+    const void* w16;      // end conv (GroupNorm + SiLU form): split-fp16 MFMA weight image [k-step 2][hi | lo][lane 64][8 halfs], x 2^8 (engine.hip packed_end_conv16); nullptr: the VALU kernel
 };
 
 // fused attention core (attention.hip): qkv [B][T][3C] (q | k | v) -> out [B][T][C]
@@ -157,10 +158,10 @@ size_t conv_dma_a16_bytes(int B, int C, int Hs, int Ws, int terms);
 // conv_pp.hip: persistent two-team kernel of the full-resolution 32-channel level.  A launch is a list of 32-channel K-chunks (9-tap chunks
 // with GroupNorm(+SiLU) staging first, then raw 1-tap chunks of a folded 1x1 shortcut), each with its own LDS weight image
 // [k16-step = tap * 2 + j][hi | lo][k-half][Cout = 32][8 halfs] (values x 2^8, split like packed_conv16).
-constexpr int PP_MAXCH = 24;     // conv_pp: <= 4 chunks of 32 channels; conv_pp64: <= 12 chunks of 16 channels; conv_pp128: <= 24 (cat[256, 128] -> 128)
+constexpr int PP_MAXCH = 24;     // conv_pp: <= 4 chunks of 32 channels; conv_sp: <= 24 chunks of 16 channels (cat[256, 128] -> 128)
 struct PPChunk {
     const float* src;     // NHWC source tensor of the chunk's K-segment
-    const void* wimg;     // weight image of this chunk in global memory: taps * 4 KiB (conv_pp64: 36 KiB per 16-channel chunk, both N-tiles)
+    const void* wimg;     // weight image of this chunk in global memory: taps * 4 KiB (conv_sp: 36 / 72 KiB per 16-channel chunk of 64 / 128 output channels)
     int cstride, coff;    // floats per pixel of src; first channel of the chunk inside the pixel vector
     int xform;            // 1 GroupNorm, 2 GroupNorm + SiLU (9-tap chunks); 0 raw (1-tap chunks)
     int gn_c0;            // index of the chunk's channel 0 in the launch's GroupNorm coefficient vectors
@@ -168,9 +169,9 @@ struct PPChunk {
     int pad_;
 };
 struct PPParams {
-    PPChunk ch[PP_MAXCH]; // n9 nine-tap chunks, then n1 one-tap chunks (conv_pp is instantiated per (n9, n1, residual); conv_pp64 walks n9 at run time)
+    PPChunk ch[PP_MAXCH]; // n9 nine-tap chunks, then n1 one-tap chunks (conv_pp is instantiated per (n9, n1, residual); conv_sp walks n9 at run time)
     int n9, n1;
-    int cout;                             // 32: conv_pp.hip, 64: conv_pp64.hip, 128: conv_pp128.hip
+    int cout;                             // 32: conv_pp.hip; 64 / 128: conv_sp.hip
     int B, H, W, lx, ly;                  // tiles per row / column = 1 << lx / 1 << ly (8 x 16-pixel tiles)
     int rot;                              // workgroup g starts (g * rot) % (tiles of its range) tiles into its range (set by the launcher)
     float* out; const float* addvec; int addvec_bs; const float* residual; float res_scale; double* stats_out; float out_scale;
@@ -178,14 +179,8 @@ struct PPParams {
 };
 bool conv_pp_supported(const ConvParams& p, int stride, int up, int terms);
 hipError_t launch_conv_pp(const PPParams& p, hipStream_t s);
-bool conv_pp64_supported(const ConvParams& p, int stride, int up, int terms);
-hipError_t launch_conv_pp64(const PPParams& p, hipStream_t s);
-bool conv_sp32_supported(const ConvParams& p, int stride, int up, int terms);    // conv_sp32.hip: the same at the 32-channel level (weights resident, epilogue overlapped)
-hipError_t launch_conv_sp32(const PPParams& p, hipStream_t s);
-bool conv_sp_supported(const ConvParams& p, int stride, int up, int terms);      // conv_sp.hip: one wave per SIMD, software-pipelined (Cout = 128)
+bool conv_sp_supported(const ConvParams& p, int stride, int up, int terms);      // conv_sp.hip: one wave per SIMD, software-pipelined (Cout = 64 / 128)
 hipError_t launch_conv_sp(const PPParams& p, hipStream_t s);
-bool conv_pp128_supported(const ConvParams& p, int stride, int up, int terms);
-hipError_t launch_conv_pp128(const PPParams& p, hipStream_t s);
 
 hipError_t launch_conv(const ConvParams& p, int stride, int up, hipStream_t s);
 hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t s, int terms = 3);   // split-fp16 MFMA variant (terms 3) / single fp16 MFMA (terms 1)

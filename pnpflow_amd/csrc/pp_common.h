@@ -1,4 +1,4 @@
-// Device helpers shared by the persistent convolutions conv_pp.hip (Cout = 32) and conv_pp64.hip (Cout = 64): vector types, the staging
+// Device helpers shared by the persistent convolutions conv_pp.hip (Cout = 32) and conv_sp.hip (Cout = 64 / 128): vector types, the staging
 // SiLU, the in-register 4 x 4 lane transpose of the epilogue, tile geometry.
 #pragma once
 #include "pf_common.h"

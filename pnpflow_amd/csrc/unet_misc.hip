@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void begin_conv_kernel(const EdgeConvParams p)
     }
 }
 
+
 hipError_t launch_begin_conv(const EdgeConvParams& p, hipStream_t s) {
     if (p.C != 32 || p.Cimg > 3) return hipErrorInvalidValue;
     dim3 grid((p.H * p.W + 255) / 256, p.B);
@@ -167,9 +168,119 @@ __global__ __launch_bounds__(256) void end_conv_kernel(const EdgeConvParams p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------
+// end_conv, round 5 (C = 32, GroupNorm + SiLU input; the raw adjoint form stays on the kernel above): stage 1 - the 32 -> 9 Cimg
+// contraction per halo pixel, 864 scalar-operand FMAs per pixel in the round-1 kernel - runs on the matrix pipe: 32 halo pixels x 32
+// channels x 32 columns (27 used: tap x image channel) is ONE 32 x 32 x 32 MFMA tile, split-fp16 like every other conv of the net
+// (a_lo w_hi + a_hi w_lo + a_hi w_hi; weights pre-scaled by 2^8, activations by 2^3: fp32-equivalent).  A lane (pixel p = lane & 31,
+// half h = lane >> 5) reads its pixel's channels 16 h ... 16 h + 15 straight from the NHWC tensor (64 contiguous bytes), normalises /
+// activates / splits them in registers - they ARE the A fragments (MFMA k of step s, half h, j = channel 16 h + 8 s + j: the weight image
+// is packed to match) - and writes the 16 results of its column to the same LDS table t[pixel][tap][co] that stage 2 gathers from.
+// ------------------------------------------------------------------------------------
+typedef _Float16 ec_h8 __attribute__((ext_vector_type(8)));
+typedef float ec_f16v __attribute__((ext_vector_type(16)));
+
+template <int CIMG>
+__global__ __launch_bounds__(256) void end_conv2_kernel(const EdgeConvParams p) {
+    constexpr int C = 32, PW = 18, PP = PW * PW, NT_ = 9 * CIMG, TP = NT_ + 1, MTILES = (PP + 31) / 32;
+    __shared__ float s_t[PP * TP];
+    __shared__ float s_sc[C], s_sh[C];
+    const int tiles_x = (p.W + 15) / 16, tiles_y = (p.H + 15) / 16;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < C) {      // GroupNorm coefficients of this image (as the round-1 kernel)
+        const int g = tid / p.gn_cpg;
+        double sm = 0.0, ss = 0.0;
+        for (int j = g * p.gn_cpg; j < (g + 1) * p.gn_cpg; ++j) {
+            const double* st = p.stats + ((size_t)b * C + j) * 2;
+            sm += st[0]; ss += st[1];
+        }
+        const double N = (double)p.gn_cpg * p.H * p.W;
+        const double mean = sm / N;
+        double var = ss / N - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+        const float sc = p.gamma[tid] * rstd;
+        s_sc[tid] = sc; s_sh[tid] = p.beta[tid] - (float)mean * sc;
+    }
+    // weight fragments: [k-step][hi | lo][lane][8 halfs]
+    const ec_h8* wimg = reinterpret_cast<const ec_h8*>(p.w16);
+    const ec_h8 wh0 = wimg[0 * 64 + lane], wl0 = wimg[1 * 64 + lane], wh1 = wimg[2 * 64 + lane], wl1 = wimg[3 * 64 + lane];
+    __syncthreads();
+    const int pl = lane & 31, h = lane >> 5;
+    float sc[16], sh[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { sc[j] = s_sc[16 * h + j]; sh[j] = s_sh[16 * h + j]; }
+    const int oy0 = ty * 16, ox0 = tx * 16;
+    for (int mt = wv; mt < MTILES; mt += 4) {
+        const int hp = mt * 32 + pl;
+        const int gy = oy0 - 1 + hp / PW, gx = ox0 - 1 + hp % PW;
+        const bool valid = hp < PP && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        float a[16];
+        if (valid) {
+            const float4* src = reinterpret_cast<const float4*>(p.in + ((size_t)(b * p.H + gy) * p.W + gx) * C + 16 * h);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) { const float4 v = src[q4]; a[4 * q4] = v.x; a[4 * q4 + 1] = v.y; a[4 * q4 + 2] = v.z; a[4 * q4 + 3] = v.w; }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { const float u = a[j] * sc[j] + sh[j]; a[j] = u * __builtin_amdgcn_rcpf(1.0f + __expf(-u)) * 8.0f; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[j] = 0.f;
+        }
+        ec_h8 ah0, al0, ah1, al1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ah0[j] = (_Float16)a[j]; al0[j] = (_Float16)(a[j] - (float)ah0[j]);
+            ah1[j] = (_Float16)a[8 + j]; al1[j] = (_Float16)(a[8 + j] - (float)ah1[j]);
+        }
+        ec_f16v acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, wh0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, wl0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, wh0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, wh1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, wl1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, wh1, acc, 0, 0, 0);
+        // D: register i of lane (column n = lane & 31, half h) is row 8 (i / 4) + 4 h + (i % 4) of the tile
+        if (pl < NT_) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = mt * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+                if (row < PP) s_t[row * TP + pl] = acc[i] * (1.0f / 2048.0f);
+            }
+        }
+    }
+    __syncthreads();
+    const int ly = tid / 16, lx = tid % 16;
+    const int oy = oy0 + ly, ox = ox0 + lx;
+    float o[CIMG];
+#pragma unroll
+    for (int co = 0; co < CIMG; ++co) o[co] = p.bias[co];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const float* tp = s_t + ((ly + tap / 3) * PW + lx + tap % 3) * TP + tap * CIMG;
+#pragma unroll
+        for (int co = 0; co < CIMG; ++co) o[co] += tp[co];
+    }
+    if (oy < p.H && ox < p.W) {
+#pragma unroll
+        for (int co = 0; co < CIMG; ++co) p.out[((size_t)(b * CIMG + co) * p.H + oy) * p.W + ox] = o[co];
+    }
+}
+
 hipError_t launch_end_conv(const EdgeConvParams& p, hipStream_t s) {
     if (p.C != 32 || (p.Cimg != 1 && p.Cimg != 3)) return hipErrorInvalidValue;
     dim3 grid(p.B * ((p.H + 15) / 16) * ((p.W + 15) / 16));
+    if (p.w16 != nullptr && p.stats != nullptr) {
+        if (p.Cimg == 3) hipLaunchKernelGGL(end_conv2_kernel<3>, grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(end_conv2_kernel<1>, grid, dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
     if (p.Cimg == 3) hipLaunchKernelGGL((end_conv_kernel<32, 3>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((end_conv_kernel<32, 1>), grid, dim3(256), 0, s, p);
     return hipGetLastError();

@@ -1258,13 +1258,13 @@ def biglong_cases():
 
 
 # U-Net batches at which the launcher hands the 32- / 64- / 128-channel levels to the persistent kernels (conv_pp.hip >= 16 384 tiles of
-# 8 x 16 px, conv_pp64.hip >= 2 048 tiles of 16 x 16 px, conv_sp.hip >= 1 024 tiles of 16 x 16 px): the batches bench.py times
+# 8 x 16 px, conv_sp.hip >= 1 024 tiles of 16 x 16 px (128 channels) / 32 x 16 px (64 channels)): the batches bench.py times
 PRODUCTION_B = {"c2": 32, "c3": 64, "c4": 16, "c2_256": 32}
 
 
 def _profile_rows(m, unet_batch, S, tmp_path, name):
     """which kernel every conv launch of the plan for `unet_batch` images takes: the 'dma' column of the engine's per-launch CSV
-    (0 conv_mfma16, 1 conv_dma, 2 conv_pp, 3 conv_pp64, 4 conv_pp128, 5 conv_sp, 6 conv_sp32)"""
+    (0 conv_mfma16, 1 conv_dma, 2 conv_pp, 5 conv_sp)"""
     import csv
     x = det_normal((1, 3, S, S), 5).cuda().expand(unet_batch, -1, -1, -1).contiguous(); t = torch.full((unet_batch,), 0.3).cuda()
     m(x, t)
@@ -1279,7 +1279,7 @@ def _profile_rows(m, unet_batch, S, tmp_path, name):
 
 def _profile_paths(m, unet_batch, S, tmp_path, name):
     rows = _profile_rows(m, unet_batch, S, tmp_path, name)
-    return {k: sum(1 for r in rows if int(r["dma"]) == k) for k in range(7)}
+    return {k: sum(1 for r in rows if int(r["dma"]) == k) for k in range(6)}
 
 
 @pytest.mark.parametrize("tag", ["c2", "c3", "c4", "c2_256"])
@@ -1293,8 +1293,8 @@ def test_full_length_recursion_on_the_baseline_nets(hip, golden, tmp_path, tag, 
     precision mode 2 (one f16 MFMA per product): the final PSNR within the north_star's 0.05 dB on the same fixtures.
     batch "B1": the fixture as the reference ran it.  batch "production" (VERDICT r4 item 3): the fixture's image, measurement and
     injected noise replicated to the batch bench.py times (images are independent units: every replica must follow the reference's
-    B = 1 trajectory), so that the recursion runs through the kernels that SHIP at that batch - the persistent conv_pp / conv_pp64 /
-    conv_pp128 kernels, which small batches never select; the engine's per-launch CSV is asserted to show them."""
+    B = 1 trajectory), so that the recursion runs through the kernels that SHIP at that batch - the persistent conv_pp / conv_sp
+    kernels, which small batches never select; the engine's per-launch CSV is asserted to show them."""
     from pnpflow_amd.utils import psnr_per_image
     net, problem, mk = biglong_cases()[tag]
     g = golden("pnp_biglong_" + tag)
@@ -1316,10 +1316,10 @@ def test_full_length_recursion_on_the_baseline_nets(hip, golden, tmp_path, tag, 
         solver.noise = None
         if B > 1 and precision == 1:
             paths = _profile_paths(m, B * ns, S, tmp_path, f"layers_{tag}.csv")
-            assert paths[2] + paths[6] >= 26, paths          # conv_pp / conv_sp32 on the 32-channel level
-            # conv_sp (or conv_pp64) on >= 13 launches of the 64-channel level; at 256^2 conv_sp / conv_pp128 also on >= 10 launches of the
-            # 128-channel level (>= 4 tiles per workgroup at 64^2)
-            assert paths[3] + paths[4] + paths[5] >= 13 + (10 if S == 256 else 0), paths
+            assert paths[2] >= 26, paths          # conv_pp on the 32-channel level
+            # conv_sp on >= 13 launches of the 64-channel level; at 256^2 also on >= 10 launches of the 128-channel level (>= 4 tiles per
+            # workgroup at 64^2)
+            assert paths[5] >= 13 + (10 if S == 256 else 0), paths
     finally:
         m.set_precision(1)
     clean = det_image((1, Cc, S, S), 31)
@@ -1683,39 +1683,6 @@ def test_conv_pp_path_is_selected_on_the_32_channel_level_and_fp32_equivalent(hi
     m2(det_normal((2, 3, 64, 64), 6).cuda(), torch.full((2,), 0.3).cuda())
 
 
-def test_conv_pp64_path_is_selected_on_the_64_channel_level_and_fp32_equivalent(hip, tmp_path):
-    """conv_pp64.hip (persistent two-team kernel, 16-channel K-chunks, weights streamed through a two-slot LDS ring by LDS-DMA, 64 x 64
-    wave tiles) takes the GroupNorm-ed 3x3 convs of the 64-channel level that carry neither an identity residual nor a folded 1x1
-    shortcut - ResidualBlock conv1 of the down path, conv1 over cat[h, skip] of the up path (models.py:58-113) - and nothing else; the
-    forward agrees with the one where those launches stay on conv_mfma16_kernel to fp32 rounding (same products, another summation
-    order: 2e-6 of max|v|), at 128^2 and at 256^2."""
-    import csv, subprocess, sys
-    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # (B = 129: 2 064 tiles over 256 workgroups - ragged ranges, odd tile counts per team, a team whose last tile is not live)
-    for net, B in (("celeba128", 160), ("afhq256", 40), ("celeba128", 129)):
-        outs = {}
-        for pp in ("0", "1"):
-            env = dict(os.environ, PNPFLOW_HIP_PP64=pp, PNPFLOW_HIP_SP="2")      # (conv_sp confined to the 128-channel level: round 5 gave it the 64-channel level by default)
-            f = str(tmp_path / f"v_{net}_{B}_pp64_{pp}.npy")
-            r = subprocess.run([sys.executable, "tools/gpu_dma_check.py", "run", net, str(B), "1", f], cwd=repo, env=env, capture_output=True, text=True, timeout=600)
-            assert r.returncode == 0, r.stderr[-2000:]
-            outs[pp] = np.load(f)
-        ref = np.abs(outs["0"]).max()
-        assert np.isfinite(outs["1"]).all() and np.abs(outs["0"] - outs["1"]).max() <= 2e-6 * ref, (net, np.abs(outs["0"] - outs["1"]).max(), ref)
-    if os.environ.get("PNPFLOW_HIP_PP64") not in (None, "1"):
-        return
-    # selection with conv_sp confined to the 128-channel level (a child process: the switches are read once per process)
-    path = str(tmp_path / "layers_pp64.csv")
-    r = subprocess.run([sys.executable, "tools/gpu_layer_profile.py", "128", "160", path], cwd=repo, env=dict(os.environ, PNPFLOW_HIP_SP="2"),
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    rows = list(csv.DictReader(open(path)))
-    pp_rows = [r for r in rows if int(r["dma"]) == 3]
-    assert len(pp_rows) == 13, len(pp_rows)          # 1 + 5 + 1 + 5 + 1 launches of K = 288 / 576 / 864 / 1152 / 1728
-    assert all(int(r["Cout"]) == 64 and int(r["H"]) == 64 and int(r["stride"]) == 1 and int(r["up"]) == 0 for r in pp_rows)
-    assert sorted(set(int(r["K"]) for r in pp_rows)) == [288, 576, 864, 1152, 1728]
-
-
 def _ab_forwards(tmp_path, cases, env_off, env_on, tag):
     """whole forwards with a kernel family switched off / on through its test-only environment switch (tools/gpu_dma_check.py in child
     processes): the outputs must agree to fp32 rounding (the same products in another summation order)"""
@@ -1733,35 +1700,24 @@ def _ab_forwards(tmp_path, cases, env_off, env_on, tag):
         assert np.isfinite(outs["on"]).all() and np.abs(outs["off"] - outs["on"]).max() <= 2e-6 * ref, (tag, net, B, np.abs(outs["off"] - outs["on"]).max(), ref)
 
 
-def test_conv_sp_and_conv_pp128_take_the_128_channel_level_and_are_fp32_equivalent(hip, tmp_path):
-    """Round 5: the GroupNorm + SiLU 3x3 convs of the 128-channel level (ResidualBlock conv1, conv1 over cat[h, skip], conv2 with the
-    identity residual: models.py:58-113 at level width 128; 18 of the level's 26 launches) run on conv_sp.hip (one wave per SIMD, software-
-    pipelined, half-chunk LDS-DMA weight slots) and, with PNPFLOW_HIP_SP=0, on conv_pp128.hip (two teams, 16-slot per-tap weight ring,
-    LDS-counter hand-over); with both off they stay on conv_mfma16_kernel.  All three forwards agree to fp32 rounding, at the headline
-    U-Net batch shape and at a ragged one (81 images: 1 296 tiles over 256 workgroups)."""
-    off = dict(PNPFLOW_HIP_SP="0", PNPFLOW_HIP_PP128="0")
-    _ab_forwards(tmp_path, (("afhq256", 80), ("afhq256", 81)), off, dict(PNPFLOW_HIP_SP="1"), "sp")
-    _ab_forwards(tmp_path, (("afhq256", 80), ("afhq256", 81)), off, dict(PNPFLOW_HIP_SP="0", PNPFLOW_HIP_PP128="1"), "pp128")
+def test_conv_sp_takes_the_64_and_128_channel_levels_and_is_fp32_equivalent(hip, tmp_path):
+    """Round 5: the GroupNorm + SiLU 3x3 convs of the 64- and 128-channel levels (ResidualBlock conv1, conv1 over cat[h, skip], conv2 with the
+    identity residual: models.py:58-113 at level widths 64 / 128) run on conv_sp.hip (one wave per SIMD, software-pipelined, half-chunk
+    LDS-DMA weight slots); with the test-only switch PNPFLOW_HIP_SP=0 they stay on conv_mfma16_kernel.  The two forwards agree to fp32
+    rounding (the same products in another summation order), at the headline U-Net batch shape, at a ragged one (81 images: 1 296 tiles
+    over 256 workgroups) and at 128^2."""
+    _ab_forwards(tmp_path, (("afhq256", 80), ("afhq256", 81), ("celeba128", 160)), dict(PNPFLOW_HIP_SP="0"), dict(PNPFLOW_HIP_SP="1"), "sp")
     if os.environ.get("PNPFLOW_HIP_SP") not in (None, "1"):
         return
     m, cfg, sd = model_for("afhq256")
     rows = _profile_rows(m, 80, 256, tmp_path, "layers_sp.csv")
     sp = [r for r in rows if int(r["dma"]) == 5]
-    assert not [r for r in rows if int(r["dma"]) in (3, 4)], "conv_pp64 / conv_pp128 selected beside conv_sp"
     # 128-channel level: 5 + 5 + 5 + 1 + 1 + 1 launches of K = 1152 (conv1), 1152 (conv2 + residual), 2304, 576, 1728, 3456
     assert sorted(int(r["K"]) for r in sp if int(r["Cout"]) == 128) == sorted([1152] * 10 + [2304] * 5 + [576, 1728, 3456])
-    # 64-channel level (the round's last kernel commit): conv1, conv2 + identity residual (K = 576 x 10), conv1 over cat[h, skip]
+    # 64-channel level: conv1, conv2 + identity residual (K = 576 x 10), conv1 over cat[h, skip]
     # (K = 1152 x 5, 864, 1728), the first block's conv1 (K = 288); the launches with a folded 1x1 shortcut stay on conv_mfma16_kernel
     assert sorted(int(r["K"]) for r in sp if int(r["Cout"]) == 64) == sorted([576] * 10 + [1152] * 5 + [288, 864, 1728])
     assert all(int(r["stride"]) == 1 and int(r["up"]) == 0 and int(r["H"]) == (64 if int(r["Cout"]) == 128 else 128) for r in sp)
-
-
-def test_conv_sp32_is_fp32_equivalent(hip, tmp_path):
-    """conv_sp32.hip (the one-wave-per-SIMD structure at the 32-channel level: weights resident in LDS, tap-row steps, the epilogue of a
-    tile riding in the next tile's MFMA shadows) is parity-green but not selected by default (it does not beat conv_pp there: DESIGN
-    4.18); PNPFLOW_HIP_SP32=1 selects it for the GroupNorm + SiLU 3x3 launches of the level - conv1 / conv2 (+ residual) of the down
-    path, conv1 over cat[h, skip] - and the forward agrees with the default one to fp32 rounding (ragged ranges included)."""
-    _ab_forwards(tmp_path, (("afhq256", 40), ("celeba128", 129)), dict(PNPFLOW_HIP_SP32="0"), dict(PNPFLOW_HIP_SP32="1"), "sp32")
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,4 +1,4 @@
-"""Build gate for the kernels that refill LDS with inline-asm LDS-DMA (global_load_lds_dwordx4: conv_pp64.hip, conv_pp128.hip, conv_sp.hip).
+"""Build gate for the kernels that refill LDS with inline-asm LDS-DMA (global_load_lds_dwordx4: conv_sp.hip).
 hipcc's waitcnt pass does not see those loads, so the hand-over of a refilled slot rests on a hand-written `s_waitcnt vmcnt(N)` in
 front of the workgroup barrier that publishes it.  This walks the compiled ISA of every kernel in layout order and fails when an
 `s_barrier` is reached while an LDS-DMA piece has been issued since the last `s_waitcnt` that names vmcnt - e.g. after a compiler

@@ -34,7 +34,7 @@ for name in ("c2_256", "c2", "c3", "c4"):
     tot_b = 0.0; tot_n = 0; rows = []
     for k in sorted(f, key=lambda k: -f[k][0]):
         fs, n = f[k]; ws = w.get(k, (0, n))[0]
-        conv = ("conv_mfma" in k or "conv_dma" in k or "conv_pp" in k or "prep_split" in k)
+        conv = ("conv_mfma" in k or "conv_dma" in k or "conv_pp" in k or "conv_sp" in k or "prep_split" in k)
         rows.append({"kernel": k[:80], "launches": n, "read_mb_per_launch": round(2 * fs * 1024 / n / 1e6, 2), "write_mb_per_launch": round(ws * 1024 / n / 1e6, 2), "conv_family": conv})
         if conv:
             tot_b += (2 * fs + ws) * 1024

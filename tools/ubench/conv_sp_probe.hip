@@ -1,4 +1,4 @@
-// Stand-alone timing of conv_pp128_kernel (pnpflow_amd/csrc/conv_sp.hip) on synthetic tensors, with s_memtime stamps of workgroup 0's
+// Stand-alone timing + parity of conv_sp_kernel (pnpflow_amd/csrc/conv_sp.hip) on synthetic tensors, with s_memtime stamps of workgroup 0's
 // phases.  build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../pnpflow_amd/csrc -o conv_sp_probe conv_sp_probe.hip
 // run: ./conv_sp_probe [H W B nch res first_step n_steps cout]
 #define PP_PROBE_BUILD 1

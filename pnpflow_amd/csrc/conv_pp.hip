@@ -148,11 +148,13 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
     };
     Pre pre0, pre1;
     struct Res { float4 rv[MT][4]; float addv; };      // residual + bias (+ time-embedding projection) of one tile
-    // residual of a tile: requested RD steps before the epilogue that adds it.  Two steps (as the patches) where a step is short (MT = 1); with
-    // one chunk per tile two residuals are then in flight (two sets, by tile parity).  With more chunks the tile before has been closed when
-    // the request is issued, with MT = 2 one step (~9 k cycles) is distance enough: ONE set
-    constexpr int RD = (NCH == 1 && MT == 2) ? 1 : 2;
-    constexpr int NRES = (NCH == 1 && MT == 1) ? 2 : 1;
+    // The library instantiates (and the tests cover) 8 x 16-pixel team tiles only: MT stays a parameter of the tile geometry, the prefetch
+    // distances below are the MT = 1 ones (16 x 16 tiles spilled 57-156 registers with this two-step prefetch: +30 ... +70 % per launch, r4)
+    static_assert(MT == 1, "conv_pp_kernel: the residual / accumulator scheme below is the one of 8 x 16-pixel team tiles");
+    // residual of a tile: requested RD = 2 steps before the epilogue that adds it (as the patches: a step is short); with one chunk per tile
+    // two residuals are then in flight (two sets, by tile parity); with more chunks the tile before has been closed when the request is issued
+    constexpr int RD = 2;
+    constexpr int NRES = NCH == 1 ? 2 : 1;
     Res res0, res1;      // (named objects, not an array: hipcc's counted vmcnt waits degrade to vmcnt(4) / vmcnt(0) when the sets are array elements)
 
     // (the prologue's requests: the first two steps' patches)
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
 
     // two accumulators per M-tile (even / odd k16-steps, summed in the epilogue): with one, the 54 MFMAs of a chunk are a single dependent
     // chain and the wave stalls on every issue (r4 counters: SQ_WAIT_INST_ANY 19 % of the wave's cycles)
-    constexpr int NACC = MT == 1 ? 2 : 1;      // (two M-tiles per wave are two independent chains already)
+    constexpr int NACC = 2;
     f32x16 acc[NACC][MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)

@@ -852,6 +852,22 @@ static int unet_walk(pf_engine* e, Builder& bd, Plan* plan) {
         op.ep.bias = upload(e, "begin_conv.bias", W(e, "begin_conv.bias").data);
         op.ep.B = B; op.ep.H = H0; op.ep.W = H0; op.ep.Cimg = ci_n; op.ep.C = ch;
         op.ep.stats_out = t0.stats;              // (sum, sumsq) per channel for the first GroupNorm, reduced in the same kernel
+        if (ch == 32 && e->precision != 0 && (ci_n == 1 || ci_n == 3)) {
+            // begin_conv2_kernel's B fragments: MFMA k of (step s, half hh, j) = 16 s + 8 hh + j = input channel * 9 + tap (zero beyond 9 Cimg),
+            // column n = output channel, x 2^8 and split like every packed conv weight
+            std::vector<_Float16> wm((size_t)2 * 2 * 64 * 8, (_Float16)0.f);
+            for (int sk = 0; sk < 2; ++sk) for (int ln = 0; ln < 64; ++ln) for (int j = 0; j < 8; ++j) {
+                const int n = ln & 31, hh = ln >> 5, kk = 16 * sk + 8 * hh + j;
+                if (kk >= 9 * ci_n) continue;
+                const int ci = kk / 9, tap = kk % 9;
+                const float wv = w.data[((size_t)n * ci_n + ci) * 9 + tap] * 256.0f;
+                const _Float16 hi = (_Float16)wv, lo = (_Float16)(wv - (float)hi);
+                wm[(((size_t)sk * 2 + 0) * 64 + ln) * 8 + j] = hi; wm[(((size_t)sk * 2 + 1) * 64 + ln) * 8 + j] = lo;
+            }
+            std::vector<float> raw(wm.size() / 2);
+            memcpy(raw.data(), wm.data(), wm.size() * sizeof(_Float16));
+            op.ep.w16 = upload(e, "begin_conv.mfma16", raw);
+        }
         plan->ops.push_back(op);
         hs.push_back(t0);
         plan->t_begin = t0;

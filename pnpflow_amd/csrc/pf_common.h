@@ -109,7 +109,7 @@ struct EdgeConvParams {
     // end conv only: GroupNorm+SiLU of the input
     const double* stats; const float* gamma; const float* beta; int gn_cpg; float gn_eps;
     double* stats_out;    // begin conv: per-channel stats of the output
-    const void* w16;      // end conv (GroupNorm + SiLU form): split-fp16 MFMA weight image [k-step 2][hi | lo][lane 64][8 halfs], x 2^8 (engine.hip packed_end_conv16); nullptr: the VALU kernel
+    const void* w16;      // split-fp16 MFMA weight image [k-step 2][hi | lo][lane 64][8 halfs], x 2^8 (engine.hip): end conv in its GroupNorm + SiLU form (k = channel), begin conv forward (k = input channel * 9 + tap); nullptr: the VALU kernels
 };
 
 // fused attention core (attention.hip): qkv [B][T][3C] (q | k | v) -> out [B][T][C]

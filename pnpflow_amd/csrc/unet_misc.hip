@@ -73,8 +73,141 @@ __global__ __launch_bounds__(256) void begin_conv_kernel(const EdgeConvParams p)
 }
 
 
+// ------------------------------------------------------------------------------------
+// begin_conv, round 5 (forward, C = 32, Cimg = 1 or 3): the Cimg x 9 -> 32 contraction per pixel on the matrix pipe, as end_conv2_kernel
+// below - 32 pixels x K = 32 (27 used: input channel x tap) x 32 channels is one split-fp16 32 x 32 x 32 MFMA tile (image x 2^3, weights
+// x 2^8: fp32-equivalent for |x| < 8 188).  The round-1 kernel above spends 864 scalar-operand FMAs per pixel and runs at 0.25 of the
+// write bandwidth (620 us for 1.34 GB; a lane-per-channel-quad v_pk_fma_f32 form measured 669 us - tools/ubench/edge_probe.hip); here a
+// lane (pixel p = lane & 31, half h = lane >> 5) gathers its 16 im2col values from the LDS image patch, splits them, and the 16 results of
+// its channel go through an LDS tile from which the workgroup writes whole 128-byte NHWC pixel rows.  Persistent: a workgroup walks a
+// contiguous range of 16 x 16-pixel tiles, the next tile's patch is fetched into registers under the current tile's work, the
+// GroupNorm statistics are carried per lane (fp32 per tile, fp64 across tiles) and flushed when the image changes.  The adjoint use
+// (backward of end_conv: no weight image) stays on the round-1 kernel.
+// ------------------------------------------------------------------------------------
+typedef _Float16 bc_h8 __attribute__((ext_vector_type(8)));
+typedef float bc_f16v __attribute__((ext_vector_type(16)));
+
+template <int CIMG>
+__global__ __launch_bounds__(256) void begin_conv2_kernel(const EdgeConvParams p) {
+    constexpr int C = 32, PW = 18, NIMG = CIMG * PW * PW, K27 = 9 * CIMG, OP = 36, NLD = (NIMG + 255) / 256;
+    __shared__ float s_img[NIMG + 4];      // [ci][18][18] + a zero slot (the padding of K to 32)
+    __shared__ __attribute__((aligned(16))) float s_o[256 * OP];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
+    const int tiles_x = (p.W + 15) / 16, tiles_y = (p.H + 15) / 16, per_img = tiles_x * tiles_y;
+    const long total = (long)per_img * p.B;
+    const long t0 = total * blockIdx.x / gridDim.x, t1 = total * (blockIdx.x + 1) / gridDim.x;
+    if (t0 >= t1) return;
+    if (tid == 0) s_img[NIMG] = 0.f;
+    // B fragments: [k-step][hi | lo][lane][8 halfs] (engine.hip packs MFMA k of (step s, half h, j) = 16 s + 8 h + j = input channel * 9 + tap)
+    const bc_h8* wimg = reinterpret_cast<const bc_h8*>(p.w16);
+    const bc_h8 wh0 = wimg[0 * 64 + lane], wl0 = wimg[1 * 64 + lane], wh1 = wimg[2 * 64 + lane], wl1 = wimg[3 * 64 + lane];
+    const float bias_n = p.bias[pl];
+    // LDS offsets of this lane's 16 im2col values relative to its pixel's patch origin (the zero slot for k >= 9 Cimg)
+    int offk[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k = 16 * (i >> 3) + 8 * h + (i & 7);
+        const int ci = k / 9, tap = k - 9 * ci;
+        offk[i] = k < K27 ? (ci * PW + tap / 3) * PW + tap % 3 : -1;
+    }
+    const int q = tid & 7;
+    double d1[4] = {0, 0, 0, 0}, d2[4] = {0, 0, 0, 0};
+    int cur_b = -1;
+    auto flush = [&]() {
+        if (p.stats_out == nullptr || cur_b < 0) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double a = d1[j], s2 = d2[j];
+            a += __shfl_xor(a, 8); s2 += __shfl_xor(s2, 8);
+            a += __shfl_xor(a, 16); s2 += __shfl_xor(s2, 16);
+            a += __shfl_xor(a, 32); s2 += __shfl_xor(s2, 32);
+            if (lane < 8) {
+                double* dst = p.stats_out + ((size_t)cur_b * C + 4 * q + j) * 2;
+                unsafeAtomicAdd(dst, a); unsafeAtomicAdd(dst + 1, s2);
+            }
+            d1[j] = 0; d2[j] = 0;
+        }
+    };
+    float nxt[NLD];
+    auto fetch = [&](long t) {
+        const int b = (int)(t / per_img), r = (int)(t - (long)b * per_img);
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + 256 * k;
+            const int ci = i / (PW * PW), rr = i - ci * (PW * PW), py = rr / PW, px = rr - py * PW;
+            const int gy = ty * 16 - 1 + py, gx = tx * 16 - 1 + px;
+            float v = 0.f;
+            if (i < NIMG && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = p.in[(((size_t)b * CIMG + ci) * p.H + gy) * p.W + gx];
+            nxt[k] = v;
+        }
+    };
+    fetch(t0);
+    for (long t = t0; t < t1; ++t) {
+        const int b = (int)(t / per_img), r = (int)(t - (long)b * per_img);
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const int y0 = ty * 16, x0 = tx * 16;
+        if (b != cur_b) { flush(); cur_b = b; }
+        __syncthreads();      // (the previous tile's patch and output tile have been read)
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) if (tid + 256 * k < NIMG) s_img[tid + 256 * k] = nxt[k];
+        __syncthreads();
+        if (t + 1 < t1) fetch(t + 1);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int mt = 2 * wv + mi;                       // M-tile: rows 2 mt, 2 mt + 1 of the tile
+            const int base = (2 * mt + (pl >> 4)) * PW + (pl & 15);
+            float a[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a[i] = s_img[offk[i] < 0 ? NIMG : base + offk[i]] * 8.0f;
+            bc_h8 ah0, al0, ah1, al1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                ah0[j] = (_Float16)a[j]; al0[j] = (_Float16)(a[j] - (float)ah0[j]);
+                ah1[j] = (_Float16)a[8 + j]; al1[j] = (_Float16)(a[8 + j] - (float)ah1[j]);
+            }
+            bc_f16v acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, wh0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, wl0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, wh0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, wh1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, wl1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, wh1, acc, 0, 0, 0);
+            // D: register i of lane (column = channel pl, half h) is pixel row 8 (i / 4) + 4 h + (i % 4) of the M-tile
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s_o[(mt * 32 + 8 * (i >> 2) + 4 * h + (i & 3)) * OP + pl] = acc[i] * (1.0f / 2048.0f) + bias_n;
+        }
+        __syncthreads();
+        float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int px = (k * 256 + tid) >> 3;              // pixel of the tile (row px / 16, column px % 16); this thread's channel quad is q
+            const int y = y0 + (px >> 4), x = x0 + (px & 15);
+            if (y < p.H && x < p.W) {
+                const float4 v = *reinterpret_cast<const float4*>(&s_o[px * OP + 4 * q]);
+                *reinterpret_cast<float4*>(p.out + (((size_t)b * p.H + y) * p.W + x) * C + 4 * q) = v;
+                s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;
+                s2[0] += v.x * v.x; s2[1] += v.y * v.y; s2[2] += v.z * v.z; s2[3] += v.w * v.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { d1[j] += (double)s1[j]; d2[j] += (double)s2[j]; }
+    }
+    flush();
+}
+
 hipError_t launch_begin_conv(const EdgeConvParams& p, hipStream_t s) {
     if (p.C != 32 || p.Cimg > 3) return hipErrorInvalidValue;
+    const long tiles = (long)p.B * ((p.H + 15) / 16) * ((p.W + 15) / 16);
+    if (p.w16 != nullptr && (p.Cimg == 1 || p.Cimg == 3) && tiles >= device_cu_count()) {      // (below one tile per CU the one-pixel-per-thread kernel is the faster one: 13 vs 24 us at 3 x 100 x 52)
+        const long want = 3L * device_cu_count();
+        const int grid = (int)(tiles < want ? tiles : want);
+        if (p.Cimg == 3) hipLaunchKernelGGL(begin_conv2_kernel<3>, dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(begin_conv2_kernel<1>, dim3(grid), dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
     dim3 grid((p.H * p.W + 255) / 256, p.B);
     hipLaunchKernelGGL(begin_conv_kernel<32>, grid, dim3(256), 0, s, p);
     return hipGetLastError();

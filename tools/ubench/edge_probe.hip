@@ -61,9 +61,31 @@ int main(int argc, char** argv) {
     (void)hipMemcpy(be, hbe.data(), 16, hipMemcpyHostToDevice); (void)hipMemcpy(g, hg.data(), 128, hipMemcpyHostToDevice); (void)hipMemcpy(bt, hbt.data(), 128, hipMemcpyHostToDevice);
     (void)hipMemcpy(w16, wm.data(), wm.size() * 2, hipMemcpyHostToDevice);
 
-    // ---- begin conv (round-1 kernel; a lane-per-channel-quad v_pk_fma_f32 variant measured in round 5 was bit-identical and no faster: 621 -> 669 us) ----
+    // ---- begin conv: round-1 VALU kernel against begin_conv2_kernel (MFMA) ---------------------------------------------------------------
+    std::vector<_Float16> wmb((size_t)2 * 2 * 64 * 8, (_Float16)0.f);      // engine.hip's packing: k = ci * 9 + tap, weights [tap][ci][C] in hwb
+    for (int sk = 0; sk < 2; ++sk) for (int ln = 0; ln < 64; ++ln) for (int j = 0; j < 8; ++j) {
+        const int n = ln & 31, hh = ln >> 5, kk = 16 * sk + 8 * hh + j;
+        if (kk >= 9 * CI) continue;
+        const int ci = kk / 9, tap = kk % 9;
+        const float wv = hwb[((size_t)tap * CI + ci) * C + n] * 256.0f;
+        const _Float16 hi = (_Float16)wv, lo = (_Float16)(wv - (float)hi);
+        wmb[(((size_t)sk * 2 + 0) * 64 + ln) * 8 + j] = hi; wmb[(((size_t)sk * 2 + 1) * 64 + ln) * 8 + j] = lo;
+    }
+    void* w16b; (void)hipMalloc(&w16b, wmb.size() * 2); (void)hipMemcpy(w16b, wmb.data(), wmb.size() * 2, hipMemcpyHostToDevice);
     EdgeConvParams p{}; p.in = img; p.w = wb; p.bias = bias; p.B = B; p.H = H; p.W = W; p.Cimg = CI; p.C = C;
-    printf("begin_conv %dx%dx%d Cimg %d: %.1f us (%.2f GB written)\n", B, H, W, CI, time_us([&] { EdgeConvParams q = p; q.out = act2; q.stats_out = st2; (void)launch_begin_conv(q, 0); }), npix * C * 4 / 1e9);
+    auto old_begin = [&](float* out, double* stats) { EdgeConvParams q = p; q.out = out; q.stats_out = stats; q.w16 = nullptr; (void)launch_begin_conv(q, 0); };
+    auto new_begin = [&](float* out, double* stats) { EdgeConvParams q = p; q.out = out; q.stats_out = stats; q.w16 = w16b; (void)launch_begin_conv(q, 0); };
+    (void)hipMemset(st1, 0, (size_t)B * C * 16); (void)hipMemset(st2, 0, (size_t)B * C * 16);
+    old_begin(act, st1); new_begin(act2, st2); (void)hipDeviceSynchronize();
+    {
+        std::vector<float> a(npix * C), b2(npix * C); std::vector<double> s1((size_t)B * C * 2), s2((size_t)B * C * 2);
+        (void)hipMemcpy(a.data(), act, a.size() * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(b2.data(), act2, a.size() * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(s1.data(), st1, s1.size() * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(s2.data(), st2, s2.size() * 8, hipMemcpyDeviceToHost);
+        double emax = 0, rmax = 0; for (size_t i = 0; i < a.size(); ++i) { rmax = fmax(rmax, fabs(a[i])); const double d = fabs((double)a[i] - b2[i]); if (!(d <= emax)) emax = d; }
+        double srel = 0; for (size_t i = 0; i < s1.size(); ++i) srel = fmax(srel, fabs(s1[i] - s2[i]) / fmax(1.0, fabs(s1[i])));
+        printf("begin_conv %dx%dx%d Cimg %d: max|MFMA - VALU| = %.3e, max|VALU| = %.3e; statistics max rel diff %.2e  %s\n", B, H, W, CI, emax, rmax, srel, emax <= 2e-6 * rmax && srel < 1e-4 ? "OK" : "FAIL");
+    }
+    printf("begin_conv: round-1 kernel %.1f us, begin_conv2_kernel %.1f us (%.2f GB written)\n", time_us([&] { old_begin(act, st1); }), time_us([&] { new_begin(act2, st2); }), npix * C * 4 / 1e9);
     for (int g : {1024, 4096, 16384})
         printf("pure float4 streaming of the %.2f GB tensor, grid %5d: write %.1f us, read %.1f us\n", npix * C * 4 / 1e9, g,
                time_us([&] { hipLaunchKernelGGL(fill_kernel, dim3(g), dim3(256), 0, 0, reinterpret_cast<float4*>(act2), npix * C / 4); }),

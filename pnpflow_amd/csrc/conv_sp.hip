@@ -248,10 +248,14 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
         const size_t pix0 = ((size_t)tl.b * p.H + tl.oy0 + wq * 2 * MT) * p.W + tl.ox0;
         char* obase = reinterpret_cast<char*>(p.out + pix0 * COUT);
         const char* rbase = RES ? reinterpret_cast<const char*>(p.residual + pix0 * COUT) : nullptr;
-        float4 rv[2][4];
+        float4 rv[3][4];      // residual of accumulator tiles k, k + 1, k + 2: requested TWO tiles ahead (one tile ahead part of the round trip was exposed: -3 % on the 64-channel level's residual launches, probe r05)
         if constexpr (RES) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) rv[0][g] = nt_load4(rbase + tile_offs(0, 0, g));
+            if (MT * NT > 1) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rv[1][g] = nt_load4(rbase + tile_offs(1 / NT, 1 % NT, g));
+            }
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -259,9 +263,9 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
             for (int nt = 0; nt < NT; ++nt) {
                 const int k = mt * NT + nt;
                 if constexpr (RES) {
-                    if (k + 1 < MT * NT) {
+                    if (k + 2 < MT * NT) {
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) rv[(k + 1) & 1][g] = nt_load4(rbase + tile_offs((k + 1) / NT, (k + 1) % NT, g));
+                        for (int g = 0; g < 4; ++g) rv[(k + 2) % 3][g] = nt_load4(rbase + tile_offs((k + 2) / NT, (k + 2) % NT, g));
                     }
                 }
                 float e[16];
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
                     oct_transpose(e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3], bit3);
                     float4 v = make_float4(e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3]);
                     if constexpr (RES) {
-                        const float rsc = p.res_scale; const float4 r4 = rv[k & 1][g];
+                        const float rsc = p.res_scale; const float4 r4 = rv[k % 3][g];
                         v.x = fmaf(r4.x, rsc, v.x); v.y = fmaf(r4.y, rsc, v.y); v.z = fmaf(r4.z, rsc, v.z); v.w = fmaf(r4.w, rsc, v.w);
                     }
                     *reinterpret_cast<float4*>(obase + tile_offs(mt, nt, g)) = v;

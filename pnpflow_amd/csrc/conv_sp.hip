@@ -308,6 +308,16 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) fb[set][nt][1] = *reinterpret_cast<const f16x8*>(smem + wb + (unsigned)(NT * 1024 + nt * 1024));
     };
+    // fragment number idx (0 .. 2 MT + 2 NT - 1, in load_tap's order) of a tap, alone: the refill taps request the next tap's fragments one per MFMA
+    // shadow (as one burst in front of their individually fenced MFMAs the twelve reads cost ~150 cycles per refill tap)
+    auto load_frag = [&](int set, int tap, unsigned pofs, int idx) __attribute__((always_inline)) {
+        const int ky = tap / 3, kx = tap % 3;
+        const unsigned wb = (unsigned)(tap < 5 ? tap * TAPB : XB + (tap - 5) * TAPB) + b_lane;
+        if (idx < MT) fa[set][idx][1] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][1] + (unsigned)((idx * 2 + ky) * SP_PITCH * 64) + pofs);
+        else if (idx < MT + NT) fb[set][idx - MT][0] = *reinterpret_cast<const f16x8*>(smem + wb + (unsigned)((idx - MT) * 1024));
+        else if (idx < 2 * MT + NT) fa[set][idx - MT - NT][0] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][0] + (unsigned)(((idx - MT - NT) * 2 + ky) * SP_PITCH * 64) + pofs);
+        else fb[set][idx - 2 * MT - NT][1] = *reinterpret_cast<const f16x8*>(smem + wb + (unsigned)(NT * 1024 + (idx - 2 * MT - NT) * 1024));
+    };
     // group g of a tap's 3 MT groups of NT MFMAs: term g / MT (a_lo w_hi, a_hi w_lo, a_hi w_hi), M-tile g % MT - an accumulator recurs every
     // MT NT MFMAs
     auto mma_group = [&](int set, int g) __attribute__((always_inline)) {
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
     // (the instruction offset 0 / 1024 / 2048 / 3072 moves the global AND the LDS address), so a piece is one instruction plus a scalar
     // bump every fourth - the first version (M0 saved / set / restored and a 64-bit base add per piece) cost ~30 cycles per piece beyond
     // the MFMA it sat behind
-    auto mma_tap_refill = [&](int set, const __attribute__((address_space(1))) char* src, int t0, int nrounds) __attribute__((always_inline)) {
+    auto mma_tap_refill = [&](int set, const __attribute__((address_space(1))) char* src, int t0, int nrounds, int nset, int ntap, unsigned npofs) __attribute__((always_inline)) {
         const unsigned dst0 = (unsigned)(t0 < 5 ? t0 * TAPB : XB + (t0 - 5) * TAPB) + (unsigned)(wq * nrounds * 1024);
         const __attribute__((address_space(1))) char* sb = src + t0 * TAPB + wq * nrounds * 1024;
         unsigned keep;
@@ -362,6 +372,7 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
                     if ((j & 3) == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" :: "v"(b_lane), "s"(sb + (j - 2) * 1024) : "memory");
                     if ((j & 3) == 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(b_lane), "s"(sb + (j - 3) * 1024) : "memory");
                 }
+                if (j < 2 * (MT + NT)) load_frag(nset, ntap, npofs, j);      // fragment j of the tap behind this one
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -419,9 +430,7 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         SP_STAMP(5);
-        load_tap((5 + SI) & 1, 5, PCUR);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_tap_refill((4 + SI) & 1, wnext, 0, 5 * TAPB / 4096);
+        mma_tap_refill((4 + SI) & 1, wnext, 0, 5 * TAPB / 4096, (5 + SI) & 1, 5, PCUR);
         SP_STAMP(6);
         // ---- taps 5, 6: staging of float4 4, 5; tap 6 also fetches the descriptor of the chunk three ahead; tap 7 its coefficients -----------
 #pragma unroll
@@ -456,9 +465,7 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         SP_STAMP(10);
-        load_tap((9 + SI) & 1, 0, PNXT);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_tap_refill((8 + SI) & 1, wnext, 5, 4 * TAPB / 4096);
+        mma_tap_refill((8 + SI) & 1, wnext, 5, 4 * TAPB / 4096, (9 + SI) & 1, 0, PNXT);
         SP_STAMP(11);
         SP_STAMP(12);
         ++stamp_n;

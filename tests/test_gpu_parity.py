@@ -1720,6 +1720,58 @@ def test_conv_sp_takes_the_64_and_128_channel_levels_and_is_fp32_equivalent(hip,
     assert all(int(r["stride"]) == 1 and int(r["up"]) == 0 and int(r["H"]) == (64 if int(r["Cout"]) == 128 else 128) for r in sp)
 
 
+def _run_probe(name, args):
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(repo, "tools", "ubench", name)
+    if not os.path.isfile(exe):
+        pytest.skip(f"{exe} not built (__graft_entry__.build() compiles it best-effort)")
+    r = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 80, 8, 0, 128), (64, 64, 81, 8, 1, 128), (64, 64, 40, 16, 0, 128), (128, 128, 40, 4, 0, 64), (128, 128, 41, 4, 1, 64), (128, 128, 24, 12, 0, 64)])
+def test_conv_sp_kernel_matches_its_reference_kernel(hip, shape):
+    """conv_sp_kernel ALONE (the production source compiled into tools/ubench/conv_sp_probe) against a reference kernel of the same arithmetic -
+    GroupNorm + SiLU + operand scale, fp16 hi / lo split, a_lo w_hi + a_hi w_lo + a_hi w_hi summed in fp32 - on every 7th pixel of the launch
+    (every position of a tile, borders included): both instantiation pairs (128 channels: 16 x 16-pixel tiles, 64 channels: 32 x 16), with and
+    without the identity residual, 4 ... 16 chunks, ragged tile ranges.  The probe prints PARITY OK when max|kernel - reference| <= 2e-5 of max|reference|."""
+    H, W, B, nch, res, cout = shape
+    out = _run_probe("conv_sp_probe", (H, W, B, nch, res, 8, 0, cout))
+    assert "PARITY OK" in out, out[-1500:]
+
+
+@pytest.mark.parametrize("shape", [(100, 52, 40, 3), (28, 28, 96, 1), (64, 64, 8, 3)])
+def test_edge_conv_mfma_kernels_match_the_valu_kernels(hip, shape):
+    """begin_conv2_kernel / end_conv2_kernel ALONE against the round-1 VALU kernels on random tensors (tools/ubench/edge_probe), at sizes whose
+    16 x 16-pixel tiles are ragged in both directions, one and three image channels: outputs within 2e-6 of max (the probe prints OK / FAIL)."""
+    out = _run_probe("edge_probe", shape)
+    lines = [l for l in out.splitlines() if l.startswith(("begin_conv ", "end_conv: max"))]
+    assert len(lines) == 2 and all(l.rstrip().endswith("OK") for l in lines), out[-1500:]
+
+
+def test_edge_convs_on_the_matrix_pipe_agree_with_the_valu_kernels_at_ragged_sizes(hip):
+    """Round 5: begin_conv / end_conv (models.py:358, 428-433, 451, 492) run as split-fp16 MFMA tiles (begin_conv2_kernel - selected from one 16 x 16-pixel
+    tile per CU on - and end_conv2_kernel - always in the default mode) instead of one-pixel-per-thread VALU kernels.  At MNIST's 28 x 28 (tiles ragged in
+    both directions, one input channel) a batch of 96 images takes begin_conv2 (384 tiles), a batch of 8 the VALU kernel (32 tiles); precision mode 0 takes
+    the VALU form of BOTH edge convs and the exact-fp32 conv kernel in between.  Images are independent units: the three forwards must agree on the
+    shared images - to fp32 rounding between the batch sizes, to the split-fp16 tolerance against mode 0."""
+    m, cfg, sd = model_for("mnist")
+    x = det_normal((96, 1, 28, 28), 11).cuda(); t = torch.linspace(0.05, 0.95, 96).cuda()
+    try:
+        big = m(x, t).float().cpu()
+        small = m(x[:8].contiguous(), t[:8].contiguous()).float().cpu()
+        m.set_precision(0)
+        exact = m(x[:8].contiguous(), t[:8].contiguous()).float().cpu()
+    finally:
+        m.set_precision(1)
+    ref = float(exact.abs().max())
+    assert torch.isfinite(big).all() and ref > 0
+    assert float((big[:8] - small).abs().max()) <= 2e-6 * ref, float((big[:8] - small).abs().max()) / ref
+    assert float((small - exact).abs().max()) <= 5e-5 * ref, float((small - exact).abs().max()) / ref
+
+
 # ---------------------------------------------------------------------------------------------
 # third-party pins (tools/pin_thirdparty.py; VERDICT r3 item 6): run when the fixtures exist, otherwise skipped as "parity unpinned"
 # ---------------------------------------------------------------------------------------------

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
     float addv[NT]; float oscale = 0.f;
     auto tile_inputs = [&](const PPTile& tl) __attribute__((always_inline)) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) addv[nt] = p.addvec != nullptr ? p.addvec[(size_t)tl.b * p.addvec_bs + nt * 32 + ch_of_col] : 0.f;
+        for (int nt = 0; nt < NT; ++nt) addv[nt] = p.addvec[(size_t)tl.b * p.addvec_bs + nt * 32 + ch_of_col];      // (conv_sp_supported: never null - the NT loads are counted in chunk 0's vmcnt)
         const float inv_last = scale_c[8 * tl.b + 4 + seg_id[3]];
         oscale = p.out_scale * (1.0f / 256.0f) * inv_last;
         asm volatile("" : "+v"(oscale));      // (consumed HERE: no scalar load may stay in flight into the chunk loop)
@@ -551,8 +551,14 @@ bool conv_sp_supported(const ConvParams& p, int stride, int up, int terms) {
     if (mode == 0 || terms != 3 || stride != 1 || up != 0 || p.gnb_x != nullptr) return false;
     if (p.Cout != 128 && !(p.Cout == 64 && mode == 1)) return false;
     if (p.out_cstride != p.Cout || (p.residual != nullptr && p.res_cstride != p.Cout)) return false;
+    // the hand-counted vmcnt in front of the first barrier of a tile's chunk 0 counts the NT bias loads of tile_inputs: a launch without a
+    // bias vector would wait NT operations too loosely - such launches stay on conv_mfma16
+    if (p.addvec == nullptr) return false;
     const int TH = p.Cout == 128 ? sp_rows(2) : sp_rows(4);      // 16 x 16-pixel workgroup tiles at 128 channels, 32 x 16 at 64
-    if (p.H % TH || p.W % 16 || p.Hs != p.H || p.Ws != p.W || p.W > 2048) return false;
+    if (p.H % TH || p.W % 16 || p.Hs != p.H || p.Ws != p.W) return false;
+    // the staging packs the patch-pixel offset py * W + px (py <= TH + 1, px <= 17) into 16 bits (pk[], issue_one): ADVICE r5 - the bound
+    // depends on the tile height, W <= 1024 at Cout 64 / W <= 2048 at Cout 128
+    if ((TH + 1) * p.W + SP_PW - 1 > 65535) return false;
     if (ilog2_exact_sp(p.H / TH) < 0 || ilog2_exact_sp(p.W / 16) < 0) return false;
     // the persistent grid pays its prologue and pipeline fill over >= 4 tiles per workgroup
     const int grid = persistent_grid();

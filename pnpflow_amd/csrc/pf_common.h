@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 namespace pf {
 
@@ -21,13 +22,13 @@ inline hipError_t set_max_dynamic_lds_once(const void* kernel, unsigned long lon
 // Compute units of the current device, queried once per device (the persistent kernels size their grids and their launch thresholds
 // by it; 0 when the query fails - the persistent kernels are then refused)
 inline int device_cu_count() {
-    static int cache[64] = {};
+    static std::atomic<int> cache[64] = {};      // (relaxed: every writer stores the same value for a device)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (dev >= 0 && dev < 64 && cache[dev] > 0) return cache[dev];
+    if (dev >= 0 && dev < 64) { const int c = cache[dev].load(std::memory_order_relaxed); if (c > 0) return c; }
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 0) v = 0;
-    if (dev >= 0 && dev < 64) cache[dev] = v;
+    if (dev >= 0 && dev < 64) cache[dev].store(v, std::memory_order_relaxed);
     return v;
 }
 // workgroups of a persistent launch: one per CU, a multiple of the 8 XCDs (the kernels map blockIdx & 7 to the XCD)

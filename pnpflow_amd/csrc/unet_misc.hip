@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void begin_conv_kernel(const EdgeConvParams p)
 // ------------------------------------------------------------------------------------
 // begin_conv, round 5 (forward, C = 32, Cimg = 1 or 3): the Cimg x 9 -> 32 contraction per pixel on the matrix pipe, as end_conv2_kernel
 // below - 32 pixels x K = 32 (27 used: input channel x tap) x 32 channels is one split-fp16 32 x 32 x 32 MFMA tile (image x 2^3, weights
-// x 2^8: fp32-equivalent for |x| < 8 188).  The round-1 kernel above spends 864 scalar-operand FMAs per pixel and runs at 0.25 of the
+// x 2^8; patches that reach beyond 2^12 are scaled down by their own exponent: fp32-equivalent over the fp32 range).  The round-1 kernel above spends 864 scalar-operand FMAs per pixel and runs at 0.25 of the
 // write bandwidth (620 us for 1.34 GB; a lane-per-channel-quad v_pk_fma_f32 form measured 669 us - tools/ubench/edge_probe.hip); here a
 // lane (pixel p = lane & 31, half h = lane >> 5) gathers its 16 im2col values from the LDS image patch, splits them, and the 16 results of
 // its channel go through an LDS tile from which the workgroup writes whole 128-byte NHWC pixel rows.  Persistent: a workgroup walks a
@@ -92,12 +92,18 @@ __global__ __launch_bounds__(256) void begin_conv2_kernel(const EdgeConvParams p
     constexpr int C = 32, PW = 18, NIMG = CIMG * PW * PW, K27 = 9 * CIMG, OP = 36, NLD = (NIMG + 255) / 256;
     __shared__ float s_img[NIMG + 4];      // [ci][18][18] + a zero slot (the padding of K to 32)
     __shared__ __attribute__((aligned(16))) float s_o[256 * OP];
+    // operand range: the patch is split into fp16 hi / lo after a power-of-two scale.  2^3 for patches below 4 096 (every image:
+    // the values are those of the fixed scale, bit for bit); a patch that reaches further is scaled down by its own exponent, as the other
+    // convs' per-segment operand scales do - |x| up to the fp32 range instead of inf beyond 8 188.  s_amax[tile parity]: bit pattern of
+    // the patch's max |x| (one LDS atomic per wave; the slot of the next tile is cleared between this tile's two barriers).
+    __shared__ unsigned s_amax[2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, pl = lane & 31, h = lane >> 5;
     const int tiles_x = (p.W + 15) / 16, tiles_y = (p.H + 15) / 16, per_img = tiles_x * tiles_y;
     const long total = (long)per_img * p.B;
     const long t0 = total * blockIdx.x / gridDim.x, t1 = total * (blockIdx.x + 1) / gridDim.x;
     if (t0 >= t1) return;
-    if (tid == 0) s_img[NIMG] = 0.f;
+    if (tid == 0) { s_img[NIMG] = 0.f; s_amax[0] = 0u; s_amax[1] = 0u; }
+    __syncthreads();
     // B fragments: [k-step][hi | lo][lane][8 halfs] (engine.hip packs MFMA k of (step s, half h, j) = 16 s + 8 h + j = input channel * 9 + tap)
     const bc_h8* wimg = reinterpret_cast<const bc_h8*>(p.w16);
     const bc_h8 wh0 = wimg[0 * 64 + lane], wl0 = wimg[1 * 64 + lane], wh1 = wimg[2 * 64 + lane], wl1 = wimg[3 * 64 + lane];
@@ -147,11 +153,26 @@ __global__ __launch_bounds__(256) void begin_conv2_kernel(const EdgeConvParams p
         const int b = (int)(t / per_img), r = (int)(t - (long)b * per_img);
         const int ty = r / tiles_x, tx = r - ty * tiles_x;
         const int y0 = ty * 16, x0 = tx * 16;
+        const int par = (int)((t - t0) & 1);
         if (b != cur_b) { flush(); cur_b = b; }
+        {
+            unsigned am = 0u;
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) am = max(am, __float_as_uint(nxt[k]) & 0x7fffffffu);
+            am = max(am, (unsigned)__shfl_xor((int)am, 1)); am = max(am, (unsigned)__shfl_xor((int)am, 2)); am = max(am, (unsigned)__shfl_xor((int)am, 4));
+            am = max(am, (unsigned)__shfl_xor((int)am, 8)); am = max(am, (unsigned)__shfl_xor((int)am, 16)); am = max(am, (unsigned)__shfl_xor((int)am, 32));
+            if (lane == 0) atomicMax(&s_amax[par], am);
+        }
         __syncthreads();      // (the previous tile's patch and output tile have been read)
 #pragma unroll
         for (int k = 0; k < NLD; ++k) if (tid + 256 * k < NIMG) s_img[tid + 256 * k] = nxt[k];
+        if (tid == 0) s_amax[par ^ 1] = 0u;
         __syncthreads();
+        // scale 2^3 while the patch stays below 2^12, else 2^(15 - e) / 2^... so that max |x| * scale < 2^15 (e = the biased exponent's excess)
+        const int ex = (int)(s_amax[par] >> 23) - 127;                    // floor(log2(max |x|)) (255 - 127 for inf / NaN: the result is non-finite either way)
+        const int sh = ex >= 12 ? ex - 11 : 0;                             // halvings of the fixed scale
+        const float sc_in = __uint_as_float((unsigned)(127 + 3 - min(sh, 120)) << 23);
+        const float sc_out = __uint_as_float((unsigned)(127 - 11 + min(sh, 120)) << 23);      // 1 / (2^8 * sc_in)
         if (t + 1 < t1) fetch(t + 1);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
@@ -159,7 +180,7 @@ __global__ __launch_bounds__(256) void begin_conv2_kernel(const EdgeConvParams p
             const int base = (2 * mt + (pl >> 4)) * PW + (pl & 15);
             float a[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) a[i] = s_img[offk[i] < 0 ? NIMG : base + offk[i]] * 8.0f;
+            for (int i = 0; i < 16; ++i) a[i] = s_img[offk[i] < 0 ? NIMG : base + offk[i]] * sc_in;
             bc_h8 ah0, al0, ah1, al1;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -177,7 +198,7 @@ __global__ __launch_bounds__(256) void begin_conv2_kernel(const EdgeConvParams p
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, wh1, acc, 0, 0, 0);
             // D: register i of lane (column = channel pl, half h) is pixel row 8 (i / 4) + 4 h + (i % 4) of the M-tile
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s_o[(mt * 32 + 8 * (i >> 2) + 4 * h + (i & 3)) * OP + pl] = acc[i] * (1.0f / 2048.0f) + bias_n;
+            for (int i = 0; i < 16; ++i) s_o[(mt * 32 + 8 * (i >> 2) + 4 * h + (i & 3)) * OP + pl] = acc[i] * sc_out + bias_n;
         }
         __syncthreads();
         float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
@@ -201,8 +222,9 @@ __global__ __launch_bounds__(256) void begin_conv2_kernel(const EdgeConvParams p
 hipError_t launch_begin_conv(const EdgeConvParams& p, hipStream_t s) {
     if (p.C != 32 || p.Cimg > 3) return hipErrorInvalidValue;
     const long tiles = (long)p.B * ((p.H + 15) / 16) * ((p.W + 15) / 16);
-    if (p.w16 != nullptr && (p.Cimg == 1 || p.Cimg == 3) && tiles >= device_cu_count()) {      // (below one tile per CU the one-pixel-per-thread kernel is the faster one: 13 vs 24 us at 3 x 100 x 52)
-        const long want = 3L * device_cu_count();
+    const int cus = device_cu_count();      // (0 when the attribute query fails: the one-pixel-per-thread kernel then - ADVICE r5)
+    if (cus > 0 && p.w16 != nullptr && (p.Cimg == 1 || p.Cimg == 3) && tiles >= cus) {      // (below one tile per CU the one-pixel-per-thread kernel is the faster one: 13 vs 24 us at 3 x 100 x 52)
+        const long want = 3L * cus;
         const int grid = (int)(tiles < want ? tiles : want);
         if (p.Cimg == 3) hipLaunchKernelGGL(begin_conv2_kernel<3>, dim3(grid), dim3(256), 0, s, p);
         else hipLaunchKernelGGL(begin_conv2_kernel<1>, dim3(grid), dim3(256), 0, s, p);

@@ -32,6 +32,7 @@ class OT_ODE(object):
         self.last_callback_seconds = 0.0
         self.init_noise = None          # optional override of the randn_like in `initialization` (parity runs)
         self.measurement_noise = None   # optional override of the torch.manual_seed(batch) draw
+        self.measurement_noise_source = getattr(args, "measurement_noise", "cpu")      # "cpu" | "device" (the reference's: ot_ode.py:44-45), see PNP_FLOW
         self.last_restored = None
 
     def model_forward(self, x, t):
@@ -208,14 +209,17 @@ class OT_ODE(object):
             if self.measurement_noise is not None:
                 noise = self.measurement_noise(batch, noisy_img)
             else:
-                torch.manual_seed(batch)                                   # ot_ode.py:44-45 (CPU generator: same on every rank)
-                noise = torch.randn(gshape, dtype=torch.float32)[lo:hi].to(self.device)
+                noise = utils.draw_measurement_noise(batch, gshape, lo, hi, self.device, self.measurement_noise_source)      # ot_ode.py:44-45
             noisy_img = noisy_img + noise * sigma_noise
             clean_img = clean_img.to('cpu')
-            if world > 1 and self.init_noise is None:
+            if (world > 1 or self.measurement_noise_source == "device") and self.init_noise is None:
                 # `initialization` draws randn_like(H_adj(y)) right after the measurement noise (ot_ode.py:27-28, 50-52): global draw, sliced
+                # (on the generator the measurement noise came from)
                 full = (G,) + tuple(clean_img.shape[1:])
-                init = torch.randn(full, dtype=torch.float32)[lo:hi].to(self.device)
+                if self.measurement_noise_source == "device":
+                    init = torch.randn(full, dtype=torch.float32, device=self.device)[lo:hi].contiguous()
+                else:
+                    init = torch.randn(full, dtype=torch.float32)[lo:hi].to(self.device)
             else:
                 init = None
             if self.args.compute_time:

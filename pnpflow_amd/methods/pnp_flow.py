@@ -36,6 +36,10 @@ class PNP_FLOW(object):
         self.batch_samples = True  # the num_samples evaluations of an iteration run as one pass over num_samples*B images
         self.last_restored = None  # the final x of the last batch (the reference only writes it to disk)
         self.measurement_noise = None   # optional override of the torch.manual_seed(batch) draw (multi-GPU shards)
+        # where the torch.manual_seed(batch) measurement noise is drawn: "cpu" (default: the same values on any device and on every
+        # rank) or "device" - the reference's own behaviour (pnp_flow.py:79-80: torch.randn_like of a device tensor), drawn for the
+        # GLOBAL batch on this rank's device generator and sliced, so that shards still reproduce the single-device run
+        self.measurement_noise_source = getattr(args, "measurement_noise", "cpu")
         self.image_offset = 0      # multi-GPU shard: index of this shard's first image in the global batch (parallel.shard_range);
                                    # the shard then draws its slice of the global batch's interpolation noise (pf_pnp_params.elem_offset)
         self._interp_calls = 0
@@ -197,8 +201,7 @@ class PNP_FLOW(object):
                 # the reference draws on the device generator after torch.manual_seed(batch)
                 # (pnp_flow.py:79-80); here the draw is made on the CPU generator so that it is
                 # reproducible on any device (and identical on every rank), then sliced and moved.
-                torch.manual_seed(batch)
-                noise = torch.randn(gshape, dtype=torch.float32)[lo:hi].to(self.device)
+                noise = utils.draw_measurement_noise(batch, gshape, lo, hi, self.device, self.measurement_noise_source)
             noisy_img = noisy_img + noise * sigma_noise
             clean_img = clean_img.to('cpu')
 

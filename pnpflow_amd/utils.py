@@ -120,6 +120,19 @@ def load_model(name_model, model, state, download=False, checkpoint_path=None, d
 
 
 # ---- metric (reference pnpflow/utils.py:560-577, 594-674) ------------------------------------
+def draw_measurement_noise(batch, gshape, lo, hi, device, source="cpu"):
+    """The `torch.manual_seed(batch); torch.randn_like(noisy_img)` draw of pnp_flow.py:79-80 / ot_ode.py:44-45 for images [lo, hi) of a
+    global batch of shape `gshape`.  source "cpu" (default): the CPU generator - the same values on any device and on every rank.
+    source "device": the reference's own behaviour - the draw is made on `device`'s generator (for the whole global batch, then
+    sliced: a shard reproduces the single-device run), so a seed-fixed run equals a run of the reference on the same device type."""
+    torch.manual_seed(batch)
+    if source == "device":
+        return torch.randn(gshape, dtype=torch.float32, device=device)[lo:hi].contiguous()
+    if source != "cpu":
+        raise ValueError(f"measurement_noise must be 'cpu' or 'device', not {source!r}")
+    return torch.randn(gshape, dtype=torch.float32)[lo:hi].to(device)
+
+
 def postprocess(img, args=None):
     return (img + 1) / 2
 

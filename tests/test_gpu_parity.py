@@ -717,6 +717,103 @@ def test_unet_256_forward_at_c4_batch(hip):
     np.testing.assert_allclose(full[:1].cpu().numpy(), ref.numpy(), atol=FWD_ATOL)
 
 
+def test_device_measurement_noise_is_the_references_draw(hip):
+    """`measurement_noise: device` (pnp_flow.py:79-80, ot_ode.py:44-45): torch.manual_seed(batch) + randn_like of a DEVICE tensor, global
+    draw then slice; the solver picks the option up from args and `solve_ip` feeds it to the engine."""
+    from pnpflow_amd.utils import draw_measurement_noise
+    gshape = (4, 3, 16, 16)
+    torch.manual_seed(3)
+    ref = torch.randn_like(torch.empty(gshape, device="cuda"))
+    assert torch.equal(draw_measurement_noise(3, gshape, 0, 4, torch.device("cuda"), "device"), ref)
+    assert torch.equal(draw_measurement_noise(3, gshape, 1, 3, torch.device("cuda"), "device"), ref[1:3])
+    torch.manual_seed(3)
+    cpu = torch.randn(gshape)
+    assert torch.equal(draw_measurement_noise(3, gshape, 0, 4, torch.device("cuda"), "cpu").cpu(), cpu)
+    m, cfg, sd = model_for("tiny4")
+    s1, a1 = _pnp_solver(m, "inpainting", 2, 1, 0.5, 1, 1, 3, 64)
+    assert s1.measurement_noise_source == "cpu"
+    from pnpflow_amd.methods.pnp_flow import PNP_FLOW
+    a1.measurement_noise = "device"
+    assert PNP_FLOW(m, torch.device("cuda"), a1).measurement_noise_source == "device"
+
+
+def test_unet_256_forward_distinct_images_at_the_bench_batch(hip):
+    """the ONE shape bench.py times - 160 x 3 x 256^2 (5 samples x 32 images), where conv_pp's / conv_sp's tile
+    ranges, rotated starts and 32-bit pixel x cstride offsets are largest - with 160 DIFFERENT images and times: samples {0, 79, 159}
+    against the oracle (a kernel that read sample b''s GroupNorm coefficients, tile or residual for sample b fails here; the replicated-
+    image production goldens cannot see that) and against their own B = 1 forwards (which run on conv_mfma16: other kernels, same values)."""
+    m, cfg, sd = model_for("afhq256")
+    B = 160
+    x = det_normal((B, 3, 256, 256), 71).cuda()
+    x = x * torch.linspace(0.25, 1.5, B, device="cuda").view(B, 1, 1, 1)      # per-sample statistics differ by more than rounding
+    t = torch.linspace(0, 0.99, B).cuda()
+    full = m(x, t)
+    assert torch.isfinite(full).all()
+    for i in (0, 79, B - 1):
+        one = m(x[i:i + 1].contiguous(), t[i:i + 1].contiguous())
+        np.testing.assert_allclose(one.cpu().numpy(), full[i:i + 1].cpu().numpy(), atol=1e-5, err_msg=f"sample {i} vs its B = 1 forward")
+        with torch.no_grad():
+            ref = O.unet_forward(sd, cfg, x[i:i + 1].cpu(), t[i:i + 1].cpu())
+        np.testing.assert_allclose(full[i:i + 1].cpu().numpy(), ref.numpy(), atol=FWD_ATOL, err_msg=f"sample {i} vs oracle")
+    # no two samples may coincide (a mis-routed tile would copy one): every sample differs from its neighbour
+    d = (full[1:] - full[:-1]).abs().amax(dim=(1, 2, 3))
+    assert float(d.min()) > 1e-3
+
+
+def test_pnp_flow_two_outer_iterations_distinct_images_at_the_headline_batch(hip, tmp_path):
+    """VERDICT r5 item 4, second half (pnp_flow.py:103-121): two outer iterations of the headline workload (256^2, BoxInpainting(40),
+    sigma 0.05, alpha 0.5, 100 x 5 schedule) at B = 32 with 32 DIFFERENT images, measurements and injected noise draws, through the
+    engine's one-graph-per-iteration path; images {0, 17, 31} against the oracle's loop on those images alone (images are independent
+    units: GroupNorm, the mask operator and the averaging are per image)."""
+    import pnpflow_amd.degradations as D
+    m, cfg, sd = model_for("afhq256")
+    S, Cc, B, steps, ns, sigma, alpha = 256, 3, 32, 100, 5, 0.05, 0.5
+    nit = 2
+    clean = torch.cat([det_image((1, Cc, S, S), 300 + b) for b in range(B)])
+    meas = det_normal((B, Cc, S, S), 43)
+    y = O.make_measurement(clean, O.BoxInpainting(40), sigma, 0, noise=meas)
+    noise = torch.stack([det_normal((B, Cc, S, S), 44, 1 + i) for i in range(nit * ns)])
+    try:
+        solver, args = _pnp_solver(m, "inpainting", steps, ns, alpha, 1, 1, Cc, S)
+        solver.noise = noise.cuda()
+        args.sigma_noise = sigma
+        its = {}
+
+        class _Stop(Exception):
+            pass
+
+        def cb(it, xx):
+            its[it] = xx.clone().cpu()
+            if it >= nit - 1:
+                raise _Stop()
+        try:
+            solver.restore_batch(y.cuda(), D.BoxInpainting(40), sigma, lr=sigma ** 2 * 1.0, iter_cb=cb, cb_iterations=list(range(nit)))
+        except _Stop:
+            pass
+        torch.cuda.synchronize()
+        solver.noise = None
+        paths = _profile_paths(m, B * ns, S, tmp_path, "layers_distinct.csv")
+        assert paths[2] >= 26 and paths[5] >= 23, paths          # the persistent kernels carry this batch
+    finally:
+        m.set_precision(1)
+    sel = [0, 17, 31]
+    ref = {}
+
+    def rec(it, xx):
+        ref[it] = xx.clone()
+        if it >= nit - 1:
+            raise _Stop()
+    try:
+        O.pnp_flow_restore(lambda a, tt: O.unet_forward(sd, cfg, a, tt), O.BoxInpainting(40), y[sel], sigma, steps=steps, num_samples=ns,
+                           alpha=alpha, noise_fn=lambda it, s, like: noise[it * ns + s][sel], record=rec)
+    except _Stop:
+        pass
+    for it in range(nit):
+        np.testing.assert_allclose(its[it][sel].numpy(), ref[it].numpy(), atol=TRAJ_ATOL, err_msg=f"outer iteration {it}")
+    # distinct images stay distinct
+    assert float((its[nit - 1][1:] - its[nit - 1][:-1]).abs().amax(dim=(1, 2, 3)).min()) > 1e-3
+
+
 def test_unet_256_retain_backward_at_c5_batch(hip):
     """C5 runs forward_retain + backward on 32 images of 256^2: batch independence of v and J^T vec at that batch (the kernels
     selected for B=32 vs B=1 differ), sample 5 against the oracle's autograd, and linearity of J^T at B=32."""
@@ -941,6 +1038,27 @@ def test_forward_range_guard(hip, case):
         out = m(x.cuda(), t.cuda())
         m.check_numerics()
         np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-4 * scale, err_msg=f"{case} precision {prec}")
+
+
+@pytest.mark.parametrize("mag", [1.0, 3.0e4, 1.0e9])
+def test_image_boundary_conv_operand_range(hip, mag):
+    """the matrix-pipe begin_conv (begin_conv2_kernel, taken from one 16 x 16 tile per CU on: here 16 x 16 tiles = 512) scaled its
+    input by a fixed 2^3 before the fp16 split, so |x| >= 8 188 became inf - only at large batch.  It now scales a patch that reaches
+    beyond 2^12 by its own exponent (models.py:358, 451: a plain fp32 conv in the reference).  One image of the batch carries the large
+    magnitude, the others stay O(1) (the scale is per patch, not per launch); sample 0 (large) and sample 5 (ordinary) against the oracle,
+    relative to each sample's own output magnitude."""
+    m, cfg, sd = model_for("tiny4")
+    B = 32
+    x = det_normal((B, 3, 64, 64), 99)
+    x[0] *= mag
+    x[7, :, 20:30, 20:30] *= mag                                     # a large region inside an ordinary image
+    t = torch.linspace(0.05, 0.95, B)
+    out = m(x.cuda(), t.cuda())
+    m.check_numerics()
+    for i in (0, 5, 7):
+        with torch.no_grad():
+            ref = O.unet_forward(sd, cfg, x[i:i + 1], t[i:i + 1])
+        np.testing.assert_allclose(out[i:i + 1].cpu().numpy(), ref.numpy(), atol=FWD_ATOL if mag == 1.0 or i == 5 else 2e-4 * float(ref.abs().max()), err_msg=f"sample {i}")      # (2e-4: test_forward_range_guard's bound for a 1e6 stream)
 
 
 def test_overflow_is_loud(hip):

@@ -434,3 +434,20 @@ def test_save_images_writes_the_reference_file_set(tmp_path, B, C):
     utils.save_images(clean, noisy, rec, args, lambda t: t, iter=50)
     names2 = set(os.listdir(tmp_path)) - set(names)
     assert names2 == {"denoising_pnp_flow_batch7_iter50.png"}
+
+
+def test_measurement_noise_sources():
+    """`solver.measurement_noise_source` / `--opts measurement_noise device`: "cpu" is the device-independent default,
+    "device" is the reference's own draw (pnp_flow.py:79-80: torch.manual_seed(batch); torch.randn_like(noisy_img) on the tensor's device) -
+    taken for the GLOBAL batch and sliced, so shards reproduce the single-device run.  On a CPU device both coincide with the reference."""
+    from pnpflow_amd.utils import draw_measurement_noise
+    gshape = (6, 3, 8, 8)
+    torch.manual_seed(4)
+    ref = torch.randn_like(torch.empty(gshape))               # what the reference draws for batch 4 on this device
+    for src in ("cpu", "device"):
+        whole = draw_measurement_noise(4, gshape, 0, 6, torch.device("cpu"), src)
+        assert torch.equal(whole, ref)
+        part = draw_measurement_noise(4, gshape, 2, 5, torch.device("cpu"), src)
+        assert torch.equal(part, ref[2:5])
+    with pytest.raises(ValueError):
+        draw_measurement_noise(0, gshape, 0, 6, torch.device("cpu"), "host")

@@ -295,6 +295,21 @@ def streaming_ceiling(tensor_bytes, passes):
         return STREAM_CEILING_GBS, False, {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
 
+def mfma_ceiling():
+    """The dense f16 MFMA rate THIS BOX delivers NOW under a pure v_mfma_f32_32x32x16_f16 load (tools/ubench/mfma_f16_chain.hip `quick`: one
+    wave per SIMD, four independent accumulator chains, ~0.6 s warm-up + ~1.2 s measured) - the matrix-pipe counterpart of
+    streaming_ceiling.  The clock under a matrix load is power-managed and differs between boxes by a few percent; a class's executed-MFMA
+    rate as a fraction of this number is comparable across boxes.  -> (TFLOP/s, measured_this_run, detail)"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "ubench", "mfma_f16_chain")
+    try:
+        res = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=120)
+        d = json.loads(res.stdout.strip().splitlines()[-1])
+        return float(d["tflops_f16_dense"]), True, d
+    except Exception as exc:          # noqa: BLE001
+        return None, False, {"error": f"{type(exc).__name__}: {exc}"[:200]}
+
+
 def conv_roofline(r, precision, workload, measure_traffic=False):
     """Roofline of the conv family (every 3x3 / 1x1 conv of the U-Net), from HIP-event timing of every conv launch over a profiled
     slice of the SAME workload at the SAME U-Net batch (eager launches; graph replay hides the per-kernel boundaries; a conv_dma
@@ -367,6 +382,17 @@ def conv_roofline(r, precision, workload, measure_traffic=False):
     passes = d["mb"] * 1e6 / d["n"] / tensor_bytes if "Cout 32" in dom else 3.0
     torch.cuda.synchronize()
     ceil_gbs, ceil_measured, ceil_detail = streaming_ceiling(tensor_bytes, passes)
+    mf_tfl, mf_measured, mf_detail = mfma_ceiling() if precision != 0 else (None, False, {"note": "precision mode 0 multiplies on the f32 MFMA"})
+    # every class against what THIS box delivered in THIS run: an HBM-bound class against the streaming probe with its own read / write
+    # mix, a matrix-bound class's EXECUTED MFMA rate against the pure-MFMA probe
+    mix = ceil_detail if ceil_measured else {}
+    for c in cls.values():
+        if c["bound"] == "hbm":
+            pc = c["mb"] * 1e6 / c["n"] / tensor_bytes
+            roof_gbs = float(mix.get({2: "1R+1W", 3: "2R+1W"}.get(int(round(pc)), "3R+1W"), ceil_gbs))
+            c["box_frac"] = c["gbs"] / roof_gbs
+        else:
+            c["box_frac"] = terms * c["tfl"] / mf_tfl if mf_tfl else None
     roof = dict(bound="hbm" if hbm_bound else "mfma",
                 achieved=round(gbs, 1) if hbm_bound else round(tfl, 2), peak=8000.0 if hbm_bound else dtype_peak,
                 unit="GB/s" if hbm_bound else "TFLOP/s", frac=round(gbs / 8000.0, 4) if hbm_bound else round(tfl / dtype_peak, 4),
@@ -378,9 +404,19 @@ def conv_roofline(r, precision, workload, measure_traffic=False):
                 streaming_ceiling={"measured_this_run": ceil_measured, "probe": "tools/ubench/stream_mix quick", "tensor_bytes": tensor_bytes,
                                    "tensor_passes_per_launch": round(passes, 2), "detail": ceil_detail, "guide_float4_copy_gbs": GUIDE_COPY_GBS,
                                    "frac_of_guide_copy": round(gbs / GUIDE_COPY_GBS, 4) if hbm_bound else None},
+                # the matrix pipe of this box in this run (pure v_mfma_f32_32x32x16_f16 load): the counterpart of streaming_ceiling
+                mfma_ceiling={"measured_this_run": mf_measured, "probe": "tools/ubench/mfma_f16_chain quick", "tflops_f16_dense": mf_tfl,
+                              "frac_of_datasheet_2500": round(mf_tfl / 2500.0, 4) if mf_tfl else None, "detail": mf_detail,
+                              "family_executed_frac_of_box_ceiling": round(terms * ach / mf_tfl, 4) if mf_tfl else None},
+                frac_of_box_ceiling=round(d["box_frac"], 4) if d.get("box_frac") is not None else None,
                 classes={k: dict(share=round(v["us"] / tot_us, 4), avg_us=round(v["us"] / v["n"], 1), bound=v["bound"], frac=round(v["frac"], 4),
                                  algorithmic_gbs=round(v["gbs"], 1), algorithmic_tflops=round(v["tfl"], 1),
-                                 executed_mfma_frac=round(terms * v["tfl"] / dtype_peak, 4)) for k, v in sorted(cls.items(), key=lambda kv: -kv[1]["us"])},
+                                 executed_mfma_frac=round(terms * v["tfl"] / dtype_peak, 4),
+                                 # against the ceilings measured on this box in this run (HBM-bound: streaming probe with the class's mix;
+                                 # matrix-bound: executed MFMA rate over the pure-MFMA probe)
+                                 frac_of_box_ceiling=round(v["box_frac"], 4) if v.get("box_frac") is not None else None,
+                                 executed_mfma_frac_of_box_ceiling=round(terms * v["tfl"] / mf_tfl, 4) if mf_tfl else None)
+                         for k, v in sorted(cls.items(), key=lambda kv: -kv[1]["us"])},
                 mfma_family=fam)
     return roof
 
@@ -408,8 +444,13 @@ def pointwise_block(dev, D):
     out = {}
 
     def add(name, secs, nbytes, shape):
+        # working sets below the 256 MiB Infinity Cache are served on-die and the launches are latency-sized (5-15 us): the rate is labelled
+        # cache-resident and NOT quoted as a fraction of the HBM peak; only tensors the cache cannot hold get frac_of_8tbs
+        resident = nbytes < 256 * 2 ** 20
         out[name] = dict(us=round(secs * 1e6, 2), algorithmic_mb=round(nbytes / 1e6, 2), achieved_gbs=round(nbytes / secs / 1e9, 1),
-                         frac_of_8tbs=round(nbytes / secs / 8e12, 4), frac_of_6p3tbs=round(nbytes / secs / 6.3e12, 4), shape=shape)
+                         regime="cache-resident, launch-latency-sized (not an HBM figure)" if resident else "hbm",
+                         frac_of_8tbs=None if resident else round(nbytes / secs / 8e12, 4),
+                         frac_of_6p3tbs=None if resident else round(nbytes / secs / 6.3e12, 4), shape=shape)
 
     cases = [("c2 box mask 32x3x128^2", D.BoxInpainting(20), 32, 128, 1), ("c3 gaussian blur 64x3x128^2", D.GaussianDeblurring(1.0, 61, "fft", 3, 128), 64, 128, 1),
              ("c4 decimation x4 16x3x256^2", D.Superresolution(4, 256), 16, 256, 4), ("c5 random mask 32x3x256^2", D.RandomInpainting(0.7), 32, 256, 1)]

@@ -44,7 +44,8 @@ constexpr int pp_a9(int MT) { return (pp_npix(MT) * 8 + 255) / 256; }           
 #ifdef PP_PROBE_BUILD
 // tools/ubench/conv_pp_probe.hip only: s_memtime stamps of workgroup 0, [team][step][8]
 __device__ unsigned long long* g_pp_dbg = nullptr;
-#define PP_STAMP(k) do { if (stamp_buf != nullptr && blockIdx.x == 0 && t == 0 && stamp_n < 64) stamp_buf[(team * 64 + stamp_n) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+__device__ int g_pp_dbg_skip = 0;      // steps of workgroup 0 that pass before the 64 stamped ones (read once per kernel: a per-stamp read perturbs every phase)
+#define PP_STAMP(k) do { if (stamp_buf != nullptr && blockIdx.x == 0 && t == 0 && stamp_n >= 0 && stamp_n < 64) stamp_buf[(team * 64 + stamp_n) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PP_STAMP(k) do { } while (0)
 #endif
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
     int stamp_n = 0; (void)stamp_n;
 #ifdef PP_PROBE_BUILD
     unsigned long long* const stamp_buf = g_pp_dbg;      // null: no stamps (the probe's plain timing runs)
+    stamp_n = -g_pp_dbg_skip;
 #endif
     // ---- one step = VALU phase + MFMA phase of chunk C of the team's it-th tile (PAR = it & 1) -------------------------------------------
     // register set of step (it, C): the step's global index it * NCH + C, modulo 2

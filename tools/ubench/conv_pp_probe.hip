@@ -4,7 +4,12 @@
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../pnpflow_amd/csrc -o conv_pp_probe conv_pp_probe.hip ; run: ./conv_pp_probe [H W B nch]
 #define PP_PROBE_BUILD 1
 #include "../../pnpflow_amd/csrc/conv_pp.hip"
+#ifndef PP_TEAM_BARRIERS      // builds with docs/experiments/r06_conv_pp_team_barriers.patch applied define it (the patched kernel needs 128 B of LDS for its team counters)
+constexpr int PP_TBAR_BYTES = 0;
+#endif
 #include <cstdio>
+#include <cstring>
+#include <utility>
 #include <vector>
 using namespace pf;
 
@@ -16,7 +21,7 @@ static float run(const PPParams& p0, int H, int W) {
     int lx = 0; while ((16 << lx) < W) ++lx;
     int ly = 0; while ((8 << ly) < H) ++ly;
     p.lx = lx; p.ly = ly; p.rot = getenv("ROT") ? atoi(getenv("ROT")) : 5;
-    const size_t lds = (size_t)N9 * 36864 + TEAMS * pp_patch_bytes(1);
+    const size_t lds = (size_t)N9 * 36864 + TEAMS * pp_patch_bytes(1) + (TEAMS == 2 ? PP_TBAR_BYTES : 0);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(TEAMS == 2 ? 256 : 512), dim3(256 * TEAMS), lds, 0, p);
     (void)hipEventRecord(e0);
@@ -51,6 +56,7 @@ int main(int argc, char** argv) {
                run<1, false, 2>(p, H, W), run<1, false, 1>(p, H, W), (p.residual = res, run<1, true, 2>(p, H, W)), run<1, true, 1>(p, H, W));
         p.residual = getenv("STAMPS") && atoi(getenv("STAMPS")) > 1 ? res : nullptr;
         (void)hipMemcpyToSymbol(HIP_SYMBOL(pf::g_pp_dbg), &dbg, sizeof(dbg));      // stamps on from here
+        { const int skip = getenv("SKIP") ? atoi(getenv("SKIP")) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(pf::g_pp_dbg_skip), &skip, sizeof(skip)); }
         const float us = p.residual ? run<1, true, 2>(p, H, W) : run<1, false, 2>(p, H, W);
         std::vector<unsigned long long> hs(2 * 64 * 8); (void)hipMemcpy(hs.data(), dbg, hs.size() * 8, hipMemcpyDeviceToHost);
         printf("stamped (8-wave workgroup, residual %d): %.1f us.  workgroup 0, cycles per step: - | epilogue | transform | requests | barrier | mfma | barrier\n", p.residual ? 1 : 0, us);
@@ -60,7 +66,29 @@ int main(int argc, char** argv) {
                 printf("team %d step %2d  start %8llu : %6llu | %6llu | %6llu | %6llu | %6llu | %6llu | %6llu\n", tm, sidx, q[0] - hs[(tm * 64 + 8) * 8], q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[6] - q[5], q[7] - q[6]);
             }
     } else {
-        printf("%d x %d x %d x 32, 2 chunks: %7.1f us\n", B, H, W, run<2, false, 2>(p, H, W));
+        // multi-chunk: the 8-wave form (TEAMS = 2, what the library launches) against the one-team form of the same kernel (one 4-wave workgroup per
+        // CU: same arithmetic in the same order, so the outputs must be BIT-equal) - the check of the team barriers (round 6)
+        auto checksum = [&]() {
+            std::vector<float> o(n); (void)hipMemcpy(o.data(), out, n * 4, hipMemcpyDeviceToHost);
+            unsigned long long hsh = 1469598103934665603ull; double sum = 0;
+            for (size_t i = 0; i < n; ++i) { unsigned u; memcpy(&u, &o[i], 4); hsh = (hsh ^ u) * 1099511628211ull; sum += o[i]; }
+            return std::make_pair(hsh, sum);
+        };
+        float us2 = 0, us1 = 0;
+        std::pair<unsigned long long, double> c2, c1;
+        // (the clock manager needs ~40 ms of load to settle: the first launches of a process run 15-20 % slower than the rest)
+        for (int k = 0; k < 6; ++k) { if (nch == 2) run<2, false, 2>(p, H, W); else run<3, false, 2>(p, H, W); }
+        if (nch == 2) {
+            (void)hipMemset(out, 0, n * 4); us2 = run<2, false, 2>(p, H, W); c2 = checksum();
+            (void)hipMemset(out, 0, n * 4); us1 = run<2, false, 1>(p, H, W); c1 = checksum();
+        } else {
+            (void)hipMemset(out, 0, n * 4); us2 = run<3, false, 2>(p, H, W); c2 = checksum();
+            (void)hipMemset(out, 0, n * 4); us1 = run<3, false, 1>(p, H, W); c1 = checksum();
+        }
+        printf("%d x %d x %d x 32, %d chunks: 8-wave form %7.1f us | one 4-wave workgroup per CU %7.1f us | outputs %s (fnv %016llx / %016llx, sum %.6e)\n", B, H, W, nch, us2, us1,
+               c2.first == c1.first ? "BIT-EQUAL" : "DIFFER", c2.first, c1.first, c2.second);
+        // a few more launches of the 8-wave form: timing spread
+        for (int k = 0; k < 4; ++k) printf("  8-wave form again: %7.1f us\n", nch == 2 ? run<2, false, 2>(p, H, W) : run<3, false, 2>(p, H, W));
     }
     return 0;
 }

@@ -377,6 +377,8 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
 #ifdef PP_PROBE_BUILD
     unsigned long long* const stamp_buf = g_pp_dbg;      // null: no stamps (the probe's plain timing runs)
     stamp_n = -g_pp_dbg_skip;
+    // shader-clock ticks of the walk of every 32nd workgroup (slots behind the step stamps): ticks / launch time = the clock the launch ran at
+    if (stamp_buf != nullptr && (blockIdx.x & 31) == 0 && tid == 0) stamp_buf[2 * 64 * 8 + 2 * (blockIdx.x >> 5)] = __builtin_readcyclecounter();
 #endif
     // ---- one step = VALU phase + MFMA phase of chunk C of the team's it-th tile (PAR = it & 1) -------------------------------------------
     // register set of step (it, C): the step's global index it * NCH + C, modulo 2
@@ -436,6 +438,9 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
     if (NRES == 2 && ((niter - 1) & 1)) epilogue(res1, tile_of(niter - 1), live_of(niter - 1));
     else epilogue(res0, tile_of(niter - 1), live_of(niter - 1));
     flush_stats();
+#ifdef PP_PROBE_BUILD
+    if (stamp_buf != nullptr && (blockIdx.x & 31) == 0 && tid == 0) stamp_buf[2 * 64 * 8 + 2 * (blockIdx.x >> 5) + 1] = __builtin_readcyclecounter();
+#endif
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------------

@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < nch; ++i) { p.ch[i] = PPChunk{}; p.ch[i].src = i == 0 ? in : in2; p.ch[i].wimg = wimg; p.ch[i].cstride = 32; p.ch[i].coff = 0; p.ch[i].xform = 2; p.ch[i].gn_c0 = 32 * i; p.ch[i].seg = i; }
     p.n9 = nch; p.n1 = 0; p.B = B; p.H = H; p.W = W; p.out = out; p.addvec = addv; p.addvec_bs = 32;
     p.res_scale = 1.f; p.stats_out = stats; p.out_scale = 1.f; p.coef = coef; p.coef_stride = 1024; p.scale = scale;
-    unsigned long long* dbg; (void)hipMalloc(&dbg, 2 * 64 * 8 * 8); (void)hipMemset(dbg, 0, 2 * 64 * 8 * 8);
+    unsigned long long* dbg; (void)hipMalloc(&dbg, (2 * 64 * 8 + 64) * 8); (void)hipMemset(dbg, 0, (2 * 64 * 8 + 64) * 8);
     p.residual = nullptr;
     if (nch == 1) {
         printf("%d x %d x %d x 32, 1 chunk: one 8-wave workgroup per CU %7.1f us | two 4-wave workgroups per CU %7.1f us | with residual %7.1f / %7.1f us\n", B, H, W,
@@ -58,7 +58,9 @@ int main(int argc, char** argv) {
         (void)hipMemcpyToSymbol(HIP_SYMBOL(pf::g_pp_dbg), &dbg, sizeof(dbg));      // stamps on from here
         { const int skip = getenv("SKIP") ? atoi(getenv("SKIP")) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(pf::g_pp_dbg_skip), &skip, sizeof(skip)); }
         const float us = p.residual ? run<1, true, 2>(p, H, W) : run<1, false, 2>(p, H, W);
-        std::vector<unsigned long long> hs(2 * 64 * 8); (void)hipMemcpy(hs.data(), dbg, hs.size() * 8, hipMemcpyDeviceToHost);
+        std::vector<unsigned long long> hs(2 * 64 * 8 + 64); (void)hipMemcpy(hs.data(), dbg, hs.size() * 8, hipMemcpyDeviceToHost);
+        { double tk = 0; int nw = 0; for (int w = 0; w < 8; ++w) if (hs[2 * 64 * 8 + 2 * w + 1] > hs[2 * 64 * 8 + 2 * w]) { tk += (double)(hs[2 * 64 * 8 + 2 * w + 1] - hs[2 * 64 * 8 + 2 * w]); ++nw; }
+          if (nw) printf("walk of %d sampled workgroups: %.0f shader-clock ticks on average = %.3f GHz over the launch's %.1f us\n", nw, tk / nw, tk / nw / (us * 1e3), us); }
         printf("stamped (8-wave workgroup, residual %d): %.1f us.  workgroup 0, cycles per step: - | epilogue | transform | requests | barrier | mfma | barrier\n", p.residual ? 1 : 0, us);
         for (int tm = 0; tm < 2; ++tm)
             for (int sidx = 8; sidx < 16; ++sidx) {

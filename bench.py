@@ -295,6 +295,58 @@ def streaming_ceiling(tensor_bytes, passes):
         return STREAM_CEILING_GBS, False, {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
 
+class PowerSampler:
+    """Board power and shader clock of THIS rank's GPU during the timed region, read from the amdgpu hwmon files (power1_input in uW,
+    freq1_input in Hz; the card is matched by PCI address) every 100 ms on a host thread - no GPU work, no effect on the timed steps.
+    Round 6 (profiles/r06_power_bound.md): the conv kernels run against the board's power management (1.6-2.1 GHz shader clock against the
+    2.4 GHz of the datasheet peaks); the line carries the evidence.  Best effort: `available: false` when the files are not readable."""
+
+    def __init__(self, dev_index):
+        import glob, threading
+        self.samples, self._stop, self._thread, self.hw, self.cap_w = [], threading.Event(), None, None, None
+        try:
+            prop = torch.cuda.get_device_properties(dev_index)
+            bdf = f"{getattr(prop, 'pci_domain_id', 0):04x}:{prop.pci_bus_id:02x}:{prop.pci_device_id:02x}"
+            for h in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+                if bdf in os.path.realpath(os.path.join(h, "device")) and os.path.isfile(os.path.join(h, "power1_input")):
+                    self.hw = h
+                    break
+            if self.hw:
+                try:
+                    self.cap_w = int(open(os.path.join(self.hw, "power1_cap")).read()) / 1e6
+                except Exception:      # noqa: BLE001
+                    self.cap_w = None
+                self._thread = threading.Thread(target=self._run, daemon=True)
+        except Exception:              # noqa: BLE001
+            self.hw = None
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                pw = int(open(os.path.join(self.hw, "power1_input")).read()) / 1e6
+                fq = int(open(os.path.join(self.hw, "freq1_input")).read()) / 1e9
+                self.samples.append((pw, fq))
+            except Exception:          # noqa: BLE001
+                pass
+            self._stop.wait(0.1)
+
+    def start(self):
+        if self._thread:
+            self._thread.start()
+        return self
+
+    def stop(self):
+        if not self._thread:
+            return {"available": False}
+        self._stop.set(); self._thread.join(timeout=2)
+        if not self.samples:
+            return {"available": False}
+        pw = sorted(s[0] for s in self.samples); fq = sorted(s[1] for s in self.samples)
+        return {"available": True, "source": "amdgpu hwmon power1_input / freq1_input, 100 ms samples over the timed steps", "samples": len(pw),
+                "board_power_w_mean": round(sum(pw) / len(pw), 1), "board_power_w_p95": round(pw[int(0.95 * (len(pw) - 1))], 1), "board_power_cap_w": self.cap_w,
+                "sclk_ghz_mean": round(sum(fq) / len(fq), 3), "sclk_ghz_min": round(fq[0], 3), "sclk_ghz_max": round(fq[-1], 3), "sclk_ghz_datasheet": 2.4}
+
+
 def mfma_ceiling():
     """The dense f16 MFMA rate THIS BOX delivers NOW under a pure v_mfma_f32_32x32x16_f16 load (tools/ubench/mfma_f16_chain.hip `quick`: one
     wave per SIMD, four independent accumulator chains, ~0.6 s warm-up + ~1.2 s measured) - the matrix-pipe counterpart of
@@ -642,12 +694,14 @@ def main():
             torch.cuda.synchronize()
 
     sync()
+    sampler = PowerSampler(local).start() if rank == 0 else None
     t0 = time.perf_counter()
     x = None
     for i in range(a.steps):
         x = r.step(a.warmup + i)
     sync()
     dt = time.perf_counter() - t0
+    power = sampler.stop() if sampler else None
     if dist_on:
         tt = comm(torch.tensor([dt], device=dev, dtype=torch.float64))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -680,6 +734,7 @@ def main():
                        "hipgraph": bool(getattr(r.solver, "use_graph", False)), "unet_batch": r.unet_batch(),
                        "parallelism": f"dp{world} (contiguous shards of the global batch, no data-path collective)"},
             "psnr_db": round(psnr_mean, 4),
+            "power": power,
             "roofline": conv_roofline(r, a.precision, a.workload, measure_traffic=(world == 1 and not a.no_extra)),
         }
         fpi = r.flops_per_image()

@@ -31,6 +31,8 @@ namespace pf {
 
 // MT = M-tiles (2 rows x 16 pixels) per wave: a team's tile is 8 MT rows x 16 columns, its halo patch (8 MT + 2) x 18 pixels x 128 B
 constexpr int PP_PW = 18;
+constexpr int pp_w9(int TERMS) { return TERMS == 3 ? 36864 : 18432; }      // LDS bytes of a 9-tap / 1-tap 32-channel chunk image ([k16-step][hi | lo] or [k16-step][hi])
+constexpr int pp_w1(int TERMS) { return TERMS == 3 ? 4096 : 2048; }
 constexpr int pp_npix(int MT) { return (8 * MT + 2) * PP_PW; }
 constexpr int pp_patch_bytes(int MT) { return pp_npix(MT) * 128; }                         // MT 1: 23 040 B, MT 2: 41 472 B per team
 constexpr int pp_a9(int MT) { return (pp_npix(MT) * 8 + 255) / 256; }                      // float4 per lane of a 9-tap chunk: 6 / 11
@@ -50,12 +52,17 @@ __device__ int g_pp_dbg_skip = 0;      // steps of workgroup 0 that pass before 
 #define PP_STAMP(k) do { } while (0)
 #endif
 
-template <int MT, int N9, int N1, bool RES, int TEAMS = 2>
+// TERMS = 3: the fp32-equivalent split (a_lo w_hi + a_hi w_lo + a_hi w_hi); TERMS = 1 (round 6): precision mode 2 - operands rounded once to fp16 (hi only:
+// the products of conv_mfma16's TERMS = 1 form), one MFMA per k16-step, hi-only weight images in LDS (half the footprint: every chunk structure fits two
+// workgroups per CU) and hi-only patch records.  Under the board's power cap the two dropped MFMAs are the saving.
+template <int MT, int N9, int N1, bool RES, int TEAMS = 2, int TERMS = 3>
 __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams p) {
     constexpr int NCH = N9 + N1;
+    constexpr int W9 = pp_w9(TERMS), W1 = pp_w1(TERMS), WSTEP = TERMS == 3 ? 2048 : 1024;      // LDS bytes of a 9-tap / 1-tap chunk image, of one k16-step
+    static_assert(TERMS == 3 || TERMS == 1, "split terms");
     constexpr int PP_NPIX = pp_npix(MT), PP_PATCH_BYTES = pp_patch_bytes(MT), PP_A9 = pp_a9(MT), TH = 8 * MT;
     constexpr int LASTN = PP_NPIX * 8 - (PP_A9 - 1) * 256;          // threads that own a float4 number PP_A9 - 1
-    constexpr int WBYTES = N9 * 36864 + N1 * 4096;                  // LDS weight images: 9-tap chunks first
+    constexpr int WBYTES = N9 * W9 + N1 * W1;                       // LDS weight images: 9-tap chunks first
     static_assert(NCH >= 1 && NCH <= PP_MAXCH && N9 >= 1, "chunk structure");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -66,7 +73,7 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
     // the per-image operand scales are read through the scalar cache (constant address space): as ordinary global loads hipcc makes them
     // VECTOR loads, and every wait for one drains the patch prefetch (one in-order vmcnt)
     const pp_float_cptr scale_c = (pp_float_cptr)(uintptr_t)p.scale;
-    auto wlds = [](int c) constexpr { return c < N9 ? c * 36864 : N9 * 36864 + (c - N9) * 4096; };
+    auto wlds = [](int c) constexpr { return c < N9 ? c * W9 : N9 * W9 + (c - N9) * W1; };
 
     // ---- weights -> LDS, once per workgroup --------------------------------------------------------------------------------------
 #pragma unroll
@@ -74,7 +81,12 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
         const uint4* src = reinterpret_cast<const uint4*>(p.ch[c].wimg);
         uint4* dst = reinterpret_cast<uint4*>(smem + wlds(c));
         const int n16 = (c < N9 ? 9 : 1) * 256;             // taps * 2 k16-steps * 2 KiB / 16
-        for (int i = tid; i < n16; i += 256 * TEAMS) dst[i] = src[i];
+        if constexpr (TERMS == 3) {
+            for (int i = tid; i < n16; i += 256 * TEAMS) dst[i] = src[i];
+        } else {
+            // hi halves only: the global image is [k16-step][hi 1 KiB | lo 1 KiB]
+            for (int i = tid; i < n16 / 2; i += 256 * TEAMS) dst[i] = src[(i >> 6) * 128 + (i & 63)];
+        }
     }
 
     // ---- per-lane constants of the staging (independent of the tile) -----------------------------------------------------------------
@@ -189,10 +201,16 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
     };
 
     auto split_store = [&](float4 v, unsigned addr) __attribute__((always_inline)) {
-        uint2 h, l;
-        split4_pp(v, h.x, h.y, l.x, l.y);
-        *reinterpret_cast<uint2*>(smem + addr) = h;
-        *reinterpret_cast<uint2*>(smem + (addr ^ 64u)) = l;                       // the lo piece q + 4 sits at slot (q ^ s) ^ 4
+        if constexpr (TERMS == 3) {
+            uint2 h, l;
+            split4_pp(v, h.x, h.y, l.x, l.y);
+            *reinterpret_cast<uint2*>(smem + addr) = h;
+            *reinterpret_cast<uint2*>(smem + (addr ^ 64u)) = l;                       // the lo piece q + 4 sits at slot (q ^ s) ^ 4
+        } else {
+            uint2 h;      // one rounding to fp16 (RNE), as conv_mfma16's TERMS = 1 staging; the record keeps its 128-byte pitch, the lo half stays unwritten and unread
+            asm("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5" : "=&v"(h.x), "=&v"(h.y) : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+            *reinterpret_cast<uint2*>(smem + addr) = h;
+        }
     };
 
     // staging of step (it, C) from set S interleaved with the requests of step + 2 into the same set: every register is re-requested the
@@ -264,22 +282,31 @@ __global__ __launch_bounds__(256 * TEAMS, 2) void conv_pp_kernel(const PPParams 
     // 2.6 k cycles - r4 stamps - and change nothing end to end: the VALU phase and the memory queue are the critical path; not kept, the
     // registers are needed by the two prefetch sets.)
     auto mma_step = [&](unsigned wbase, int s, int ky, int kx, int j) __attribute__((always_inline)) {
-        const f16x8 bh = *reinterpret_cast<const f16x8*>(smem + wbase + (unsigned)((s * 2 + 0) * 1024));
-        const f16x8 bl = *reinterpret_cast<const f16x8*>(smem + wbase + (unsigned)((s * 2 + 1) * 1024));
-        f16x8 ah[MT], al[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const unsigned off = (unsigned)((mt * 2 + ky) * PP_PW * 128);
-            ah[mt] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][j][0] + off);
-            al[mt] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][j][1] + off);
-        }
         const int ai = (s & 1) % NACC;
+        if constexpr (TERMS == 3) {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(smem + wbase + (unsigned)((s * 2 + 0) * 1024));
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(smem + wbase + (unsigned)((s * 2 + 1) * 1024));
+            f16x8 ah[MT], al[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[ai][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[ai][mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) {
+                const unsigned off = (unsigned)((mt * 2 + ky) * PP_PW * 128);
+                ah[mt] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][j][0] + off);
+                al[mt] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][j][1] + off);
+            }
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[ai][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[ai][mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) acc[ai][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[ai][mt], 0, 0, 0);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[ai][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[ai][mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) acc[ai][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[ai][mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[ai][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[ai][mt], 0, 0, 0);
+        } else {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(smem + wbase + (unsigned)(s * WSTEP));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][j][0] + (unsigned)((mt * 2 + ky) * PP_PW * 128));
+                acc[ai][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[ai][mt], 0, 0, 0);
+            }
+        }
     };
 
     auto flush_stats = [&]() __attribute__((always_inline)) {
@@ -459,9 +486,9 @@ static bool pp_structure(int n9, int n1, bool res) {
 }
 
 bool conv_pp_supported(const ConvParams& p, int stride, int up, int terms) {
-    static const int mode = getenv("PNPFLOW_HIP_PP") ? atoi(getenv("PNPFLOW_HIP_PP")) : 1;
+    static const int mode = getenv("PNPFLOW_HIP_PP") ? atoi(getenv("PNPFLOW_HIP_PP")) : 1;      // test-only A/B switch: 0 off, 1 on, 3 on in the default mode only (mode 2 on conv_mfma16)
     constexpr int TH = 8 * PP_MT;
-    if (mode == 0 || terms != 3 || stride != 1 || up != 0 || p.gnb_x != nullptr) return false;
+    if (mode == 0 || (terms != 3 && !(terms == 1 && mode != 3)) || stride != 1 || up != 0 || p.gnb_x != nullptr) return false;
     if (p.Cout != 32 || p.out_cstride != 32 || (p.residual != nullptr && p.res_cstride != 32)) return false;
     if (p.H % TH || p.W % 16 || p.Hs != p.H || p.Ws != p.W) return false;
     if (ilog2_exact(p.H / TH) < 0 || ilog2_exact(p.W / 16) < 0) return false;
@@ -481,42 +508,49 @@ bool conv_pp_supported(const ConvParams& p, int stride, int up, int terms) {
     }
     if (!pp_structure(n9, n1, p.residual != nullptr)) return false;
     if (p.gn_C > 0 && p.coef == nullptr) return false;
-    return (size_t)n9 * 36864 + (size_t)n1 * 4096 + 2 * pp_patch_bytes(PP_MT) <= 160 * 1024;
+    return (size_t)n9 * pp_w9(terms) + (size_t)n1 * pp_w1(terms) + 2 * pp_patch_bytes(PP_MT) <= 160 * 1024;
 }
 
 // TEAMS = 1: two independent 4-wave workgroups per CU (each with its own copy of the weights) where LDS allows - the teams of one
 // 8-wave workgroup wait for each other at every phase boundary, independent workgroups only for their own data (r4: 192 vs 214 us on the
 // one-chunk conv); TEAMS = 2 (one workgroup per CU, weights shared) for the structures whose weights do not fit twice
-template <int N9, int N1, bool RES, int TEAMS>
+template <int N9, int N1, bool RES, int TEAMS, int TERMS>
 static hipError_t launch_pp_tt(const PPParams& p0, hipStream_t s) {
     static unsigned long long attr_set = 0ull;
-    auto kern = conv_pp_kernel<PP_MT, N9, N1, RES, TEAMS>;
+    auto kern = conv_pp_kernel<PP_MT, N9, N1, RES, TEAMS, TERMS>;
     { hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(kern), attr_set, 160 * 1024); if (e != hipSuccess) return e; }
     const int grid = persistent_grid() * (TEAMS == 1 ? 2 : 1);
     if (grid <= 0) return hipErrorInvalidConfiguration;
     PPParams p = p0;
     p.lx = ilog2_exact(p.W / 16); p.ly = ilog2_exact(p.H / (8 * PP_MT));
     p.rot = 5;
-    const size_t lds = (size_t)N9 * 36864 + (size_t)N1 * 4096 + TEAMS * pp_patch_bytes(PP_MT);
+    const size_t lds = (size_t)N9 * pp_w9(TERMS) + (size_t)N1 * pp_w1(TERMS) + TEAMS * pp_patch_bytes(PP_MT);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * TEAMS), lds, s, p);
     return hipGetLastError();
 }
 
-template <int N9, int N1, bool RES>
+template <int N9, int N1, bool RES, int TERMS>
 static hipError_t launch_pp_t(const PPParams& p, hipStream_t s) {
-    constexpr size_t one = (size_t)N9 * 36864 + (size_t)N1 * 4096 + pp_patch_bytes(PP_MT);
-    if constexpr (2 * one <= 160 * 1024) return launch_pp_tt<N9, N1, RES, 1>(p, s);
-    else return launch_pp_tt<N9, N1, RES, 2>(p, s);
+    constexpr size_t one = (size_t)N9 * pp_w9(TERMS) + (size_t)N1 * pp_w1(TERMS) + pp_patch_bytes(PP_MT);
+    if constexpr (2 * one <= 160 * 1024) return launch_pp_tt<N9, N1, RES, 1, TERMS>(p, s);
+    else return launch_pp_tt<N9, N1, RES, 2, TERMS>(p, s);
 }
 
-hipError_t launch_conv_pp(const PPParams& p, hipStream_t s) {
+template <int TERMS>
+static hipError_t launch_conv_pp_terms(const PPParams& p, hipStream_t s) {
     const bool res = p.residual != nullptr;
-    if (p.n9 == 1 && p.n1 == 0) return res ? launch_pp_t<1, 0, true>(p, s) : launch_pp_t<1, 0, false>(p, s);
+    if (p.n9 == 1 && p.n1 == 0) return res ? launch_pp_t<1, 0, true, TERMS>(p, s) : launch_pp_t<1, 0, false, TERMS>(p, s);
     if (res) return hipErrorInvalidValue;
-    if (p.n9 == 2 && p.n1 == 0) return launch_pp_t<2, 0, false>(p, s);
-    if (p.n9 == 3 && p.n1 == 0) return launch_pp_t<3, 0, false>(p, s);
-    if (p.n9 == 1 && p.n1 == 2) return launch_pp_t<1, 2, false>(p, s);
-    if (p.n9 == 1 && p.n1 == 3) return launch_pp_t<1, 3, false>(p, s);
+    if (p.n9 == 2 && p.n1 == 0) return launch_pp_t<2, 0, false, TERMS>(p, s);
+    if (p.n9 == 3 && p.n1 == 0) return launch_pp_t<3, 0, false, TERMS>(p, s);
+    if (p.n9 == 1 && p.n1 == 2) return launch_pp_t<1, 2, false, TERMS>(p, s);
+    if (p.n9 == 1 && p.n1 == 3) return launch_pp_t<1, 3, false, TERMS>(p, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_conv_pp(const PPParams& p, hipStream_t s, int terms) {
+    if (terms == 1) return launch_conv_pp_terms<1>(p, s);
+    if (terms == 3) return launch_conv_pp_terms<3>(p, s);
     return hipErrorInvalidValue;
 }
 

@@ -596,9 +596,11 @@ static bool attach_dma(Builder& bd, ConvParams& p, int stride, int up, std::vect
 // levels: 16-channel K-chunks, weights streamed through LDS slots): the launch becomes a list of K-chunks in the kernel argument
 static int attach_pp(Builder& bd, const ConvParams& p, int stride, int up, PPParams& q) {      // 0: no; 1: conv_pp; 2: conv_sp
     pf_engine* e = bd.e;
-    if (e->precision != 1) return 0;
-    const bool sp = (p.Cout == 128 || p.Cout == 64) && conv_sp_supported(p, stride, up, 3);
-    if (!sp && !(p.Cout == 32 && conv_pp_supported(p, stride, up, 3))) return 0;
+    if (e->precision == 0) return 0;
+    // precision mode 2 (one MFMA per product): conv_pp's hi-only form on the 32-channel level (round 6); conv_sp is default-mode only
+    const int terms = e->precision == 2 ? 1 : 3;
+    const bool sp = terms == 3 && (p.Cout == 128 || p.Cout == 64) && conv_sp_supported(p, stride, up, 3);
+    if (!sp && !(p.Cout == 32 && conv_pp_supported(p, stride, up, terms))) return 0;
     q = PPParams{};
     q.cout = p.Cout;
     const int kc = sp ? 16 : 32;
@@ -1366,7 +1368,7 @@ static int run_backward(pf_engine* e, Plan* plan, const float* vec, float* g, hi
 
 static hipError_t dispatch_conv(pf_engine* e, const Op& op, hipStream_t s) {
     if (op.use_pp == 2 && e->precision == 1) return launch_conv_sp(op.ppp, s);
-    if (op.use_pp && e->precision == 1) return launch_conv_pp(op.ppp, s);
+    if (op.use_pp == 1 && e->precision != 0) return launch_conv_pp(op.ppp, s, e->precision == 2 ? 1 : 3);
     if (op.dma) return launch_conv_dma(op.cp, op.up, s, e->precision == 2 ? 1 : 3);
     if (e->precision != 0) {
         bool ok16 = true;

@@ -179,7 +179,7 @@ struct PPParams {
     const float* coef; int coef_stride; const float* scale;      // ConvParams::coef / ::scale of the launch
 };
 bool conv_pp_supported(const ConvParams& p, int stride, int up, int terms);
-hipError_t launch_conv_pp(const PPParams& p, hipStream_t s);
+hipError_t launch_conv_pp(const PPParams& p, hipStream_t s, int terms = 3);      // terms 1: precision mode 2 (hi-only operands)
 bool conv_sp_supported(const ConvParams& p, int stride, int up, int terms);      // conv_sp.hip: one wave per SIMD, software-pipelined (Cout = 64 / 128)
 hipError_t launch_conv_sp(const PPParams& p, hipStream_t s);
 

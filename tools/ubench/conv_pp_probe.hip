@@ -8,20 +8,21 @@
 constexpr int PP_TBAR_BYTES = 0;
 #endif
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <utility>
 #include <vector>
 using namespace pf;
 
-template <int N9, bool RES, int TEAMS = 2>
+template <int N9, bool RES, int TEAMS = 2, int TERMS = 3>
 static float run(const PPParams& p0, int H, int W) {
-    auto kern = conv_pp_kernel<1, N9, 0, RES, TEAMS>;
+    auto kern = conv_pp_kernel<1, N9, 0, RES, TEAMS, TERMS>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     PPParams p = p0;
     int lx = 0; while ((16 << lx) < W) ++lx;
     int ly = 0; while ((8 << ly) < H) ++ly;
     p.lx = lx; p.ly = ly; p.rot = getenv("ROT") ? atoi(getenv("ROT")) : 5;
-    const size_t lds = (size_t)N9 * 36864 + TEAMS * pp_patch_bytes(1) + (TEAMS == 2 ? PP_TBAR_BYTES : 0);
+    const size_t lds = (size_t)N9 * pp_w9(TERMS) + TEAMS * pp_patch_bytes(1) + (TEAMS == 2 ? PP_TBAR_BYTES : 0);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(TEAMS == 2 ? 256 : 512), dim3(256 * TEAMS), lds, 0, p);
     (void)hipEventRecord(e0);
@@ -31,6 +32,62 @@ static float run(const PPParams& p0, int H, int W) {
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
     if (hipGetLastError() != hipSuccess) printf("launch error\n");
     return ms * 1e3f / reps;
+}
+
+// Reference of the kernel's arithmetic on a sample of output pixels (every `step`-th pixel): the same operands - GroupNorm + SiLU + operand scale,
+// fp16 hi / lo split - and the same products (terms 3: a_lo w_hi + a_hi w_lo + a_hi w_hi; terms 1: a_hi w_hi), summed in fp32 in another order; weights
+// read back from the packed image ([k16-step = tap * 2 + j][hi | lo][k-half][column][8 halfs], MFMA column 8 g + k = output channel 4 k + g).
+__global__ void ref_kernel_pp(PPParams p, int terms, int step, int nsamp, float* ref) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nsamp * 32) return;
+    const int n = idx & 31, sidx = idx >> 5;
+    const long pix = (long)sidx * step;
+    const int x = (int)(pix % p.W), y = (int)((pix / p.W) % p.H), b = (int)(pix / ((long)p.W * p.H));
+    const int col = (n & 3) * 8 + (n >> 2);
+    float acc = 0.f;
+    for (int c = 0; c < p.n9; ++c) {
+        const PPChunk& k = p.ch[c];
+        const float* cb = p.coef + ((size_t)b * 2 * p.coef_stride + k.gn_c0);
+        const float asc = p.scale[8 * b + k.seg];
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            if (yy < 0 || yy >= p.H || xx < 0 || xx >= p.W) continue;
+            const float* src = k.src + ((size_t)(b * p.H + yy) * p.W + xx) * k.cstride + k.coff;
+            for (int kk = 0; kk < 32; ++kk) {
+                float v = src[kk] * cb[kk] + cb[p.coef_stride + kk];
+                v = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+                v *= asc;
+                const _Float16 ah = (_Float16)v, al = (_Float16)(v - (float)ah);
+                const int j = kk >> 4, kh = (kk >> 3) & 1, i = kk & 7;
+                const _Float16* wt = reinterpret_cast<const _Float16*>(reinterpret_cast<const char*>(k.wimg) + (tap * 2 + j) * 2048);
+                const float wh = (float)wt[(kh * 32 + col) * 8 + i], wl = (float)wt[512 + (kh * 32 + col) * 8 + i];
+                acc += terms == 3 ? (float)al * wh + (float)ah * wl + (float)ah * wh : (float)ah * wh;
+            }
+        }
+    }
+    const float oscale = p.out_scale * (1.0f / 256.0f) * p.scale[8 * b + 4 + p.ch[p.n9 - 1].seg];
+    float o = acc * oscale + (p.addvec ? p.addvec[(size_t)b * p.addvec_bs + n] : 0.f);
+    if (p.residual) o += p.res_scale * p.residual[((size_t)(b * p.H + y) * p.W + x) * 32 + n];
+    ref[idx] = o;
+}
+
+static bool parity(const PPParams& p, int terms, const float* out, const char* what) {
+    const int step = 7, nsamp = (int)(((long)p.B * p.H * p.W + step - 1) / step);
+    float* ref; (void)hipMalloc(&ref, (size_t)nsamp * 32 * 4);
+    hipLaunchKernelGGL(ref_kernel_pp, dim3((nsamp * 32 + 255) / 256), dim3(256), 0, 0, p, terms, step, nsamp, ref);
+    std::vector<float> hr((size_t)nsamp * 32), ho((size_t)p.B * p.H * p.W * 32);
+    (void)hipMemcpy(hr.data(), ref, hr.size() * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(ho.data(), out, ho.size() * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(ref);
+    double emax = 0, rmax = 0;
+    for (int sI = 0; sI < nsamp; ++sI)
+        for (int n_ = 0; n_ < 32; ++n_) {
+            const double r = hr[(size_t)sI * 32 + n_], o = ho[(size_t)sI * step * 32 + n_];
+            if (fabs(r) > rmax) rmax = fabs(r);
+            if (!(fabs(r - o) <= emax)) emax = fabs(r - o);
+        }
+    const bool ok = emax <= 2e-5 * rmax;
+    printf("PARITY %s (%s, terms %d): max|kernel - reference| = %.3e over %d sampled pixels x 32 channels, max|reference| = %.3e\n", ok ? "OK" : "FAIL", what, terms, emax, nsamp, rmax);
+    return ok;
 }
 
 int main(int argc, char** argv) {
@@ -51,6 +108,26 @@ int main(int argc, char** argv) {
     p.res_scale = 1.f; p.stats_out = stats; p.out_scale = 1.f; p.coef = coef; p.coef_stride = 1024; p.scale = scale;
     unsigned long long* dbg; (void)hipMalloc(&dbg, (2 * 64 * 8 + 64) * 8); (void)hipMemset(dbg, 0, (2 * 64 * 8 + 64) * 8);
     p.residual = nullptr;
+    if (getenv("PARITY")) {
+        // every form the library launches at this chunk count, both split modes, against the reference kernel
+        bool ok = true;
+        auto clr = [&]() { (void)hipMemset(out, 0, n * 4); };
+        if (nch == 1) {
+            clr(); run<1, false, 1, 3>(p, H, W); ok &= parity(p, 3, out, "1 chunk");
+            clr(); run<1, false, 1, 1>(p, H, W); ok &= parity(p, 1, out, "1 chunk");
+            p.residual = res;
+            clr(); run<1, true, 1, 3>(p, H, W); ok &= parity(p, 3, out, "1 chunk + residual");
+            clr(); run<1, true, 1, 1>(p, H, W); ok &= parity(p, 1, out, "1 chunk + residual");
+        } else if (nch == 2) {
+            clr(); run<2, false, 2, 3>(p, H, W); ok &= parity(p, 3, out, "2 chunks, 8-wave form");
+            clr(); run<2, false, 1, 1>(p, H, W); ok &= parity(p, 1, out, "2 chunks");
+        } else {
+            clr(); run<3, false, 2, 3>(p, H, W); ok &= parity(p, 3, out, "3 chunks, 8-wave form");
+            clr(); run<3, false, 1, 1>(p, H, W); ok &= parity(p, 1, out, "3 chunks");
+        }
+        printf("%s\n", ok ? "ALL PARITY OK" : "PARITY FAILED");
+        return ok ? 0 : 1;
+    }
     if (nch == 1) {
         printf("%d x %d x %d x 32, 1 chunk: one 8-wave workgroup per CU %7.1f us | two 4-wave workgroups per CU %7.1f us | with residual %7.1f / %7.1f us\n", B, H, W,
                run<1, false, 2>(p, H, W), run<1, false, 1>(p, H, W), (p.residual = res, run<1, true, 2>(p, H, W)), run<1, true, 1>(p, H, W));

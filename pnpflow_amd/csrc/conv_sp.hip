@@ -34,11 +34,14 @@ constexpr int sp_rows(int MT) { return 8 * MT; }                                
 constexpr int sp_npix(int MT) { return (sp_rows(MT) + 2) * SP_PW; }
 constexpr int sp_patch(int MT) { return (sp_rows(MT) + 2) * SP_PITCH * 64; }      // MT 2: 23 040 B
 constexpr int sp_a9(int MT) { return (sp_npix(MT) * 4 + 255) / 256; }             // float4 per lane and chunk (MT 2: 6)
-constexpr int sp_tap(int NT) { return 2 * NT * 1024; }                             // bytes of one tap: (hi | lo) x NT x 1 KiB
-constexpr int sp_x(int NT) { return 5 * sp_tap(NT); }                              // slot X: taps 0..4
-constexpr int sp_y(int NT) { return 4 * sp_tap(NT); }                              // slot Y: taps 5..8
+// TERMS = 3: the fp32-equivalent split; TERMS = 1 (round 6): precision mode 2 - hi-only operands, one MFMA per (M-tile, N-tile) and tap, hi-only weight
+// images (a tap is NT KiB; slot X is rounded up to whole 4 KiB refill rounds: at NT = 2 its five taps are 10 KiB and the refill fetches 12 - the two
+// extra KiB are the head of tap 5 in the chunk image, never read from X)
+constexpr int sp_tap(int NT, int TERMS = 3) { return (TERMS == 3 ? 2 : 1) * NT * 1024; }      // bytes of one tap: (hi | lo) x NT x 1 KiB
+constexpr int sp_x(int NT, int TERMS = 3) { return (5 * sp_tap(NT, TERMS) + 4095) / 4096 * 4096; }      // slot X: taps 0..4
+constexpr int sp_y(int NT, int TERMS = 3) { return 4 * sp_tap(NT, TERMS); }                  // slot Y: taps 5..8
 constexpr int SP_TAB = PP_MAXCH * 32;                                               // chunk table: 32 B per chunk (see the kernel's prologue)
-constexpr int sp_lds(int MT, int NT) { return sp_x(NT) + sp_y(NT) + 2 * sp_patch(MT) + SP_TAB; }
+constexpr int sp_lds(int MT, int NT, int TERMS = 3) { return sp_x(NT, TERMS) + sp_y(NT, TERMS) + 2 * sp_patch(MT) + SP_TAB; }
 // the A9 float4 of the next chunk are staged under the seven taps that carry no refill (0-3, 5-7), front-loaded: with A9 = 6 one under
 // each of taps 0-3, 5, 6; with A9 = 10 two under taps 0-2 and one under taps 3, 5, 6, 7
 constexpr int sp_stage_n(int A9, int tap) {            // float4 staged under `tap`
@@ -61,10 +64,13 @@ __device__ unsigned long long* g_sp_dbg = nullptr;
 #define SP_STAMP(k) do { } while (0)
 #endif
 
-template <int MT, int NT, bool RES>
+template <int MT, int NT, bool RES, int TERMS = 3>
 __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
     constexpr int TH = sp_rows(MT), NPIX = sp_npix(MT), A9 = sp_a9(MT), PATCH = sp_patch(MT);
-    constexpr int TAPB = sp_tap(NT), XB = sp_x(NT), COUT = 32 * NT, OB = COUT * 4;        // OB: bytes of an output pixel
+    constexpr int TAPB = sp_tap(NT, TERMS), XB = sp_x(NT, TERMS), COUT = 32 * NT, OB = COUT * 4;        // OB: bytes of an output pixel
+    constexpr int NFRAG = (TERMS == 3 ? 2 : 1) * (MT + NT), NMMA = TERMS * MT * NT;      // fragment reads / MFMAs of a tap
+    static_assert(TERMS == 3 || TERMS == 1, "split terms");
+    static_assert(sp_y(NT, TERMS) % 4096 == 0 && 9 * TAPB >= XB, "refill rounds of 4 KiB; slot X's over-fetch stays inside the chunk image");
     // hand-counted vmcnt: the patch requests issued behind a refill and in front of the barrier that publishes it
     constexpr int REQ1 = sp_stage_0(A9, 4), REQ2 = A9 - REQ1 + 3;      // taps 0-3; taps 5-7 + the three coefficient loads of tap 7 (scale, shift, operand scale)
     static_assert(sp_stage_0(A9, 9) == A9 && REQ1 + NT + 4 * MT * NT < 64, "staging distribution / vmcnt range");
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wq = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    constexpr unsigned PATCH0 = (unsigned)(XB + sp_y(NT)), TAB = PATCH0 + 2u * (unsigned)PATCH;
+    constexpr unsigned PATCH0 = (unsigned)(XB + sp_y(NT, TERMS)), TAB = PATCH0 + 2u * (unsigned)PATCH;
     const pp_float_cptr scale_c = (pp_float_cptr)(uintptr_t)p.scale;
     const int nch = p.n9;
 
@@ -187,10 +193,14 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
         const float f = ((S.inval >> i) & 1u) ? 0.0f : S.ascale;
         v.x *= f; v.y *= f; v.z *= f; v.w *= f;
         f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-        f16x4 l = {(_Float16)(v.x - (float)h[0]), (_Float16)(v.y - (float)h[1]), (_Float16)(v.z - (float)h[2]), (_Float16)(v.w - (float)h[3])};
-        const unsigned addr = ldsw[i] + pofs;
-        *reinterpret_cast<f16x4*>(smem + addr) = h;
-        *reinterpret_cast<f16x4*>(smem + (addr ^ 32u)) = l;
+        if constexpr (TERMS == 3) {
+            f16x4 l = {(_Float16)(v.x - (float)h[0]), (_Float16)(v.y - (float)h[1]), (_Float16)(v.z - (float)h[2]), (_Float16)(v.w - (float)h[3])};
+            const unsigned addr = ldsw[i] + pofs;
+            *reinterpret_cast<f16x4*>(smem + addr) = h;
+            *reinterpret_cast<f16x4*>(smem + (addr ^ 32u)) = l;
+        } else {      // one rounding to fp16; the pixel record keeps its 64-byte pitch, its lo half stays unwritten and unread
+            *reinterpret_cast<f16x4*>(smem + ldsw[i] + pofs) = h;
+        }
     };
 
     f32x16 acc[MT][NT];
@@ -299,42 +309,52 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
     auto load_tap = [&](int set, int tap, unsigned pofs) __attribute__((always_inline)) {
         const int ky = tap / 3, kx = tap % 3;
         const unsigned wb = (unsigned)(tap < 5 ? tap * TAPB : XB + (tap - 5) * TAPB) + b_lane;
+        if constexpr (TERMS == 3) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) fa[set][mt][1] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][1] + (unsigned)((mt * 2 + ky) * SP_PITCH * 64) + pofs);
+            for (int mt = 0; mt < MT; ++mt) fa[set][mt][1] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][1] + (unsigned)((mt * 2 + ky) * SP_PITCH * 64) + pofs);
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) fb[set][nt][0] = *reinterpret_cast<const f16x8*>(smem + wb + (unsigned)(nt * 1024));
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) fa[set][mt][0] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][0] + (unsigned)((mt * 2 + ky) * SP_PITCH * 64) + pofs);
+        if constexpr (TERMS == 3) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) fb[set][nt][1] = *reinterpret_cast<const f16x8*>(smem + wb + (unsigned)(NT * 1024 + nt * 1024));
+            for (int nt = 0; nt < NT; ++nt) fb[set][nt][1] = *reinterpret_cast<const f16x8*>(smem + wb + (unsigned)(NT * 1024 + nt * 1024));
+        }
     };
     // fragment number idx (0 .. 2 MT + 2 NT - 1, in load_tap's order) of a tap, alone: the refill taps request the next tap's fragments one per MFMA
     // shadow (as one burst in front of their individually fenced MFMAs the twelve reads cost ~150 cycles per refill tap)
     auto load_frag = [&](int set, int tap, unsigned pofs, int idx) __attribute__((always_inline)) {
         const int ky = tap / 3, kx = tap % 3;
         const unsigned wb = (unsigned)(tap < 5 ? tap * TAPB : XB + (tap - 5) * TAPB) + b_lane;
-        if (idx < MT) fa[set][idx][1] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][1] + (unsigned)((idx * 2 + ky) * SP_PITCH * 64) + pofs);
-        else if (idx < MT + NT) fb[set][idx - MT][0] = *reinterpret_cast<const f16x8*>(smem + wb + (unsigned)((idx - MT) * 1024));
-        else if (idx < 2 * MT + NT) fa[set][idx - MT - NT][0] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][0] + (unsigned)(((idx - MT - NT) * 2 + ky) * SP_PITCH * 64) + pofs);
-        else fb[set][idx - 2 * MT - NT][1] = *reinterpret_cast<const f16x8*>(smem + wb + (unsigned)(NT * 1024 + (idx - 2 * MT - NT) * 1024));
+        if constexpr (TERMS == 3) {
+            if (idx < MT) fa[set][idx][1] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][1] + (unsigned)((idx * 2 + ky) * SP_PITCH * 64) + pofs);
+            else if (idx < MT + NT) fb[set][idx - MT][0] = *reinterpret_cast<const f16x8*>(smem + wb + (unsigned)((idx - MT) * 1024));
+            else if (idx < 2 * MT + NT) fa[set][idx - MT - NT][0] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][0] + (unsigned)(((idx - MT - NT) * 2 + ky) * SP_PITCH * 64) + pofs);
+            else fb[set][idx - 2 * MT - NT][1] = *reinterpret_cast<const f16x8*>(smem + wb + (unsigned)(NT * 1024 + (idx - 2 * MT - NT) * 1024));
+        } else {      // hi fragments only: NT B fragments, then MT A fragments
+            if (idx < NT) fb[set][idx][0] = *reinterpret_cast<const f16x8*>(smem + wb + (unsigned)(idx * 1024));
+            else fa[set][idx - NT][0] = *reinterpret_cast<const f16x8*>(smem + a_addr[kx][0] + (unsigned)(((idx - NT) * 2 + ky) * SP_PITCH * 64) + pofs);
+        }
     };
     // group g of a tap's 3 MT groups of NT MFMAs: term g / MT (a_lo w_hi, a_hi w_lo, a_hi w_hi), M-tile g % MT - an accumulator recurs every
     // MT NT MFMAs
     auto mma_group = [&](int set, int g) __attribute__((always_inline)) {
-        const int term = g / MT, mt = g % MT;
+        const int term = TERMS == 3 ? g / MT : 2, mt = g % MT;      // (TERMS = 1: the a_hi w_hi product alone)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][mt][term == 0 ? 1 : 0], fb[set][nt][term == 1 ? 1 : 0], acc[mt][nt], 0, 0, 0);
     };
     auto mma_tap = [&](int set) __attribute__((always_inline)) {
 #pragma unroll
-        for (int g = 0; g < 3 * MT; ++g) mma_group(set, g);
+        for (int g = 0; g < TERMS * MT; ++g) mma_group(set, g);
     };
     // a tap whose side work is plain C++ (staging, requests, scalar work): the scheduler places it into the MFMA shadows by this pattern -
     // per MFMA at most one LDS read, two plain VALU, one transcendental and two SALU (a wave alone on its SIMD hides ~5 issue slots per
     // 32-cycle MFMA; the first version let 5-8 instructions into each of the first nine shadows and none into the rest: 920-1000 cycles
     // per tap of 768 matrix-pipe cycles); the LDS writes and the request in the last quarter
     auto tap_pattern = [&]() __attribute__((always_inline)) {
+        if constexpr (TERMS == 3) {
 #pragma unroll
         for (int k = 0; k < 3 * MT * NT; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -345,6 +365,20 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
             __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
             if (k >= 3 * MT * NT - 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             if (k == 3 * MT * NT - 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        } else {
+            // a third of the shadows for the same staging: per MFMA one LDS read (six of eight), the vector work in equal shares (the tap is
+            // bound by its vector issue as much as by its eight MFMAs), LDS writes and the request behind the last ones
+#pragma unroll
+        for (int k = 0; k < MT * NT; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (k < NFRAG) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, A9 > 7 ? 10 : 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, A9 > 7 ? 2 : 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x004, 4, 0);
+            if (k >= MT * NT - 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            if (k >= MT * NT - 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
         }
     };
     // a tap that carries LDS-DMA refill pieces (asm statements: pinned by hand, ONE piece per MFMA shadow): `nrounds` x 4 KiB from tap t0 of
@@ -358,8 +392,8 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
 #pragma unroll
-        for (int g = 0; g < 3 * MT; ++g) {
-            const int term = g / MT, mt = g % MT;
+        for (int g = 0; g < TERMS * MT; ++g) {
+            const int term = TERMS == 3 ? g / MT : 2, mt = g % MT;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][mt][term == 0 ? 1 : 0], fb[set][nt][term == 1 ? 1 : 0], acc[mt][nt], 0, 0, 0);
@@ -372,7 +406,7 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
                     if ((j & 3) == 2) asm volatile("global_load_lds_dwordx4 %0, %1 offset:2048" :: "v"(b_lane), "s"(sb + (j - 2) * 1024) : "memory");
                     if ((j & 3) == 3) asm volatile("global_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(b_lane), "s"(sb + (j - 3) * 1024) : "memory");
                 }
-                if (j < 2 * (MT + NT)) load_frag(nset, ntap, npofs, j);      // fragment j of the tap behind this one
+                if (j < NFRAG) load_frag(nset, ntap, npofs, j);      // fragment j of the tap behind this one
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -430,7 +464,7 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         SP_STAMP(5);
-        mma_tap_refill((4 + SI) & 1, wnext, 0, 5 * TAPB / 4096, (5 + SI) & 1, 5, PCUR);
+        mma_tap_refill((4 + SI) & 1, wnext, 0, XB / 4096, (5 + SI) & 1, 5, PCUR);
         SP_STAMP(6);
         // ---- taps 5, 6: staging of float4 4, 5; tap 6 also fetches the descriptor of the chunk three ahead; tap 7 its coefficients -----------
 #pragma unroll
@@ -490,7 +524,11 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
         {
             const char* w0 = reinterpret_cast<const char*>(p.ch[0].wimg);
 #pragma unroll
-            for (int j = 0; j < 9 * TAPB / 4096; ++j) glds16_sp(dma_lane, w0 + j * 4096, (unsigned)(j * 4096) + (unsigned)(wq * 1024));      // X | Y are contiguous
+            for (int j = 0; j < (TERMS == 3 ? 9 * TAPB : XB) / 4096; ++j) glds16_sp(dma_lane, w0 + j * 4096, (unsigned)(j * 4096) + (unsigned)(wq * 1024));      // TERMS = 3: X | Y are contiguous, as the chunk image is; TERMS = 1: slot X (taps 0..4 + the round-up)
+            if constexpr (TERMS != 3) {
+#pragma unroll
+                for (int j = 0; j < 4 * TAPB / 4096; ++j) glds16_sp(dma_lane, w0 + 5 * TAPB + j * 4096, (unsigned)(XB + j * 4096) + (unsigned)(wq * 1024));      // slot Y: taps 5..8
+            }
         }
 #pragma unroll
         for (int i = 0; i < A9; ++i) transform_one(cf0, i, 0);
@@ -547,8 +585,8 @@ __global__ __launch_bounds__(256, 1) void conv_sp_kernel(const PPParams p) {
 static int ilog2_exact_sp(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
 
 bool conv_sp_supported(const ConvParams& p, int stride, int up, int terms) {
-    static const int mode = getenv("PNPFLOW_HIP_SP") ? atoi(getenv("PNPFLOW_HIP_SP")) : 1;      // test-only A/B switch: 0 off, 1 on, 2 the 128-channel level only
-    if (mode == 0 || terms != 3 || stride != 1 || up != 0 || p.gnb_x != nullptr) return false;
+    static const int mode = getenv("PNPFLOW_HIP_SP") ? atoi(getenv("PNPFLOW_HIP_SP")) : 1;      // test-only A/B switch: 0 off, 1 on, 2 the 128-channel level only, 3 on in the default mode only
+    if (mode == 0 || (terms != 3 && !(terms == 1 && mode != 3)) || stride != 1 || up != 0 || p.gnb_x != nullptr) return false;
     if (p.Cout != 128 && !(p.Cout == 64 && mode == 1)) return false;
     if (p.out_cstride != p.Cout || (p.residual != nullptr && p.res_cstride != p.Cout)) return false;
     // the hand-counted vmcnt in front of the first barrier of a tile's chunk 0 counts the NT bias loads of tile_inputs: a launch without a
@@ -574,26 +612,26 @@ bool conv_sp_supported(const ConvParams& p, int stride, int up, int terms) {
     return p.gn_C > 0 && p.coef != nullptr && p.scale != nullptr;      // (with_coef: every GroupNorm-ed split-fp16 launch carries operand scales)
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int TERMS>
 static hipError_t launch_sp_t(const PPParams& p0, hipStream_t s) {
     static unsigned long long attr_set[2] = {0ull, 0ull};
     const bool res = p0.residual != nullptr;
-    const void* kern = res ? reinterpret_cast<const void*>(conv_sp_kernel<MT, NT, true>) : reinterpret_cast<const void*>(conv_sp_kernel<MT, NT, false>);
+    const void* kern = res ? reinterpret_cast<const void*>(conv_sp_kernel<MT, NT, true, TERMS>) : reinterpret_cast<const void*>(conv_sp_kernel<MT, NT, false, TERMS>);
     { hipError_t e = set_max_dynamic_lds_once(kern, attr_set[res ? 1 : 0], 160 * 1024); if (e != hipSuccess) return e; }
     const int grid = persistent_grid();
     if (grid <= 0) return hipErrorInvalidConfiguration;
     PPParams p = p0;
     p.lx = ilog2_exact_sp(p.W / 16); p.ly = ilog2_exact_sp(p.H / sp_rows(MT));
     p.rot = 5;
-    if (res) hipLaunchKernelGGL((conv_sp_kernel<MT, NT, true>), dim3(grid), dim3(256), sp_lds(MT, NT), s, p);
-    else hipLaunchKernelGGL((conv_sp_kernel<MT, NT, false>), dim3(grid), dim3(256), sp_lds(MT, NT), s, p);
+    if (res) hipLaunchKernelGGL((conv_sp_kernel<MT, NT, true, TERMS>), dim3(grid), dim3(256), sp_lds(MT, NT, TERMS), s, p);
+    else hipLaunchKernelGGL((conv_sp_kernel<MT, NT, false, TERMS>), dim3(grid), dim3(256), sp_lds(MT, NT, TERMS), s, p);
     return hipGetLastError();
 }
 
-hipError_t launch_conv_sp(const PPParams& p0, hipStream_t s) {
-    if (p0.n9 < 2 || (p0.n9 & 1) || p0.n1 != 0) return hipErrorInvalidValue;
-    if (p0.cout == 128) return launch_sp_t<2, 4>(p0, s);
-    if (p0.cout == 64) return launch_sp_t<4, 2>(p0, s);
+hipError_t launch_conv_sp(const PPParams& p0, hipStream_t s, int terms) {
+    if (p0.n9 < 2 || (p0.n9 & 1) || p0.n1 != 0 || (terms != 3 && terms != 1)) return hipErrorInvalidValue;
+    if (p0.cout == 128) return terms == 3 ? launch_sp_t<2, 4, 3>(p0, s) : launch_sp_t<2, 4, 1>(p0, s);
+    if (p0.cout == 64) return terms == 3 ? launch_sp_t<4, 2, 3>(p0, s) : launch_sp_t<4, 2, 1>(p0, s);
     return hipErrorInvalidValue;
 }
 

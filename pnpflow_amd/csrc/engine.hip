@@ -481,6 +481,31 @@ static const void* packed_conv_sp128(pf_engine* e, const std::string& wname, int
     return upload(e, key, raw);
 }
 
+// hi-only image of the same chunk for conv_sp's TERMS = 1 form (precision mode 2): [tap][N-tile][k-half][column][8 halfs] = 9 taps of NT KiB, values
+// RNE16(w x 2^8) - the hi halves of the images above, i.e. the weights conv_mfma16's TERMS = 1 form multiplies with
+static const void* packed_conv_sp_h(pf_engine* e, const std::string& wname, int lo, int cout) {
+    const std::string key = wname + "#sph" + std::to_string(cout) + "_" + std::to_string(lo);
+    auto it = e->dev.find(key);
+    if (it != e->dev.end()) return it->second;
+    const HostTensor& t = W(e, wname);
+    const int O = (int)t.shape[0], I = (int)t.shape[1], kk = (int)(t.shape[2] * t.shape[3]);
+    if (O != cout || (cout != 64 && cout != 128) || kk != 9) return nullptr;
+    const int NT = cout / 32;
+    std::vector<_Float16> out((size_t)9 * NT * 512, (_Float16)0.f);
+    for (int tap = 0; tap < 9; ++tap)
+        for (int nt = 0; nt < NT; ++nt)
+            for (int kh = 0; kh < 2; ++kh)
+                for (int n = 0; n < 32; ++n)
+                    for (int i = 0; i < 8; ++i) {
+                        const int c = lo + kh * 8 + i;
+                        const int oc = 32 * nt + 4 * (n & 7) + (n >> 3);
+                        out[((size_t)tap * NT + nt) * 512 + ((size_t)kh * 32 + n) * 8 + i] = (_Float16)(t.data[((size_t)oc * I + c) * 9 + tap] * 256.0f);
+                    }
+    std::vector<float> raw(out.size() / 2);
+    memcpy(raw.data(), out.data(), out.size() * sizeof(_Float16));
+    return upload(e, key, raw);
+}
+
 static void fill_packed_seg(ConvSeg& s, const float* w, int taps, int Cout) {
     (void)taps; (void)Cout;
     s.w = w; s.w_mode = 0; s.w_bs = 0; s.w_cs = 0; s.w_ts = 0; s.w_ns = 0; s.w_ks = 0; s.w16 = nullptr;
@@ -597,9 +622,9 @@ static bool attach_dma(Builder& bd, ConvParams& p, int stride, int up, std::vect
 static int attach_pp(Builder& bd, const ConvParams& p, int stride, int up, PPParams& q) {      // 0: no; 1: conv_pp; 2: conv_sp
     pf_engine* e = bd.e;
     if (e->precision == 0) return 0;
-    // precision mode 2 (one MFMA per product): conv_pp's hi-only form on the 32-channel level (round 6); conv_sp is default-mode only
+    // precision mode 2 (one MFMA per product): the hi-only TERMS = 1 forms of both persistent kernels (round 6)
     const int terms = e->precision == 2 ? 1 : 3;
-    const bool sp = terms == 3 && (p.Cout == 128 || p.Cout == 64) && conv_sp_supported(p, stride, up, 3);
+    const bool sp = (p.Cout == 128 || p.Cout == 64) && conv_sp_supported(p, stride, up, terms);
     if (!sp && !(p.Cout == 32 && conv_pp_supported(p, stride, up, terms))) return 0;
     q = PPParams{};
     q.cout = p.Cout;
@@ -614,6 +639,7 @@ static int attach_pp(Builder& bd, const ConvParams& p, int stride, int up, PPPar
             k.src = sg.src; k.cstride = sg.cstride; k.coff = sg.coff + cc * kc; k.xform = sg.xform;
             k.gn_c0 = sg.gn_off + cc * kc; k.seg = i;
             k.wimg = !sp ? packed_conv_pp(e, it->second.name, it->second.lo + cc * kc)
+                     : terms == 1 ? packed_conv_sp_h(e, it->second.name, it->second.lo + cc * kc, p.Cout)
                      : p.Cout == 128 ? packed_conv_sp128(e, it->second.name, it->second.lo + cc * kc) : packed_conv_sp64(e, it->second.name, it->second.lo + cc * kc);
             if (!k.wimg) return 0;
             (sg.taps == 9 ? q.n9 : q.n1) += 1;
@@ -1367,7 +1393,7 @@ static int run_backward(pf_engine* e, Plan* plan, const float* vec, float* g, hi
 }
 
 static hipError_t dispatch_conv(pf_engine* e, const Op& op, hipStream_t s) {
-    if (op.use_pp == 2 && e->precision == 1) return launch_conv_sp(op.ppp, s);
+    if (op.use_pp == 2 && e->precision != 0) return launch_conv_sp(op.ppp, s, e->precision == 2 ? 1 : 3);
     if (op.use_pp == 1 && e->precision != 0) return launch_conv_pp(op.ppp, s, e->precision == 2 ? 1 : 3);
     if (op.dma) return launch_conv_dma(op.cp, op.up, s, e->precision == 2 ? 1 : 3);
     if (e->precision != 0) {

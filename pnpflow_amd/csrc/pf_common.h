@@ -181,7 +181,7 @@ struct PPParams {
 bool conv_pp_supported(const ConvParams& p, int stride, int up, int terms);
 hipError_t launch_conv_pp(const PPParams& p, hipStream_t s, int terms = 3);      // terms 1: precision mode 2 (hi-only operands)
 bool conv_sp_supported(const ConvParams& p, int stride, int up, int terms);      // conv_sp.hip: one wave per SIMD, software-pipelined (Cout = 64 / 128)
-hipError_t launch_conv_sp(const PPParams& p, hipStream_t s);
+hipError_t launch_conv_sp(const PPParams& p, hipStream_t s, int terms = 3);      // terms 1: precision mode 2 (hi-only operands and weight images)
 
 hipError_t launch_conv(const ConvParams& p, int stride, int up, hipStream_t s);
 hipError_t launch_conv16(const ConvParams& p, int stride, int up, hipStream_t s, int terms = 3);   // split-fp16 MFMA variant (terms 3) / single fp16 MFMA (terms 1)

@@ -1821,7 +1821,7 @@ def test_conv_pp_mode2_form_matches_conv_mfma16_mode2(hip, tmp_path):
     try:
         m.set_precision(2)
         rows = _profile_rows(m, 80, 256, tmp_path, "layers_pp_mode2.csv")
-        assert sum(1 for r in rows if int(r["dma"]) == 2) == 26 and not any(int(r["dma"]) == 5 for r in rows)      # conv_sp is default-mode only
+        assert sum(1 for r in rows if int(r["dma"]) == 2) == 26
         # and the mode still meets the oracle at its own tolerance (FP16_REL_L2: relative L2 of a forward, one fp16 rounding per operand)
         x = det_normal((80, 3, 256, 256), 72).cuda(); t = torch.linspace(0.05, 0.95, 80).cuda()
         v = m(x, t)
@@ -1875,14 +1875,43 @@ def test_conv_pp_kernel_matches_its_reference_kernel(hip, shape):
     assert "ALL PARITY OK" in out and "FAIL" not in out, out[-1500:]
 
 
-@pytest.mark.parametrize("shape", [(64, 64, 80, 8, 0, 128), (64, 64, 81, 8, 1, 128), (64, 64, 40, 16, 0, 128), (128, 128, 40, 4, 0, 64), (128, 128, 41, 4, 1, 64), (128, 128, 24, 12, 0, 64)])
+def test_conv_sp_mode2_form_matches_conv_mfma16_mode2(hip, tmp_path):
+    """Round 6: in precision mode 2 the 64- and 128-channel levels run on conv_sp's TERMS = 1 instantiations (hi-only patch records, hi-only LDS-DMA
+    weight images of NT KiB per tap, one MFMA per (M-tile, N-tile) and tap); with the test-only switch PNPFLOW_HIP_SP=3 the mode stays on
+    conv_mfma16_kernel there.  Same bounds and reasoning as test_conv_pp_mode2_form_matches_conv_mfma16_mode2 (two correct mode-2 forwards differ by
+    about the mode's own fp16 rounding noise); the kernel alone is held to 2e-5 of max against its reference kernel in
+    test_conv_sp_kernel_matches_its_reference_kernel's terms = 1 cases.  The per-launch CSV shows the same 36 launches on conv_sp as in the default mode."""
+    _ab_forwards(tmp_path, (("afhq256", 80), ("afhq256", 81), ("celeba128", 160)), dict(PNPFLOW_HIP_SP="3"), dict(PNPFLOW_HIP_SP="1"), "sp_mode2", prec="2",
+                 tol=4e-3, rel_l2=FP16_REL_L2)
+    if os.environ.get("PNPFLOW_HIP_SP") not in (None, "1"):
+        return
+    m, cfg, sd = model_for("afhq256")
+    try:
+        m.set_precision(2)
+        rows = _profile_rows(m, 80, 256, tmp_path, "layers_sp_mode2.csv")
+        sp = [r for r in rows if int(r["dma"]) == 5]
+        assert sorted(int(r["K"]) for r in sp if int(r["Cout"]) == 128) == sorted([1152] * 10 + [2304] * 5 + [576, 1728, 3456])
+        assert sorted(int(r["K"]) for r in sp if int(r["Cout"]) == 64) == sorted([576] * 10 + [1152] * 5 + [288, 864, 1728])
+        x = det_normal((80, 3, 256, 256), 73).cuda(); t = torch.linspace(0.05, 0.95, 80).cuda()
+        v = m(x, t)
+        with torch.no_grad():
+            ref = O.unet_forward(sd, cfg, x[79:].cpu(), t[79:].cpu())
+        assert float((v[79:].cpu() - ref).norm() / ref.norm()) <= FP16_REL_L2
+    finally:
+        m.set_precision(1)
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 80, 8, 0, 128), (64, 64, 81, 8, 1, 128), (64, 64, 40, 16, 0, 128), (128, 128, 40, 4, 0, 64), (128, 128, 41, 4, 1, 64), (128, 128, 24, 12, 0, 64),
+                                   (64, 64, 80, 8, 0, 128, 1), (64, 64, 81, 8, 1, 128, 1), (128, 128, 40, 4, 0, 64, 1), (128, 128, 41, 4, 1, 64, 1), (128, 128, 24, 12, 0, 64, 1)])
 def test_conv_sp_kernel_matches_its_reference_kernel(hip, shape):
     """conv_sp_kernel ALONE (the production source compiled into tools/ubench/conv_sp_probe) against a reference kernel of the same arithmetic -
     GroupNorm + SiLU + operand scale, fp16 hi / lo split, a_lo w_hi + a_hi w_lo + a_hi w_hi summed in fp32 - on every 7th pixel of the launch
     (every position of a tile, borders included): both instantiation pairs (128 channels: 16 x 16-pixel tiles, 64 channels: 32 x 16), with and
-    without the identity residual, 4 ... 16 chunks, ragged tile ranges.  The probe prints PARITY OK when max|kernel - reference| <= 2e-5 of max|reference|."""
-    H, W, B, nch, res, cout = shape
-    out = _run_probe("conv_sp_probe", (H, W, B, nch, res, 8, 0, cout))
+    without the identity residual, 4 ... 16 chunks, ragged tile ranges; a seventh entry 1 = the round-6 TERMS = 1 form of precision mode 2 (hi-only
+    operands and weight images, the a_hi w_hi product alone).  The probe prints PARITY OK when max|kernel - reference| <= 2e-5 of max|reference|."""
+    H, W, B, nch, res, cout = shape[:6]
+    terms = shape[6] if len(shape) > 6 else 3
+    out = _run_probe("conv_sp_probe", (H, W, B, nch, res, 8, 0, cout, terms))
     assert "PARITY OK" in out, out[-1500:]
 
 

@@ -1,6 +1,6 @@
 // Stand-alone timing + parity of conv_sp_kernel (pnpflow_amd/csrc/conv_sp.hip) on synthetic tensors, with s_memtime stamps of workgroup 0's
 // phases.  build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../pnpflow_amd/csrc -o conv_sp_probe conv_sp_probe.hip
-// run: ./conv_sp_probe [H W B nch res first_step n_steps cout]
+// run: ./conv_sp_probe [H W B nch res first_step n_steps cout terms]
 #define PP_PROBE_BUILD 1
 #include "../../pnpflow_amd/csrc/conv_sp.hip"
 #include <cstdio>
@@ -8,21 +8,21 @@
 #include <vector>
 using namespace pf;
 
-template <int MT, int NT, bool RES>
+template <int MT, int NT, bool RES, int TERMS = 3>
 static float run(const PPParams& p0, int H, int W) {
-    auto kern = conv_sp_kernel<MT, NT, RES>;
+    auto kern = conv_sp_kernel<MT, NT, RES, TERMS>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     PPParams p = p0;
     int lx = 0; while ((16 << lx) < W) ++lx;
     int ly = 0; while ((sp_rows(MT) << ly) < H) ++ly;
     p.lx = lx; p.ly = ly; p.rot = 5;
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(256), dim3(256), sp_lds(MT, NT), 0, p);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(256), dim3(256), sp_lds(MT, NT, TERMS), 0, p);
     const int reps = 10;
     float best = 1e30f;
     for (int batch = 0; batch < 4; ++batch) {      // best of four batches of ten launches (run-to-run noise of one batch: +-3 %)
         (void)hipEventRecord(e0);
-        for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, dim3(256), dim3(256), sp_lds(MT, NT), 0, p);
+        for (int w = 0; w < reps; ++w) hipLaunchKernelGGL(kern, dim3(256), dim3(256), sp_lds(MT, NT, TERMS), 0, p);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
         best = ms < best ? ms : best;
@@ -34,7 +34,7 @@ static float run(const PPParams& p0, int H, int W) {
 // Reference of the kernel's arithmetic on a sample of output pixels (every `step`-th pixel of the launch): the same operands - GroupNorm + SiLU
 // + operand scale, fp16 hi / lo split - and the same three products per term (a_lo w_hi + a_hi w_lo + a_hi w_hi), summed in fp32 in
 // another order; weights read back from the packed image ([tap][hi | lo][N-tile][lane-linear 1 KiB], MFMA column 8 g + k = channel 4 k + g).
-__global__ void ref_kernel(PPParams p, int nt_n, int step, int nsamp, float* ref) {
+__global__ void ref_kernel(PPParams p, int nt_n, int step, int nsamp, float* ref, int terms) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int cout = 32 * nt_n;
     if (idx >= nsamp * cout) return;
@@ -42,7 +42,7 @@ __global__ void ref_kernel(PPParams p, int nt_n, int step, int nsamp, float* ref
     const long pix = (long)sidx * step;
     const int x = (int)(pix % p.W), y = (int)((pix / p.W) % p.H), b = (int)(pix / ((long)p.W * p.H));
     const int nt = n >> 5, ch = n & 31, col = (ch & 3) * 8 + (ch >> 2);
-    const int tapb = 2 * nt_n * 1024;
+    const int tapb = (terms == 3 ? 2 : 1) * nt_n * 1024;      // terms 1 (precision mode 2): hi-only tap images, the a_hi w_hi product alone
     float acc = 0.f;
     for (int c = 0; c < p.n9; ++c) {
         const PPChunk& k = p.ch[c];
@@ -59,8 +59,8 @@ __global__ void ref_kernel(PPParams p, int nt_n, int step, int nsamp, float* ref
                 v *= asc;
                 const _Float16 ah = (_Float16)v, al = (_Float16)(v - (float)ah);
                 const int lane = col + 32 * (kk >> 3), j = kk & 7;
-                const float wh = (float)wt[(nt * 1024 + lane * 16) / 2 + j], wl = (float)wt[(nt_n * 1024 + nt * 1024 + lane * 16) / 2 + j];
-                acc += (float)al * wh + (float)ah * wl + (float)ah * wh;
+                const float wh = (float)wt[(nt * 1024 + lane * 16) / 2 + j], wl = terms == 3 ? (float)wt[(nt_n * 1024 + nt * 1024 + lane * 16) / 2 + j] : 0.f;
+                acc += terms == 3 ? (float)al * wh + (float)ah * wl + (float)ah * wh : (float)ah * wh;
             }
         }
     }
@@ -74,7 +74,8 @@ int main(int argc, char** argv) {
     const int H = argc > 1 ? atoi(argv[1]) : 64, W = argc > 2 ? atoi(argv[2]) : 64, B = argc > 3 ? atoi(argv[3]) : 160, nch = argc > 4 ? atoi(argv[4]) : 8;
     const int useres = argc > 5 ? atoi(argv[5]) : 0, s0 = argc > 6 ? atoi(argv[6]) : 4, ns = argc > 7 ? atoi(argv[7]) : 2 * nch + 2;
     const int cout = argc > 8 ? atoi(argv[8]) : 128;      // 128: <2, 4> (16 x 16-pixel tiles), 64: <4, 2> (32 x 16)
-    const size_t wbytes = cout == 128 ? 73728 : 36864;
+    const int terms = argc > 9 ? atoi(argv[9]) : 3;       // 3: the fp32-equivalent split; 1: precision mode 2 (hi-only operands and weight images)
+    const size_t wbytes = (cout == 128 ? 73728 : 36864) / (terms == 3 ? 1 : 2);
     const size_t n = (size_t)B * H * W * 128;
     float *in, *res, *out, *coef, *scale, *addv; double* stats; void* wimg;
     (void)hipMalloc(&in, n * 4); (void)hipMalloc(&res, n * 4); (void)hipMalloc(&out, n * 4);
@@ -91,7 +92,10 @@ int main(int argc, char** argv) {
     p.res_scale = 1.f; p.stats_out = stats; p.out_scale = 1.f; p.coef = coef; p.coef_stride = 1024; p.scale = scale;
     p.residual = useres ? res : nullptr;
     unsigned long long* dbg; (void)hipMalloc(&dbg, 64 * 16 * 8); (void)hipMemset(dbg, 0, 64 * 16 * 8);
-    auto go = [&]() -> float { return cout == 128 ? (useres ? run<2, 4, true>(p, H, W) : run<2, 4, false>(p, H, W)) : (useres ? run<4, 2, true>(p, H, W) : run<4, 2, false>(p, H, W)); };
+    auto go = [&]() -> float {
+        if (terms == 1) return cout == 128 ? (useres ? run<2, 4, true, 1>(p, H, W) : run<2, 4, false, 1>(p, H, W)) : (useres ? run<4, 2, true, 1>(p, H, W) : run<4, 2, false, 1>(p, H, W));
+        return cout == 128 ? (useres ? run<2, 4, true>(p, H, W) : run<2, 4, false>(p, H, W)) : (useres ? run<4, 2, true>(p, H, W) : run<4, 2, false>(p, H, W));
+    };
     const float us_plain = go();
     (void)hipMemcpyToSymbol(HIP_SYMBOL(pf::g_sp_dbg), &dbg, sizeof(dbg));      // stamps on from here
     const float us = go();
@@ -99,7 +103,7 @@ int main(int argc, char** argv) {
     {   // parity on a sample of pixels
         const int step = 7, nsamp = (int)(((long)B * H * W + step - 1) / step);
         float* ref; (void)hipMalloc(&ref, (size_t)nsamp * cout * 4);
-        hipLaunchKernelGGL(ref_kernel, dim3((nsamp * cout + 255) / 256), dim3(256), 0, 0, p, cout / 32, step, nsamp, ref);
+        hipLaunchKernelGGL(ref_kernel, dim3((nsamp * cout + 255) / 256), dim3(256), 0, 0, p, cout / 32, step, nsamp, ref, terms);
         std::vector<float> hr((size_t)nsamp * cout), ho((size_t)B * H * W * cout);
         (void)hipMemcpy(hr.data(), ref, hr.size() * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(ho.data(), out, ho.size() * 4, hipMemcpyDeviceToHost);
         double emax = 0, rmax = 0; long bad = -1;

@@ -22,6 +22,14 @@
 // (NB = loads per fragment step, IPW = DMA instructions per wave and chunk; the last chunk issues no DMA and waits vmcnt(2 NB)).
 //
 // Epilogue (bias / time embedding / residual / statistics / fused GroupNorm-backward first stage) is conv_mfma16.hip's.
+//
+// UP = 2 (round 6): the nearest-x2 upsampling conv (models.py:70-91: F.interpolate(scale 2, nearest) then a 3x3 conv) in its PHASE form.  Output
+// pixel (2i + dy, 2j + dx) reads upsampled rows 2i + dy - 1 .. 2i + dy + 1 = source rows {i-1, i, i} (dy = 0) / {i, i, i+1} (dy = 1), so each of the
+// four output phases is a 2 x 2 conv of the SOURCE image whose taps are sums of the 3 x 3 weights that land on the same source pixel
+// (engine.hip: packed phase image, N = 4 Cout rows, 4 taps): 16 instead of 36 multiply-adds per source pixel and (c_in, c_out) pair.  The grid tiles
+// the source image; a wave's 32 weight rows belong to one phase (dy, dx) = ((n / Cout) >> 1, (n / Cout) & 1), its taps (ty, tx) read patch pixel
+// (row + ty + dy, col + tx + dx) and it writes pixel (2 row + dy, 2 col + dx).  The image border needs no case: the taps that fall outside the
+// upsampled image are exactly the ones whose source pixel is outside the source image (zero border records).
 // Reference: the convolutions of pnpflow/models.py:94-113 (ResidualBlock), :145-162 (SelfAttention 1x1), :70-91 (Upsample).
 #include <cstdlib>
 #include <type_traits>
@@ -156,10 +164,11 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* const s_buf = smem_raw;
 
-    const int tiles_x = p.W / TW, tiles_y = p.H / TH;
+    const int WC = UP == 2 ? 4 * p.Cout : p.Cout;       // rows of the weight image (UP = 2: four phases x Cout)
+    const int tiles_x = (UP == 2 ? p.Ws : p.W) / TW, tiles_y = (UP == 2 ? p.Hs : p.H) / TH;
     int bid, nb;
     if (p.xcd_map) {
-        const int NBk = p.Cout / BN;
+        const int NBk = WC / BN;
         const int total = gridDim.x;
         const int work = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
         bid = work / NBk; nb = work % NBk;
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvParams p) {
         const int py = pp / PW, px = pp - py * PW;
         const int g = q ^ ((px >> 1) & 7);
         int sy, sx;
-        if (UP) { sy = (oy0 - 1 + py + 2) >> 1; sx = (ox0 - 1 + px + 2) >> 1; }      // nearest-x2 upsampled view of the padded source
+        if (UP == 1) { sy = (oy0 - 1 + py + 2) >> 1; sx = (ox0 - 1 + px + 2) >> 1; }      // nearest-x2 upsampled view of the padded source
         else { sy = oy0 + py; sx = ox0 + px; }
         a_off[i] = (unsigned)((sy * Wp + sx) * 128 + g * 16);
     }
@@ -203,12 +212,15 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvParams p) {
     };
 
     // weight fragments: per-lane byte offset of this lane's output channel inside a [slice][tap] block, scalar base per step
-    const int nclamp = min(n0 + wn * 32 + l31, p.Cout - 1);
+    const int nclamp = min(n0 + wn * 32 + l31, WC - 1);
+    // UP = 2: phase and first output channel of this wave's 32 weight rows (Cout is a multiple of 32: a wave never straddles two phases)
+    const int phase = UP == 2 ? (n0 + wn * 32) / p.Cout : 0, ph_dy = phase >> 1, ph_dx = phase & 1;
+    const int nc0 = UP == 2 ? (n0 + wn * 32) - phase * p.Cout : n0 + wn * 32;
     // block (k16-slice, tap) = [hi halves: Cout x 32 B][lo halves: Cout x 32 B] (TERMS = 1: the hi part only): a wave's fragment load is one
     // contiguous 1 KiB run
     const unsigned b_voff = (unsigned)(nclamp * 32 + hi * 16);
-    const unsigned b_voff_lo = b_voff + (unsigned)p.Cout * 32u;
-    const size_t wblk = (size_t)p.Cout * (TERMS == 3 ? 64 : 32);           // bytes of one [slice][tap] block
+    const unsigned b_voff_lo = b_voff + (unsigned)WC * 32u;
+    const size_t wblk = (size_t)WC * (TERMS == 3 ? 64 : 32);           // bytes of one [slice][tap] block
     // first block of chunk (si, ch): fragment step (tap, j) of the chunk is block j * taps + tap behind it
     auto wchunk = [&](int wsi, int wch) -> const char* {
         const ConvSeg& sg = p.seg[wsi];
@@ -219,7 +231,11 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvParams p) {
     const int prow = l31 >> 4, pcol = l31 & 15;
     unsigned lb[3];                              // (pixel byte address | swizzled hi bit) per kx
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) lb[kx] = (unsigned)(((wm * MT * 2 + prow) * PW + pcol + kx) * 128) | (unsigned)(((((pcol + kx) >> 1) & 7) ^ hi) << 4);
+    for (int kx = 0; kx < 3; ++kx) {
+        // (UP = 2: entry tx of the 2 x 2 window = patch column pcol + tx + dx, patch row offset dy folded into the pixel address)
+        const int col = pcol + kx + (UP == 2 ? ph_dx : 0), row = wm * MT * 2 + prow + (UP == 2 ? ph_dy : 0);
+        lb[kx] = (unsigned)((row * PW + col) * 128) | (unsigned)((((col >> 1) & 7) ^ hi) << 4);
+    }
 
     f32x16 acc[MT];
 #pragma unroll
@@ -268,6 +284,7 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvParams p) {
         constexpr bool CARRY = decltype(carry_c)::value;
         constexpr int NS = TAPS * KS;
         static_assert(NS >= 2 && NS <= 36 && (!CARRY || NS % 3 == 0), "unrolled steps / ring phase");
+        static_assert(TAPS == 9 || TAPS == 1 || (TAPS == 4 && UP == 2), "3x3, 1x1, or the 2x2 phase window of the upsampling conv");
         // weight block of fragment step s2 of this chunk ((tap, slice) = (s2 / KS, s2 % KS)), or of step s2 - NS in {0, 1} of the next
         auto wstep = [&](int s2) -> const char* {
             if (s2 < NS) return wcur + (size_t)((s2 % KS) * TAPS + s2 / KS) * wblk;
@@ -283,8 +300,8 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvParams p) {
         unsigned lbc[3];
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) lbc[kx] = lb[kx] + (unsigned)(cur * BUF);
-#define PF_KY(S) (TAPS == 9 ? ((S) / KS) / 3 : 1)
-#define PF_KX(S) (TAPS == 9 ? ((S) / KS) % 3 : 1)
+#define PF_KY(S) (TAPS == 9 ? ((S) / KS) / 3 : TAPS == 4 ? ((S) / KS) >> 1 : 1)
+#define PF_KX(S) (TAPS == 9 ? ((S) / KS) % 3 : TAPS == 4 ? ((S) / KS) & 1 : 1)
 #define PF_STEP(S, FC, FN)                                                                                                     \
         if constexpr ((S) < NS) {                                                                                              \
             constexpr bool REQ_ = CARRY || (S) + 2 < NS;                                                                       \
@@ -322,6 +339,15 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvParams p) {
         bload<TERMS>(f0, b_voff, b_voff_lo, w0);
         bload<TERMS>(f1, b_voff, b_voff_lo, w0 + (size_t)9 * wblk);      // step 1 = (tap 0, slice 1)
     }
+    if constexpr (UP == 2) {      // one raw segment of 2 x 2 phase windows
+        while (more) {
+            int nsi = si, nch = ch + 1;
+            if (nch * KC >= p.seg[si].C) { nsi = si + 1; nch = 0; }
+            more = nsi < p.nseg;
+            chunk_body(std::integral_constant<int, 4>{}, std::false_type{}, wchunk(si, ch), nullptr, 4, cur, more ? nsi : si, more ? nch : ch);
+            si = nsi; ch = nch; cur ^= 1;
+        }
+    }
     // 9-tap segments first (conv_dma_supported orders them so), then the 1-tap ones: two loops, one body each
     while (more && p.seg[si].taps == 9) {
         if (ch == 0 && si > 0) rescale(si);
@@ -356,7 +382,7 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvParams p) {
     const float oscale = p.out_scale * (1.0f / 256.0f) * (p.nseg == 1 ? seg_inv[0] : (p.nseg == 2 ? seg_inv[1] : seg_inv[2]));
     const int cq = lane & 7;                           // this lane's channel quad inside a 32-channel tile
     {
-        const int ncol = n0 + wn * 32;                 // first channel of this wave's N-tile
+        const int ncol = nc0;                          // first channel of this wave's N-tile
         const int n = ncol + l31;
         const float add = (p.addvec != nullptr && n < p.Cout) ? p.addvec[(size_t)b * p.addvec_bs + n] : 0.f;
         const int n4 = ncol + cq * 4;
@@ -410,7 +436,8 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int px = (lane >> 3) + 8 * i;    // pixel of the 32-pixel M-tile (2 rows x 16 cols)
-                const int oy = oy0 + (wm * MT + mt) * 2 + (px >> 4), ox = ox0 + (px & 15);
+                int oy = oy0 + (wm * MT + mt) * 2 + (px >> 4), ox = ox0 + (px & 15);
+                if constexpr (UP == 2) { oy = 2 * oy + ph_dy; ox = 2 * ox + ph_dx; }      // (tile coordinates are source pixels)
                 float4 v = *reinterpret_cast<const float4*>(s_tr + px * TP + cq * 4);
                 if (nok4 && oy < p.H && ox < p.W) {
                     const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
@@ -469,7 +496,7 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvParams p) {
             float tot = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) tot += s_red[(w * BN + col) * 2 + which];
-            const int n = n0 + col;
+            const int n = UP == 2 ? (n0 + col) % p.Cout : n0 + col;      // (UP = 2: the four phases add into the same channel)
             if (n < p.Cout) {
                 if constexpr (GNB) unsafeAtomicAdd(p.gnb_sum + ((size_t)b * p.gnb_Ct + p.gnb_coff + n) * 2 + which, (double)tot);
                 else unsafeAtomicAdd(p.stats_out + ((size_t)b * p.Cout + n) * 2 + which, (double)tot);
@@ -486,8 +513,21 @@ static int dma_mode() {      // PNPFLOW_HIP_DMA: 0 off, 1 (default) where the gr
     return m;
 }
 
+// the phase form of the nearest-x2 upsampling conv (UP = 2; the caller has packed the 4-phase 2 x 2 weight image: one raw segment of taps = 4)
+static bool conv_dma_phase_supported(const ConvParams& p, int terms) {
+    static const int mode = getenv("PNPFLOW_HIP_UPPHASE") ? atoi(getenv("PNPFLOW_HIP_UPPHASE")) : 1;      // test-only A/B switch: 0 = the 9-tap form on the upsampled view
+    if (mode == 0 || p.nseg != 1 || p.seg[0].taps != 4 || p.residual != nullptr || p.gnb_x != nullptr) return false;
+    if (p.H != 2 * p.Hs || p.W != 2 * p.Ws || p.Hs % DMA_TH != 0 || p.Ws % 16 != 0 || p.Cout % 32 != 0 || (4 * p.Cout) % DMA_BN != 0) return false;
+    const ConvSeg& s = p.seg[0];
+    if (s.w_mode != 0 || (terms == 3 ? s.w16 : s.w16h) == nullptr || s.C % (terms == 3 ? 32 : 64) != 0) return false;
+    if ((size_t)(p.Hs + 2) * (p.Ws + 2) * 128 >= (1ull << 31)) return false;
+    if (dma_mode() >= 2) return true;
+    return (long)p.B * (p.Hs / DMA_TH) * (p.Ws / 16) * (4 * p.Cout / DMA_BN) >= 512;
+}
+
 bool conv_dma_supported(const ConvParams& p, int stride, int up, int terms) {
-    if (dma_mode() == 0 || stride != 1 || (up != 0 && up != 1)) return false;
+    if (dma_mode() == 0 || stride != 1 || (up != 0 && up != 1 && up != 2)) return false;
+    if (up == 2) return conv_dma_phase_supported(p, terms);
     if (p.Cout % DMA_BN != 0 || p.H % DMA_TH != 0 || p.W % 16 != 0) return false;
     if (up == 1 && (p.H != 2 * p.Hs || p.W != 2 * p.Ws)) return false;
     if (up == 0 && (p.H != p.Hs || p.W != p.Ws)) return false;
@@ -521,8 +561,8 @@ static hipError_t launch_dma_t(const ConvParams& p, hipStream_t stream) {
     constexpr int MT = 4, WM = 1, WN = 4;
     constexpr int PH = DMA_TH + 2, PW = 18, NINST = (PH * PW * 8 + 63) / 64, IPW = (NINST + 3) / 4, BUF = IPW * 4 * 1024;
     const size_t lds = 2 * BUF;
-    const int tiles = p.B * (p.H / DMA_TH) * (p.W / 16);
-    dim3 grid(tiles, p.Cout / DMA_BN);
+    const int tiles = UP == 2 ? p.B * (p.Hs / DMA_TH) * (p.Ws / 16) : p.B * (p.H / DMA_TH) * (p.W / 16);
+    dim3 grid(tiles, (UP == 2 ? 4 * p.Cout : p.Cout) / DMA_BN);
     ConvParams pp = p; pp.xcd_map = 0;
     if (((long)grid.x * grid.y) % 8 == 0) { pp.xcd_map = 1; grid = dim3(grid.x * grid.y, 1); }
     if (p.gnb_x != nullptr) {
@@ -543,6 +583,7 @@ size_t conv_dma_a16_bytes(int B, int C, int Hs, int Ws, int terms) {
 
 hipError_t launch_conv_dma(const ConvParams& p, int up, hipStream_t s, int terms) {
     for (int i = 0; i < p.nseg; ++i) if (p.seg[i].a16 == nullptr) return hipErrorInvalidValue;
+    if (up == 2) return terms == 3 ? launch_dma_t<2, 3>(p, s) : launch_dma_t<2, 1>(p, s);
     if (terms == 3) return up ? launch_dma_t<1, 3>(p, s) : launch_dma_t<0, 3>(p, s);
     return up ? launch_dma_t<1, 1>(p, s) : launch_dma_t<0, 1>(p, s);
 }

@@ -807,16 +807,67 @@ static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x, i
     return out;
 }
 
+// Phase form of Upsample (models.py:70-91: nearest x2, then a 3x3 conv): output pixel (2i + dy, 2j + dx) sees the upsampled rows 2i + dy - 1 ..
+// 2i + dy + 1, i.e. source rows {i-1, i, i} for dy = 0 and {i, i, i+1} for dy = 1 (columns alike) - a 2 x 2 conv of the SOURCE image per phase whose
+// tap (ty, tx) carries the sum of the 3 x 3 weights that read the same source pixel: rows R(0,0) = {0}, R(0,1) = {1,2}, R(1,0) = {0,1}, R(1,1) = {2}.
+// 16 instead of 36 multiply-adds per source pixel.  Host tensor [phase * Cout + oc][c][ty * 2 + tx] (sums in double, rounded once to fp32), registered
+// under `wname + "#phase"` so that the ordinary packers (packed_conv16 / packed_conv16h) build its images.
+static std::string phase_weight(pf_engine* e, const std::string& wname) {
+    const std::string key = wname + "#phase";
+    if (e->host.count(key)) return key;
+    const HostTensor& t = W(e, wname);
+    const int O = (int)t.shape[0], I = (int)t.shape[1];
+    HostTensor ph; ph.shape = {4 * O, I, 2, 2}; ph.data.assign((size_t)4 * O * I * 4, 0.f); ph.loaded = true;
+    static const int R0[2][2] = {{0, 1}, {0, 2}}, R1[2][2] = {{1, 3}, {2, 3}};      // [d][t] -> first / one-past-last 3x3 index:  d = 0: {0}, {1,2};  d = 1: {0,1}, {2}
+    for (int dy = 0; dy < 2; ++dy) for (int dx = 0; dx < 2; ++dx)
+        for (int oc = 0; oc < O; ++oc) for (int c = 0; c < I; ++c)
+            for (int ty = 0; ty < 2; ++ty) for (int tx = 0; tx < 2; ++tx) {
+                double sum = 0.0;
+                for (int ky = R0[dy][ty]; ky < R1[dy][ty]; ++ky)
+                    for (int kx = R0[dx][tx]; kx < R1[dx][tx]; ++kx) sum += (double)t.data[((size_t)oc * I + c) * 9 + ky * 3 + kx];
+                ph.data[(((size_t)(dy * 2 + dx) * O + oc) * I + c) * 4 + ty * 2 + tx] = (float)sum;
+            }
+    e->host[key] = std::move(ph);
+    return key;
+}
+
+// the upsampling conv on conv_dma's UP = 2 form, when the shape qualifies (split-fp16 modes only; the exact-fp32 mode and small / ragged sizes keep
+// the 9-tap form on the upsampled view)
+static bool push_conv_up_phase(Builder& bd, const ConvParams& p9, const std::string& wname) {
+    pf_engine* e = bd.e;
+    if (e->precision == 0) return false;
+    const int terms = e->precision == 2 ? 1 : 3;
+    ConvParams q = p9;
+    ConvSeg& sg = q.seg[0];
+    {   // cheap shape test before any weight image is built
+        ConvParams t = q; t.seg[0].taps = 4; t.seg[0].w16 = (const void*)1; t.seg[0].w16h = (const void*)1;
+        if (!conv_dma_supported(t, 1, 2, terms)) return false;
+    }
+    const std::string key = phase_weight(e, wname);
+    sg.taps = 4; sg.w = nullptr; sg.w16 = packed_conv16(e, key, 0, sg.C);
+    if (!sg.w16) return false;
+    ConvParams p = with_coef(bd, q, bd.plan->ops);
+    Op op{}; op.kind = OP_CONV;
+    op.dma = attach_dma(bd, p, 1, 2, bd.plan->ops) ? 1 : 0;
+    if (!op.dma) { bd.ok = false; e->err = "phase upsampling conv: conv_dma refused a launch it had accepted"; return false; }
+    op.cp = p; op.stride = 1; op.up = 2; op.flops = conv_flops(p);
+    bd.plan->gemm_flops += op.flops;
+    bd.plan->ops.push_back(op);
+    return true;
+}
+
 static Tensor resample_conv(Builder& bd, const std::string& pfx, const Tensor& x, bool down) {
     pf_engine* e = bd.e; const int B = bd.B;
     const int H = down ? x.H / 2 : x.H * 2, Wd = down ? x.W / 2 : x.W * 2;
     Tensor out = bd.make(x.C, H, Wd, true);
     ConvParams p = base_params(B, H, Wd, x.H, x.W, out);
     add_seg(p, x, 0, 9, 0);
-    fill_packed_seg(p.seg[0], packed_conv(e, pfx + "weight", 0, x.C), 9, x.C);
-    p.seg[0].w16 = packed_conv16(e, pfx + "weight", 0, x.C);
     p.addvec = upload(e, pfx + "bias", W(e, pfx + "bias").data); p.addvec_bs = 0;
-    push_conv(bd, p, down ? 2 : 1, down ? 0 : 1);
+    if (down || !push_conv_up_phase(bd, p, pfx + "weight")) {
+        fill_packed_seg(p.seg[0], packed_conv(e, pfx + "weight", 0, x.C), 9, x.C);
+        p.seg[0].w16 = packed_conv16(e, pfx + "weight", 0, x.C);
+        push_conv(bd, p, down ? 2 : 1, down ? 0 : 1);
+    }
     if (bd.plan->retain) {
         TapeRec tr; tr.kind = down ? TP_DOWN : TP_UP; tr.pfx = pfx; tr.in0 = x; tr.out = out;
         bd.plan->tape.push_back(tr);

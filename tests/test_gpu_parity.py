@@ -1716,7 +1716,9 @@ def test_conv_dma_path_is_selected_at_the_solver_batch_and_bit_identical(hip, tm
     outs = {}
     for prec in (1, 2):
         for dma in ("0", "1"):
-            env = dict(os.environ, PNPFLOW_HIP_DMA=dma)
+            # (PNPFLOW_HIP_UPPHASE=0: the upsampling convs in their 9-tap form on both sides - their round-6 phase form exists on conv_dma only and
+            # sums weights before multiplying: fp32-equivalent, not bit-identical; test_upsampling_conv_phase_form_is_fp32_equivalent)
+            env = dict(os.environ, PNPFLOW_HIP_DMA=dma, PNPFLOW_HIP_UPPHASE="0")
             f = str(tmp_path / f"v_p{prec}_d{dma}.npy")
             r = subprocess.run([sys.executable, "tools/gpu_dma_check.py", "run", "celeba128", "160", str(prec), f], cwd=repo, env=env, capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stderr[-2000:]
@@ -1739,8 +1741,8 @@ def test_conv_dma_path_is_selected_at_the_solver_batch_and_bit_identical(hip, tm
     rows = list(csv.DictReader(open(path)))
     dma_rows = [r for r in rows if int(r["dma"]) == 1]          # (2 = conv_pp.hip: the 32-channel level, test below)
     assert len(rows) == 142 and 30 <= len(dma_rows) <= 80, (len(rows), len(dma_rows))
-    assert all(int(r["Cout"]) % 128 == 0 for r in dma_rows)
-    assert any(int(r["up"]) == 1 for r in dma_rows) and any(int(r["taps0"]) == 1 and int(r["Cout"]) == 768 for r in dma_rows)
+    assert all(int(r["Cout"]) % 128 == 0 or int(r["up"]) == 2 for r in dma_rows)      # (up = 2: the phase form of the upsampling convs, N = 4 Cout weight rows)
+    assert any(int(r["up"]) in (1, 2) for r in dma_rows) and any(int(r["taps0"]) == 1 and int(r["Cout"]) == 768 for r in dma_rows)
 
 
 def test_conv_pp_path_is_selected_on_the_32_channel_level_and_fp32_equivalent(hip, tmp_path):
@@ -1850,6 +1852,29 @@ def test_conv_sp_takes_the_64_and_128_channel_levels_and_is_fp32_equivalent(hip,
     # (K = 1152 x 5, 864, 1728), the first block's conv1 (K = 288); the launches with a folded 1x1 shortcut stay on conv_mfma16_kernel
     assert sorted(int(r["K"]) for r in sp if int(r["Cout"]) == 64) == sorted([576] * 10 + [1152] * 5 + [288, 864, 1728])
     assert all(int(r["stride"]) == 1 and int(r["up"]) == 0 and int(r["H"]) == (64 if int(r["Cout"]) == 128 else 128) for r in sp)
+
+
+def test_upsampling_conv_phase_form_is_fp32_equivalent(hip, tmp_path):
+    """Round 6: Upsample (models.py:70-91: nearest x2, then a 3x3 conv) runs in its phase form on conv_dma (UP = 2): each of the four output phases is
+    a 2 x 2 conv of the SOURCE image whose taps are the sums of the 3 x 3 weights that read the same source pixel - 16 instead of 36 multiply-adds per
+    source pixel.  a (w1 + w2) against a w1 + a w2: equal up to fp32 rounding, so whole forwards with the test-only switch PNPFLOW_HIP_UPPHASE=0 (9-tap
+    form on the upsampled view) agree to 2e-6 of max|v| - at the headline U-Net batch shape, a ragged batch and at 128^2 - and in precision mode 2 to
+    that mode's own rounding noise.  The per-launch CSV shows the three upsampling convs as up = 2 launches of K = 4 C on conv_dma, and distinct images
+    of a batch still agree with the oracle (sample 0 and the last one)."""
+    _ab_forwards(tmp_path, (("afhq256", 80), ("afhq256", 41), ("celeba128", 160)), dict(PNPFLOW_HIP_UPPHASE="0"), dict(PNPFLOW_HIP_UPPHASE="1"), "upphase")
+    _ab_forwards(tmp_path, (("afhq256", 40),), dict(PNPFLOW_HIP_UPPHASE="0"), dict(PNPFLOW_HIP_UPPHASE="1"), "upphase_mode2", prec="2", tol=4e-3, rel_l2=FP16_REL_L2)
+    if os.environ.get("PNPFLOW_HIP_UPPHASE") not in (None, "1") or os.environ.get("PNPFLOW_HIP_DMA") not in (None, "1"):
+        return
+    m, cfg, sd = model_for("afhq256")
+    rows = _profile_rows(m, 80, 256, tmp_path, "layers_upphase.csv")
+    up = [r for r in rows if int(r["up"]) != 0]
+    assert sorted((int(r["up"]), int(r["Cout"]), int(r["K"]), int(r["H"]), int(r["dma"])) for r in up) == [(2, 64, 256, 256, 1), (2, 128, 512, 128, 1), (2, 256, 1024, 64, 1)], up
+    x = det_normal((80, 3, 256, 256), 74).cuda(); t = torch.linspace(0.05, 0.95, 80).cuda()
+    v = m(x, t)
+    with torch.no_grad():
+        for i in (0, 79):
+            ref = O.unet_forward(sd, cfg, x[i:i + 1].cpu(), t[i:i + 1].cpu())
+            assert float((v[i:i + 1].cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
 
 
 def _run_probe(name, args, env=None):

@@ -41,7 +41,7 @@ for name in ("c2_256", "c2", "c3", "c4"):
             tot_n += n if "prep_split" not in k else 0          # a prep pass is part of its conv launch's cost, not a launch of its own
     if tot_n:
         out[name] = {"bytes_per_launch": round(tot_b / tot_n, 1), "launches": tot_n, "commit": commit,
-                     "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over 2 forwards + warm-up of tools/gpu_forward_only.py, tools/pmc_traffic.sh; 2 x FETCH_SIZE + WRITE_SIZE, KiB units; profiles/r05_pmc_{name}_{{fetch,write}}.md",
+                     "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over 2 forwards + warm-up of tools/gpu_forward_only.py, tools/pmc_traffic.sh; 2 x FETCH_SIZE + WRITE_SIZE, KiB units; profiles/r06_pmc_{name}_{{fetch,write}}.md",
                      "kernels": rows[:16]}
 json.dump(out, open("gpurun_out/pmc/traffic.json", "w"), indent=1)
 for k, v in out.items(): print(k, v["bytes_per_launch"] / 1e6, "MB per conv launch over", v["launches"], "launches")

@@ -513,16 +513,19 @@ static int dma_mode() {      // PNPFLOW_HIP_DMA: 0 off, 1 (default) where the gr
     return m;
 }
 
-// the phase form of the nearest-x2 upsampling conv (UP = 2; the caller has packed the 4-phase 2 x 2 weight image: one raw segment of taps = 4)
-static bool conv_dma_phase_supported(const ConvParams& p, int terms) {
+// the phase form of the nearest-x2 upsampling conv (UP = 2): shape test (what the engine asks before it builds the 4-phase 2 x 2 weight images) ...
+bool conv_dma_phase_shape_ok(const ConvParams& p, int terms) {
     static const int mode = getenv("PNPFLOW_HIP_UPPHASE") ? atoi(getenv("PNPFLOW_HIP_UPPHASE")) : 1;      // test-only A/B switch: 0 = the 9-tap form on the upsampled view
-    if (mode == 0 || p.nseg != 1 || p.seg[0].taps != 4 || p.residual != nullptr || p.gnb_x != nullptr) return false;
+    if (mode == 0 || dma_mode() == 0 || p.nseg != 1 || p.residual != nullptr || p.gnb_x != nullptr) return false;
     if (p.H != 2 * p.Hs || p.W != 2 * p.Ws || p.Hs % DMA_TH != 0 || p.Ws % 16 != 0 || p.Cout % 32 != 0 || (4 * p.Cout) % DMA_BN != 0) return false;
-    const ConvSeg& s = p.seg[0];
-    if (s.w_mode != 0 || (terms == 3 ? s.w16 : s.w16h) == nullptr || s.C % (terms == 3 ? 32 : 64) != 0) return false;
+    if (p.seg[0].w_mode != 0 || p.seg[0].C % (terms == 3 ? 32 : 64) != 0) return false;
     if ((size_t)(p.Hs + 2) * (p.Ws + 2) * 128 >= (1ull << 31)) return false;
     if (dma_mode() >= 2) return true;
     return (long)p.B * (p.Hs / DMA_TH) * (p.Ws / 16) * (4 * p.Cout / DMA_BN) >= 512;
+}
+// ... and the launch test: one raw segment of taps = 4 that carries the packed phase image
+static bool conv_dma_phase_supported(const ConvParams& p, int terms) {
+    return conv_dma_phase_shape_ok(p, terms) && p.seg[0].taps == 4 && (terms == 3 ? p.seg[0].w16 : p.seg[0].w16h) != nullptr;
 }
 
 bool conv_dma_supported(const ConvParams& p, int stride, int up, int terms) {

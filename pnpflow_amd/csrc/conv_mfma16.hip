@@ -443,7 +443,10 @@ static long wg_count16(const ConvParams& p, int TH, int BN) {
 
 template <int S, int UP, int KC, int TERMS>
 static hipError_t launch_sel16(const ConvParams& p, hipStream_t stream) {
-    constexpr long MIN_WGS = 512;     // >= 2 workgroups per CU
+    // >= 2 workgroups per CU; >= 4 for the pure 1x1 launches (KC = 64): four short chunks per workgroup are a latency chain (load - stage - barrier -
+    // MFMA), which more, smaller workgroups overlap better - proj_out of the 128^2 nets' attention blocks at U-Net batch 160 (16^2 x 256 -> 256): 53.9 ->
+    // 44.7 us on the 4 x 16-pixel tile (r6, same-box A/B with the threshold at 512 / 1024 / 2048 / 4096: C2 11.39 -> 11.46 images/s, C5 unchanged)
+    constexpr long MIN_WGS = KC == 64 ? 1024 : 512;
     if constexpr (S == 1) {
         if (p.Cout <= 32) {
             return launch_cfg16<2, 1, 4, 1, S, UP, KC, TERMS>(p, stream);                                                        // 16x16 px x 32

@@ -839,10 +839,7 @@ static bool push_conv_up_phase(Builder& bd, const ConvParams& p9, const std::str
     const int terms = e->precision == 2 ? 1 : 3;
     ConvParams q = p9;
     ConvSeg& sg = q.seg[0];
-    {   // cheap shape test before any weight image is built
-        ConvParams t = q; t.seg[0].taps = 4; t.seg[0].w16 = (const void*)1; t.seg[0].w16h = (const void*)1;
-        if (!conv_dma_supported(t, 1, 2, terms)) return false;
-    }
+    if (!conv_dma_phase_shape_ok(q, terms)) return false;      // (before any weight image is built)
     const std::string key = phase_weight(e, wname);
     sg.taps = 4; sg.w = nullptr; sg.w16 = packed_conv16(e, key, 0, sg.C);
     if (!sg.w16) return false;

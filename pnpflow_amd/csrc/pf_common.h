@@ -153,6 +153,7 @@ struct PrepParams {
 };
 hipError_t launch_prep_split(const PrepParams& p, hipStream_t s);
 bool conv_dma_supported(const ConvParams& p, int stride, int up, int terms);
+bool conv_dma_phase_shape_ok(const ConvParams& p, int terms);      // the nearest-x2 upsampling conv described by p (its 9-tap form) can run in conv_dma's phase form (up = 2)
 hipError_t launch_conv_dma(const ConvParams& p, int up, hipStream_t s, int terms);
 size_t conv_dma_a16_bytes(int B, int C, int Hs, int Ws, int terms);
 

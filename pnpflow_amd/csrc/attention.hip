@@ -35,6 +35,45 @@ __device__ __forceinline__ void split4(float4 v, f16x4& h, f16x4& l) {
     l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
 }
 
+// Output of a workgroup's 32 x C tile: lane (l31, hi) holds rows (r & 3) + 8 (r >> 2) + 4 hi of channel wave * 32 TC + 32 nt + l31 (for a fixed r the 32 lanes
+// of a half-wave write 128 contiguous bytes).  `row_scale`: the long variant's 1 / l per row (LDS), or null.  With the folded output projection (AttnParams)
+// the tile leaves as  out = acc + bias[c] + residual[b][t][c].
+template <int TC>
+__device__ __forceinline__ void attn_store(const AttnParams& p, const f32x16 (&acc_o)[TC], const float* row_scale, int b, int T, int q0, int wave, int l31, int hi) {
+    constexpr int C = 128 * TC;
+    const int ch0 = wave * TC * 32 + l31;
+    const size_t tile = ((size_t)b * T + q0) * C + ch0;
+    float* obase = p.out + tile;
+    if (p.residual == nullptr) {
+#pragma unroll
+        for (int nt = 0; nt < TC; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                obase[(size_t)row * C + nt * 32] = row_scale != nullptr ? acc_o[nt][r] * row_scale[row] : acc_o[nt][r];
+            }
+        return;
+    }
+    // every residual value is requested before the first store: loads and stores share one in-order counter, so a load issued behind stores waits
+    // for their acknowledgements (interleaved load - add - store: +30 us on a 77 us kernel)
+    const float* rbase = p.residual + tile;
+    float rv[TC][16];
+#pragma unroll
+    for (int nt = 0; nt < TC; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[nt][r] = rbase[(size_t)((r & 3) + 8 * (r >> 2) + 4 * hi) * C + nt * 32];
+#pragma unroll
+    for (int nt = 0; nt < TC; ++nt) {
+        const float bias = p.bias != nullptr ? p.bias[ch0 + nt * 32] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float o = row_scale != nullptr ? acc_o[nt][r] * row_scale[row] : acc_o[nt][r];
+            obase[(size_t)row * C + nt * 32] = (o + bias) + rv[nt][r];
+        }
+    }
+}
+
 template <int TK, int TC>
 __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
     constexpr int T = 128 * TK, C = 128 * TC, BQ = 32;
@@ -198,14 +237,7 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
     for (; j + 4 <= T / 16; j += 4) { v_step(j, v0, v3); v_step(j + 1, v1, v0); v_step(j + 2, v2, v1); v_step(j + 3, v3, v2); }
     static_assert((T / 16) % 4 == 0, "the ring of 4 realigns every 4 steps");
 
-    float* obase = p.out + ((size_t)b * T + q0) * C + wave * TC * 32 + l31;
-#pragma unroll
-    for (int nt = 0; nt < TC; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            obase[(size_t)row * C + nt * 32] = acc_o[nt][r];
-        }
+    attn_store<TC>(p, acc_o, nullptr, b, T, q0, wave, l31, hi);
 }
 
 // Long-sequence variant (T a multiple of 256 above 256: the 1024-token attention block of the 256x256 nets).  The keys are
@@ -364,14 +396,7 @@ __global__ __launch_bounds__(256) void attn_fused_long_kernel(const AttnParams p
     }
     if ((tid & 7) == 0) s_scale[tid >> 3] = 1.0f / l_run;
     __syncthreads();
-    float* obase = p.out + ((size_t)b * T + q0) * C + wave * TC * 32 + l31;
-#pragma unroll
-    for (int nt = 0; nt < TC; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            obase[(size_t)row * C + nt * 32] = acc_o[nt][r] * s_scale[row];
-        }
+    attn_store<TC>(p, acc_o, s_scale, b, T, q0, wave, l31, hi);
 }
 
 template <int TC>
@@ -400,6 +425,54 @@ hipError_t launch_attn_cfg(const AttnParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+// per-channel (sum, sum of squares) of [B][HW][C]: one 1024-thread workgroup per image, thread = (row group, channel quad), eight rows in flight per thread;
+// fp32 partial sums of at most 64 rows per thread (the conv epilogues sum 256 before their fp64 step), added in fp64 across row groups
+__global__ __launch_bounds__(1024) void tensor_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int HW, int C) {
+    __shared__ float s_red[1024 * 8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int cq = C / 4, groups = 1024 / cq;                // C in {128, 256}: 32 / 64 quads, 32 / 16 row groups
+    const int q = tid % cq, g = tid / cq;
+    const float* base = x + (size_t)b * HW * C + q * 4;
+    double a[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    for (int r0 = g; r0 < HW; r0 += 64 * groups) {
+        float f1[4] = {0.f, 0.f, 0.f, 0.f}, f2[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < 64; k0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = r0 + (k0 + k) * groups;
+                v[k] = r < HW ? *reinterpret_cast<const float4*>(base + (size_t)r * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                f1[0] += v[k].x; f1[1] += v[k].y; f1[2] += v[k].z; f1[3] += v[k].w;
+                f2[0] += v[k].x * v[k].x; f2[1] += v[k].y * v[k].y; f2[2] += v[k].z * v[k].z; f2[3] += v[k].w * v[k].w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] += (double)f1[j]; s2[j] += (double)f2[j]; }
+    }
+    // (row-group partials cross LDS as fp32 when HW <= 64 groups - one fp32 partial per thread, exact hand-over; larger tensors hand over the rounded fp64 sums)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s_red[tid * 8 + j * 2] = (float)a[j]; s_red[tid * 8 + j * 2 + 1] = (float)s2[j]; }
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double t1 = 0.0, t2 = 0.0;
+            for (int k = 0; k < groups; ++k) { t1 += (double)s_red[(k * cq + q) * 8 + j * 2]; t2 += (double)s_red[(k * cq + q) * 8 + j * 2 + 1]; }
+            double* st = stats + ((size_t)b * C + q * 4 + j) * 2;
+            st[0] = t1; st[1] = t2;
+        }
+    }
+}
+
+hipError_t launch_tensor_stats(const float* x, double* stats, int B, int HW, int C, hipStream_t s) {
+    if (x == nullptr || stats == nullptr || B <= 0 || HW <= 0 || C % 4 != 0 || C / 4 > 1024 || 1024 % (C / 4) != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(tensor_stats_kernel, dim3(B), dim3(1024), 0, s, x, stats, HW, C);
+    return hipGetLastError();
+}
 
 bool attn_fused_supported(int T, int C) { return (T == 128 || (T >= 256 && T % 256 == 0 && T <= 4096)) && (C == 128 || C == 256); }
 

@@ -36,7 +36,7 @@ struct LevelDesc { std::vector<ResDesc> blocks; std::string resample; int res_ch
 
 struct Tensor { float* p = nullptr; int C = 0, H = 0, W = 0; double* stats = nullptr; };
 
-enum OpKind { OP_MEMSET, OP_TEMB, OP_BEGIN, OP_CONV, OP_SOFTMAX, OP_ATTN, OP_END, OP_GN_COEF, OP_PREP,
+enum OpKind { OP_MEMSET, OP_TEMB, OP_BEGIN, OP_CONV, OP_SOFTMAX, OP_ATTN, OP_STATS, OP_END, OP_GN_COEF, OP_PREP,
               // NCSN++ net (engine_ncsnpp.inc)
               OP_NX_TEMB, OP_NX_IMG_IN, OP_NX_FIR, OP_NX_IMG_OUT,
               // backward-only
@@ -738,6 +738,44 @@ static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x, i
         upload(e, key + ".b", bias);
         e->dev[key + ".w"] = packed_conv(e, key + ".w", 0, C);
     }
+    static const bool fuse_env = !(getenv("PNPFLOW_HIP_FUSED_ATTN") && atoi(getenv("PNPFLOW_HIP_FUSED_ATTN")) == 0);
+    static const bool fold_env = !(getenv("PNPFLOW_HIP_ATTN_FOLD") && atoi(getenv("PNPFLOW_HIP_ATTN_FOLD")) == 0);      // test-only A/B switch
+    const bool fused = fuse_env && e->precision != 0 && !bd.plan->retain && attn_fused_supported(HW, C);
+    // Round 6: proj_out folded into the value projection.  out = x + proj_out(P v) and nothing non-linear sits between the two products, so
+    // proj_out(P v) = P (v Wp^T) + bp:  v' = GroupNorm(x) (Wp Wv)^T + Wp bv  replaces v in the stacked q,k,v conv (weights merged once on the host, in
+    // double), the fused core adds bp and x in its epilogue and sums the result's GroupNorm statistics - the proj_out launch (and the round trip of P v
+    // through HBM) is gone.  Exact algebra: the two forms differ by fp32 rounding.  The SelfAttention of the OT U-Net only (s_out = 1); the retained forward of
+    // the VJP keeps the reference's structure (its backward walks it).
+    const bool fold = fused && fold_env && s_out == 1.0f;
+    if (fold) {
+        key = pfx + "qkvf";
+        if (!e->dev.count(key + ".w")) {
+            const auto& wv = W(e, pfx + "attn_v.weight").data; const auto& bv = W(e, pfx + "attn_v.bias").data;
+            const auto& wp = W(e, pfx + "proj_out.weight").data;
+            HostTensor cat; cat.shape = {3 * C, C, 1, 1}; cat.data.reserve((size_t)3 * C * C);
+            std::vector<float> bias;
+            for (const char* nm : {"attn_q.", "attn_k."}) {
+                const auto& w = W(e, pfx + nm + "weight").data; cat.data.insert(cat.data.end(), w.begin(), w.end());
+                const auto& bb = W(e, pfx + nm + "bias").data; bias.insert(bias.end(), bb.begin(), bb.end());
+            }
+            std::vector<double> row((size_t)C);
+            for (int o = 0; o < C; ++o) {
+                std::fill(row.begin(), row.end(), 0.0);
+                double bsum = 0.0;
+                for (int m = 0; m < C; ++m) {
+                    const double a = (double)wp[(size_t)o * C + m];
+                    const float* wr = wv.data() + (size_t)m * C;
+                    for (int i = 0; i < C; ++i) row[i] += a * (double)wr[i];
+                    bsum += a * (double)bv[m];
+                }
+                for (int i = 0; i < C; ++i) cat.data.push_back((float)row[i]);
+                bias.push_back((float)bsum);
+            }
+            e->host[key + ".w"] = cat; e->host[key + ".w"].loaded = true;
+            upload(e, key + ".b", bias);
+            e->dev[key + ".w"] = packed_conv(e, key + ".w", 0, C);
+        }
+    }
     Tensor qkv = bd.make(3 * C, H, Wd, false);
     {
         ConvParams p = base_params(B, H, Wd, H, Wd, qkv);
@@ -750,9 +788,20 @@ static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x, i
         p.addvec = e->dev.at(key + ".b"); p.addvec_bs = 0;
         push_conv(bd, p);
     }
+    if (fold) {
+        Tensor out = bd.make(C, H, Wd, true);
+        Op op{}; op.kind = OP_ATTN;
+        op.ap.qkv = qkv.p; op.ap.out = out.p; op.ap.B = B; op.ap.T = HW; op.ap.C = C; op.ap.scale = 1.0f / sqrtf((float)C);
+        op.ap.bias = upload(e, pfx + "proj_out.bias", W(e, pfx + "proj_out.bias").data); op.ap.residual = x.p;
+        op.flops = (size_t)4 * B * HW * HW * C;
+        bd.plan->ops.push_back(op);
+        // the result's GroupNorm statistics: one small pass over the tile-sized tensor (L2 / Infinity-Cache resident), plain stores
+        { Op st{}; st.kind = OP_STATS; st.P[0] = out.p; st.O = out.stats; st.I[0] = HW; st.I[1] = C; bd.plan->ops.push_back(st); }
+        bd.release(qkv.p);
+        return out;
+    }
     Tensor S{}, o = bd.make(C, H, Wd, false);
-    static const bool fuse_env = !(getenv("PNPFLOW_HIP_FUSED_ATTN") && atoi(getenv("PNPFLOW_HIP_FUSED_ATTN")) == 0);
-    if (fuse_env && e->precision != 0 && !bd.plan->retain && attn_fused_supported(HW, C)) {
+    if (fused) {
         // S = q k^T / sqrt(C), softmax, O = P v in one launch (attention.hip); the exact-fp32 mode and the retained
         // forward of the VJP (whose backward reads P) keep the three-launch path below
         Op op{}; op.kind = OP_ATTN;
@@ -877,6 +926,7 @@ static void fix_stats(Op& op, double* slab) {
     auto fxm = [&](double*& p) { if (p) p = (double*)((char*)slab + ((uintptr_t)p - 1)); };
     if (op.kind == OP_CONV) { for (int i = 0; i < op.cp.nseg; ++i) fx(op.cp.seg[i].stats); fxm(op.cp.stats_out); fxm(op.cp.gnb_sum); if (op.use_pp) op.ppp.stats_out = op.cp.stats_out; }
     if (op.kind == OP_GN_COEF) for (int i = 0; i < op.gp.nseg; ++i) fx(op.gp.st[i]);
+    if (op.kind == OP_STATS) { double* d = (double*)op.O; fxm(d); op.O = d; }
     if (op.kind == OP_NX_FIR) fxm(op.fp.stats_raw);
     if (op.kind == OP_END) fx(op.ep.stats);
     if (op.kind == OP_BEGIN) fxm(op.ep.stats_out);
@@ -1490,6 +1540,7 @@ static int run_plan(pf_engine* e, Plan* plan, const float* x, const float* t, fl
                 break;
             case OP_SOFTMAX: r = launch_softmax_rows(op.sm, op.sm_rows, op.sm_cols, s); break;
             case OP_ATTN: r = launch_attn_fused(op.ap, s); break;
+            case OP_STATS: r = launch_tensor_stats((const float*)op.P[0], (double*)op.O, plan->B, op.I[0], op.I[1], s); break;
             case OP_END: { EdgeConvParams ep = op.ep; ep.out = v; r = launch_end_conv(ep, s); break; }
             case OP_GN_COEF: r = launch_gn_coef(op.gp, plan->B, s); break;
             case OP_NX_TEMB: { NxTembParams tp = op.ntp; tp.t = t; tp.t_scale = t_scale; r = launch_nx_temb(tp, s); break; }

@@ -65,11 +65,19 @@ __device__ __forceinline__ void attn_store(const AttnParams& p, const f32x16 (&a
 #pragma unroll
     for (int nt = 0; nt < TC; ++nt) {
         const float bias = p.bias != nullptr ? p.bias[ch0 + nt * 32] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float o = row_scale != nullptr ? acc_o[nt][r] * row_scale[row] : acc_o[nt][r];
-            obase[(size_t)row * C + nt * 32] = (o + bias) + rv[nt][r];
+            float o = row_scale != nullptr ? acc_o[nt][r] * row_scale[row] : acc_o[nt][r];
+            o = (o + bias) + rv[nt][r];
+            obase[(size_t)row * C + nt * 32] = o;
+            s1 += o; s2 += o * o;
+        }
+        // the tile's share of the result's GroupNorm statistics (32 rows per channel, fp32): a plain store per (tile, channel); launch_partial_stats adds the tiles
+        if (p.stats_part != nullptr) {
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            if (hi == 0) *reinterpret_cast<float2*>(p.stats_part + (((size_t)b * (T / 32) + q0 / 32) * C + ch0 + nt * 32) * 2) = make_float2(s1, s2);
         }
     }
 }
@@ -426,51 +434,24 @@ hipError_t launch_attn_cfg(const AttnParams& p, hipStream_t s) {
 
 }  // namespace
 
-// per-channel (sum, sum of squares) of [B][HW][C]: one 1024-thread workgroup per image, thread = (row group, channel quad), eight rows in flight per thread;
-// fp32 partial sums of at most 64 rows per thread (the conv epilogues sum 256 before their fp64 step), added in fp64 across row groups
-__global__ __launch_bounds__(1024) void tensor_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int HW, int C) {
-    __shared__ float s_red[1024 * 8];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int cq = C / 4, groups = 1024 / cq;                // C in {128, 256}: 32 / 64 quads, 32 / 16 row groups
-    const int q = tid % cq, g = tid / cq;
-    const float* base = x + (size_t)b * HW * C + q * 4;
-    double a[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-    for (int r0 = g; r0 < HW; r0 += 64 * groups) {
-        float f1[4] = {0.f, 0.f, 0.f, 0.f}, f2[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k0 = 0; k0 < 64; k0 += 8) {
-            float4 v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int r = r0 + (k0 + k) * groups;
-                v[k] = r < HW ? *reinterpret_cast<const float4*>(base + (size_t)r * C) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                f1[0] += v[k].x; f1[1] += v[k].y; f1[2] += v[k].z; f1[3] += v[k].w;
-                f2[0] += v[k].x * v[k].x; f2[1] += v[k].y * v[k].y; f2[2] += v[k].z * v[k].z; f2[3] += v[k].w * v[k].w;
-            }
+// per-image sum of the attention core's per-tile partial statistics part[B][nparts][C][2] (fp32) in tile order, in fp64: the GroupNorm statistics of the
+// folded block's result (plain stores, deterministic)
+__global__ __launch_bounds__(256) void partial_stats_kernel(const float* __restrict__ part, double* __restrict__ stats, int nparts, int C) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double a = 0.0, q = 0.0;
+        for (int k = 0; k < nparts; ++k) {
+            const float2 v = *reinterpret_cast<const float2*>(part + (((size_t)b * nparts + k) * C + c) * 2);
+            a += (double)v.x; q += (double)v.y;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { a[j] += (double)f1[j]; s2[j] += (double)f2[j]; }
-    }
-    // (row-group partials cross LDS as fp32 when HW <= 64 groups - one fp32 partial per thread, exact hand-over; larger tensors hand over the rounded fp64 sums)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { s_red[tid * 8 + j * 2] = (float)a[j]; s_red[tid * 8 + j * 2 + 1] = (float)s2[j]; }
-    __syncthreads();
-    if (g == 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            double t1 = 0.0, t2 = 0.0;
-            for (int k = 0; k < groups; ++k) { t1 += (double)s_red[(k * cq + q) * 8 + j * 2]; t2 += (double)s_red[(k * cq + q) * 8 + j * 2 + 1]; }
-            double* st = stats + ((size_t)b * C + q * 4 + j) * 2;
-            st[0] = t1; st[1] = t2;
-        }
+        double* st = stats + ((size_t)b * C + c) * 2;
+        st[0] = a; st[1] = q;
     }
 }
 
-hipError_t launch_tensor_stats(const float* x, double* stats, int B, int HW, int C, hipStream_t s) {
-    if (x == nullptr || stats == nullptr || B <= 0 || HW <= 0 || C % 4 != 0 || C / 4 > 1024 || 1024 % (C / 4) != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(tensor_stats_kernel, dim3(B), dim3(1024), 0, s, x, stats, HW, C);
+hipError_t launch_partial_stats(const float* part, double* stats, int B, int nparts, int C, hipStream_t s) {
+    if (part == nullptr || stats == nullptr || B <= 0 || nparts <= 0 || C <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(partial_stats_kernel, dim3(B), dim3(256), 0, s, part, stats, nparts, C);
     return hipGetLastError();
 }
 

@@ -116,10 +116,11 @@ struct EdgeConvParams {
 // fused attention core (attention.hip): qkv [B][T][3C] (q | k | v) -> out [B][T][C]
 // round 6 (engine.hip attn_block): with proj_out folded into the value projection (out = x + P (v Wp^T) + bp: exact algebra) the core's epilogue
 // adds `bias[c]` and `residual[b][t][c]`; both null = the plain core
-struct AttnParams { const float* qkv; float* out; int B, T, C; float scale; const float* bias; const float* residual; };
-// per-channel (sum, sum of squares) of an NHWC tensor [B][HW][C] -> stats[b][C][2] (plain stores: the GroupNorm statistics of a tensor whose producer does
-// not reduce them itself - the folded attention core: 655 k fp64 atomics per launch from its 32-query tiles cost 30 us of a 110 us kernel)
-hipError_t launch_tensor_stats(const float* x, double* stats, int B, int HW, int C, hipStream_t s);
+// `stats_part` [B][T / 32][C][2] (or null): fp32 (sum, sum of squares) of every 32-query tile of the result, for launch_partial_stats
+struct AttnParams { const float* qkv; float* out; int B, T, C; float scale; const float* bias; const float* residual; float* stats_part; };
+// GroupNorm statistics stats[b][C][2] of a tensor from per-tile partial sums part[B][nparts][C][2] (fp32), added in tile order in fp64 (plain stores): the
+// folded attention core's result (fp64 atomics from its 32-query tiles - 655 k per launch - cost 30 us of a 110 us kernel)
+hipError_t launch_partial_stats(const float* part, double* stats, int B, int nparts, int C, hipStream_t s);
 bool attn_fused_supported(int T, int C);
 hipError_t launch_attn_fused(const AttnParams& p, hipStream_t s);
 

@@ -101,6 +101,9 @@ struct Plan {
     std::vector<Op> bops;
     size_t bwd_flops = 0;
     float* vec_scaled = nullptr; float* vjp_scale = nullptr; unsigned int* vjp_amax = nullptr;   // VJP input normalisation
+    // retained forward: (mean, rstd) [B][gn_C] of every GroupNorm a conv launch applies, keyed by the norm's gamma vector on the device - written by that launch's
+    // gn_coef_kernel, read by the backward's GroupNorm stages (round 6: replaces one gn_fwd_coeffs launch per GroupNorm and Euler step)
+    std::map<const float*, std::pair<float*, float*>> gn_ret;
     float* nx_sigma = nullptr;         // NCSN++ retained forward: the divisor t * t_scale of its output, per image (read by the backward)
 };
 
@@ -580,6 +583,11 @@ static ConvParams with_coef(Builder& bd, ConvParams p, std::vector<Op>& ops) {
     for (int i = 0; i < p.nseg; ++i) { g.st[i] = p.seg[i].stats; g.C[i] = p.seg[i].C; g.xform[i] = p.seg[i].xform; g.gn_off[i] = p.seg[i].gn_off; }
     g.gn_C = p.gn_C; g.gn_cpg = p.gn_cpg; g.HW = p.Hs * p.Ws; g.eps = p.gn_eps; g.gamma = p.gamma; g.beta = p.beta;
     g.coef = plan->coef; g.coef_stride = Plan::COEF_STRIDE; g.scale = want_scale ? plan->scale : nullptr; g.flags = plan->flags; g.id = (int)ops.size();
+    static const bool ret_env = !(getenv("PNPFLOW_HIP_GN_RETAIN") && atoi(getenv("PNPFLOW_HIP_GN_RETAIN")) == 0);      // test-only A/B switch
+    if (plan->retain && ret_env && p.gn_C > 0 && &ops == &plan->ops && !plan->gn_ret.count(p.gamma)) {
+        float* mu = bd.acquire((size_t)bd.B * p.gn_C); float* rs = bd.acquire((size_t)bd.B * p.gn_C);
+        if (mu && rs) { g.mu_out = mu; g.rs_out = rs; plan->gn_ret[p.gamma] = {mu, rs}; }
+    }
     ops.push_back(op);
     p.coef = plan->coef; p.coef_stride = Plan::COEF_STRIDE; p.scale = want_scale ? plan->scale : nullptr;
     return p;
@@ -1221,6 +1229,7 @@ static void gen_seg(ConvParams& p, const float* src, int C, int cstride, const f
 // dst[j] = where dx goes, add[j] = optional extra addend (identity-shortcut gradient).
 struct GnBwd {
     std::vector<Tensor> srcs; int Ct = 0, cpg = 0, HW = 0; bool silu = false;
+    bool retained = false;            // mu / rs are the retained forward's (Plan::gn_ret): not this stage's to recycle
     float *mu = nullptr, *rs = nullptr, *m1 = nullptr, *m2 = nullptr; double* bsum = nullptr;
     const float *gamma = nullptr, *beta = nullptr;
     std::vector<bool> fused;
@@ -1231,10 +1240,16 @@ static GnBwd gn_bwd_begin(BwdCtx& c, const std::vector<Tensor>& srcs, const std:
     GnBwd g; g.srcs = srcs; g.silu = silu; g.HW = srcs[0].H * srcs[0].W;
     for (auto& t : srcs) g.Ct += t.C;
     g.cpg = g.Ct / groups; g.fused.assign(srcs.size(), false);
-    g.mu = c.fvec((size_t)B * g.Ct); g.rs = c.fvec((size_t)B * g.Ct); g.m1 = c.fvec((size_t)B * g.Ct); g.m2 = c.fvec((size_t)B * g.Ct);
+    g.m1 = c.fvec((size_t)B * g.Ct); g.m2 = c.fvec((size_t)B * g.Ct);
     g.bsum = c.dsum((size_t)B * g.Ct * 2);
     g.gamma = upload(e, norm_prefix + "weight", W(e, norm_prefix + "weight").data);
     g.beta = upload(e, norm_prefix + "bias", W(e, norm_prefix + "bias").data);
+    auto rt = c.plan->gn_ret.find(g.gamma);
+    if (rt != c.plan->gn_ret.end()) {      // the forward launch that applied this GroupNorm left its (mean, rstd) behind
+        g.mu = rt->second.first; g.rs = rt->second.second; g.retained = true;
+        return g;
+    }
+    g.mu = c.fvec((size_t)B * g.Ct); g.rs = c.fvec((size_t)B * g.Ct);
     Op op{}; op.kind = OP_GN_FWD_COEF; op.P[0] = srcs[0].stats; op.P[1] = srcs.size() > 1 ? srcs[1].stats : nullptr; op.P[2] = g.mu; op.P[3] = g.rs;
     op.I[0] = srcs[0].C; op.I[1] = srcs.size() > 1 ? srcs[1].C : 0; op.I[2] = g.cpg; op.I[3] = g.HW; c.push(op);
     return g;
@@ -1271,7 +1286,8 @@ static void gn_bwd_finish(BwdCtx& c, GnBwd& g, const std::vector<Tensor>& gtmp, 
         dst[j]->has = true; c.push(op);
         coff += g.srcs[j].C;
     }
-    c.bd->recycle(g.mu); c.bd->recycle(g.rs); c.bd->recycle(g.m1); c.bd->recycle(g.m2);
+    if (!g.retained) { c.bd->recycle(g.mu); c.bd->recycle(g.rs); }
+    c.bd->recycle(g.m1); c.bd->recycle(g.m2);
 }
 
 static void gn_backward(BwdCtx& c, const std::vector<Tensor>& srcs, const std::vector<Tensor>& gtmp, const std::vector<GradEntry*>& dst,

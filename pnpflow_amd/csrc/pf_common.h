@@ -145,6 +145,9 @@ struct GnCoefParams {
     float* scale;                    // [B][8] (s of segment 0..2, pad, 1/s of segment 0..2, pad), or nullptr
     unsigned int* flags;             // [0] bit 0 is set when a statistic is not finite (an activation overflowed / NaN upstream); [1] = id + 1 of the first launch that saw it
     int id;                          // index of the consuming conv in the plan (diagnostics)
+    // retained forwards (VJP): per-channel mean and 1 / sqrt(var + eps) of the GroupNorm, [B][gn_C] each - what the backward's GroupNorm stages need (they were
+    // recomputed from the same statistics by a launch of their own per GroupNorm: 9 900 launches of 5 us per 95 Euler steps of C5); null otherwise
+    float* mu_out; float* rs_out;
 };
 hipError_t launch_gn_coef(const GnCoefParams& p, int B, hipStream_t s);
 

@@ -578,6 +578,7 @@ __global__ __launch_bounds__(256) void gn_coef_kernel(const GnCoefParams p) {
         const float sc = ga * rstd;
         p.coef[((size_t)b * 2 + 0) * p.coef_stride + c] = sc;
         p.coef[((size_t)b * 2 + 1) * p.coef_stride + c] = be - (float)mean * sc;
+        if (p.mu_out != nullptr) { p.mu_out[(size_t)b * p.gn_C + c] = (float)mean; p.rs_out[(size_t)b * p.gn_C + c] = rstd; }
         gn_ms += (double)ga * ga + (double)be * be;          // E[(gamma*xhat + beta)^2] with E[xhat] = 0, E[xhat^2] = 1 per group
     }
     if (bad) atomicOr(&s_bad, 1);

@@ -38,6 +38,34 @@ __device__ __forceinline__ void split4(float4 v, f16x4& h, f16x4& l) {
 // Output of a workgroup's 32 x C tile: lane (l31, hi) holds rows (r & 3) + 8 (r >> 2) + 4 hi of channel wave * 32 TC + 32 nt + l31 (for a fixed r the 32 lanes
 // of a half-wave write 128 contiguous bytes).  `row_scale`: the long variant's 1 / l per row (LDS), or null.  With the folded output projection (AttnParams)
 // the tile leaves as  out = acc + bias[c] + residual[b][t][c].
+// Packed keys / values (AttnParams::kv_packed: the stacked q,k,v conv stored hi | lo << 16 per element - the same split as split4, made once per element
+// instead of once per query tile): a float4 of four packed words -> (4 hi halfs, 4 lo halfs) with two v_perm_b32 per pair
+__device__ __forceinline__ void unpack4(float4 v, f16x4& h, f16x4& l) {
+    const unsigned u0 = __float_as_uint(v.x), u1 = __float_as_uint(v.y), u2 = __float_as_uint(v.z), u3 = __float_as_uint(v.w);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 hh = {__builtin_amdgcn_perm(u1, u0, 0x05040100u), __builtin_amdgcn_perm(u3, u2, 0x05040100u)};
+    const u32x2 ll = {__builtin_amdgcn_perm(u1, u0, 0x07060302u), __builtin_amdgcn_perm(u3, u2, 0x07060302u)};
+    h = __builtin_bit_cast(f16x4, hh); l = __builtin_bit_cast(f16x4, ll);
+}
+// eight values of one channel (fp32, or packed words): the B fragment pair of a P v step
+template <bool packed>
+__device__ __forceinline__ void v_frag(const float (&c)[8], f16x8& vh, f16x8& vl) {
+    if constexpr (packed) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        unsigned u[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] = __float_as_uint(c[i]);
+        const u32x4 hh = {__builtin_amdgcn_perm(u[1], u[0], 0x05040100u), __builtin_amdgcn_perm(u[3], u[2], 0x05040100u),
+                          __builtin_amdgcn_perm(u[5], u[4], 0x05040100u), __builtin_amdgcn_perm(u[7], u[6], 0x05040100u)};
+        const u32x4 ll = {__builtin_amdgcn_perm(u[1], u[0], 0x07060302u), __builtin_amdgcn_perm(u[3], u[2], 0x07060302u),
+                          __builtin_amdgcn_perm(u[5], u[4], 0x07060302u), __builtin_amdgcn_perm(u[7], u[6], 0x07060302u)};
+        vh = __builtin_bit_cast(f16x8, hh); vl = __builtin_bit_cast(f16x8, ll);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { vh[i] = (_Float16)c[i]; vl[i] = (_Float16)(c[i] - (float)vh[i]); }
+    }
+}
+
 template <int TC>
 __device__ __forceinline__ void attn_store(const AttnParams& p, const f32x16 (&acc_o)[TC], const float* row_scale, int b, int T, int q0, int wave, int l31, int hi) {
     constexpr int C = 128 * TC;
@@ -82,7 +110,7 @@ __device__ __forceinline__ void attn_store(const AttnParams& p, const f32x16 (&a
     }
 }
 
-template <int TK, int TC>
+template <int TK, int TC, bool KVP>
 __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
     constexpr int T = 128 * TK, C = 128 * TC, BQ = 32;
     constexpr int QROW = C + 4;                 // dwords per query row: C/2 hi | C/2 lo | 4 pad (conflict-free ds_read_b128)
@@ -106,6 +134,7 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
     const int b = (slot / NQB) * 8 + xcd, q0 = (slot % NQB) * BQ;
     if (b >= p.B) return;
     const float* base = p.qkv + (size_t)b * T * 3 * C;
+    constexpr bool kvp = KVP;
 
     // k chunks 0 and 1 start their trip before anything else
     constexpr int K_PER = T * 8 / 256;          // float4 per thread per 32-channel chunk of k
@@ -141,7 +170,8 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
 #pragma unroll
         for (int i = 0; i < K_PER; ++i) {
             const int idx = tid + i * 256, key = idx >> 3, c4 = idx & 7;
-            f16x4 h, l; split4(rk[i], h, l);
+            f16x4 h, l;
+            if constexpr (kvp) unpack4(rk[i], h, l); else split4(rk[i], h, l);
             *reinterpret_cast<f16x4*>(s_k + key * KROW + c4 * 2) = h;
             *reinterpret_cast<f16x4*>(s_k + key * KROW + 16 + c4 * 2) = l;
         }
@@ -234,8 +264,7 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
 #pragma unroll
         for (int nt = 0; nt < TC; ++nt) {
             f16x8 vh, vl;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { vh[i] = (_Float16)cur[nt][i]; vl[i] = (_Float16)(cur[nt][i] - (float)vh[i]); }
+            v_frag<kvp>(cur[nt], vh, vl);
             acc_o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, acc_o[nt], 0, 0, 0);
             acc_o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, acc_o[nt], 0, 0, 0);
             acc_o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, acc_o[nt], 0, 0, 0);
@@ -252,7 +281,7 @@ __global__ __launch_bounds__(256) void attn_fused_kernel(const AttnParams p) {
 // walked in blocks of 256 with an online softmax: per block S = q k^T (as above), the running row maximum m and row sum l
 // are updated, P = exp(S - m) stays unnormalised, the accumulated output is rescaled by exp(m_old - m_new) and O += P v;
 // the division by l happens once at the end.  The query block is re-staged per key block (P overwrites it in LDS).
-template <int TC>
+template <int TC, bool KVP>
 __global__ __launch_bounds__(256) void attn_fused_long_kernel(const AttnParams p) {
     constexpr int TB = 256, TK = 2, C = 128 * TC, BQ = 32;      // keys per block: 2 tiles of 32 per wave
     constexpr int QROW = C + 4, PROW = TB + 4, AROW = QROW > PROW ? QROW : PROW, KROW = 36, SROW = TB + 4;
@@ -268,6 +297,7 @@ __global__ __launch_bounds__(256) void attn_fused_long_kernel(const AttnParams p
     const int b = (slot / nqb) * 8 + xcd, q0 = (slot % nqb) * BQ;       // all query blocks of an image on one XCD (see above)
     if (b >= p.B) return;
     const float* base = p.qkv + (size_t)b * T * 3 * C;
+    constexpr bool kvp = KVP;
 
     constexpr int K_PER = TB * 8 / 256, NCH = C / 32;
     float4 rka[K_PER], rkb[K_PER];
@@ -307,7 +337,8 @@ __global__ __launch_bounds__(256) void attn_fused_long_kernel(const AttnParams p
 #pragma unroll
             for (int i = 0; i < K_PER; ++i) {
                 const int idx = tid + i * 256, key = idx >> 3, c4 = idx & 7;
-                f16x4 h, l; split4(rk[i], h, l);
+                f16x4 h, l;
+                if constexpr (kvp) unpack4(rk[i], h, l); else split4(rk[i], h, l);
                 *reinterpret_cast<f16x4*>(s_k + key * KROW + c4 * 2) = h;
                 *reinterpret_cast<f16x4*>(s_k + key * KROW + 16 + c4 * 2) = l;
             }
@@ -392,8 +423,7 @@ __global__ __launch_bounds__(256) void attn_fused_long_kernel(const AttnParams p
 #pragma unroll
             for (int nt = 0; nt < TC; ++nt) {
                 f16x8 vh, vl;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { vh[i] = (_Float16)cur[nt][i]; vl[i] = (_Float16)(cur[nt][i] - (float)vh[i]); }
+                v_frag<kvp>(cur[nt], vh, vl);
                 acc_o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, acc_o[nt], 0, 0, 0);
                 acc_o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, acc_o[nt], 0, 0, 0);
                 acc_o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, acc_o[nt], 0, 0, 0);
@@ -407,26 +437,26 @@ __global__ __launch_bounds__(256) void attn_fused_long_kernel(const AttnParams p
     attn_store<TC>(p, acc_o, s_scale, b, T, q0, wave, l31, hi);
 }
 
-template <int TC>
+template <int TC, bool KVP>
 hipError_t launch_attn_long_cfg(const AttnParams& p, hipStream_t s) {
     constexpr int C = 128 * TC;
     constexpr int AROW = (C > 256 ? C : 256) + 4;
     const size_t lds = (size_t)(32 * AROW + 256 * 36 + 32) * 4;
     static unsigned long long attr_set = 0ull;
-    auto kern = attn_fused_long_kernel<TC>;
+    auto kern = attn_fused_long_kernel<TC, KVP>;
     { hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(kern), attr_set, 160 * 1024); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(kern, dim3((p.T / 32) * ((p.B + 7) / 8) * 8), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 
-template <int TK, int TC>
+template <int TK, int TC, bool KVP>
 hipError_t launch_attn_cfg(const AttnParams& p, hipStream_t s) {
     constexpr int T = 128 * TK, C = 128 * TC;
     constexpr int AROW = (C > T ? C : T) + 4;
     constexpr int KBUF = T * 36, SBUF = 32 * (T + 4);
     const size_t lds = (size_t)(32 * AROW + (KBUF > SBUF ? KBUF : SBUF)) * 4;
     static unsigned long long attr_set = 0ull;
-    auto kern = attn_fused_kernel<TK, TC>;
+    auto kern = attn_fused_kernel<TK, TC, KVP>;
     { hipError_t e = set_max_dynamic_lds_once(reinterpret_cast<const void*>(kern), attr_set, 160 * 1024); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(kern, dim3((T / 32) * ((p.B + 7) / 8) * 8), dim3(256), lds, s, p);
     return hipGetLastError();
@@ -459,9 +489,14 @@ bool attn_fused_supported(int T, int C) { return (T == 128 || (T >= 256 && T % 2
 
 hipError_t launch_attn_fused(const AttnParams& p, hipStream_t s) {
     if (!attn_fused_supported(p.T, p.C)) return hipErrorInvalidValue;
-    if (p.T > 256) return p.C == 256 ? launch_attn_long_cfg<2>(p, s) : launch_attn_long_cfg<1>(p, s);     // online softmax over key blocks
-    if (p.T == 256) return p.C == 256 ? launch_attn_cfg<2, 2>(p, s) : launch_attn_cfg<2, 1>(p, s);
-    return p.C == 256 ? launch_attn_cfg<1, 2>(p, s) : launch_attn_cfg<1, 1>(p, s);
+    if (p.kv_packed) {
+        if (p.T > 256) return p.C == 256 ? launch_attn_long_cfg<2, true>(p, s) : launch_attn_long_cfg<1, true>(p, s);
+        if (p.T == 256) return p.C == 256 ? launch_attn_cfg<2, 2, true>(p, s) : launch_attn_cfg<2, 1, true>(p, s);
+        return p.C == 256 ? launch_attn_cfg<1, 2, true>(p, s) : launch_attn_cfg<1, 1, true>(p, s);
+    }
+    if (p.T > 256) return p.C == 256 ? launch_attn_long_cfg<2, false>(p, s) : launch_attn_long_cfg<1, false>(p, s);     // online softmax over key blocks
+    if (p.T == 256) return p.C == 256 ? launch_attn_cfg<2, 2, false>(p, s) : launch_attn_cfg<2, 1, false>(p, s);
+    return p.C == 256 ? launch_attn_cfg<1, 2, false>(p, s) : launch_attn_cfg<1, 1, false>(p, s);
 }
 
 }  // namespace pf

@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvParams p) {
                         }
                         *reinterpret_cast<float4*>(p.out + pix * p.out_cstride + n4) = make_float4(d[0], d[1], d[2], d[3]);
                     } else {
-                        *reinterpret_cast<float4*>(p.out + pix * p.out_cstride + n4) = v;
+                        *reinterpret_cast<float4*>(p.out + pix * p.out_cstride + n4) = (p.pack_from_p1 != 0 && n4 >= p.pack_from_p1 - 1) ? pack_hilo4(v) : v;
                         s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;
                         s2[0] += v.x * v.x; s2[1] += v.y * v.y; s2[2] += v.z * v.z; s2[3] += v.w * v.w;
                     }

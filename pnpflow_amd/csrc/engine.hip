@@ -755,6 +755,8 @@ static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x, i
     // through HBM) is gone.  Exact algebra: the two forms differ by fp32 rounding.  The SelfAttention of the OT U-Net only (s_out = 1); the retained forward of
     // the VJP keeps the reference's structure (its backward walks it).
     const bool fold = fused && fold_env && s_out == 1.0f;
+    static const bool pack_env = !(getenv("PNPFLOW_HIP_ATTN_PACK") && atoi(getenv("PNPFLOW_HIP_ATTN_PACK")) == 0);      // test-only A/B switch
+    const bool kv_packed = fused && pack_env;
     if (fold) {
         key = pfx + "qkvf";
         if (!e->dev.count(key + ".w")) {
@@ -794,12 +796,14 @@ static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x, i
         p.gamma = upload(e, pfx + "norm.weight", W(e, pfx + "norm.weight").data);
         p.beta = upload(e, pfx + "norm.bias", W(e, pfx + "norm.bias").data);
         p.addvec = e->dev.at(key + ".b"); p.addvec_bs = 0;
+        // the fused core's keys and values leave this conv as packed fp16 (hi, lo) pairs: split once per element here instead of once per 32-query tile there
+        p.pack_from_p1 = kv_packed ? C + 1 : 0;
         push_conv(bd, p);
     }
     if (fold) {
         Tensor out = bd.make(C, H, Wd, true);
         Op op{}; op.kind = OP_ATTN;
-        op.ap.qkv = qkv.p; op.ap.out = out.p; op.ap.B = B; op.ap.T = HW; op.ap.C = C; op.ap.scale = 1.0f / sqrtf((float)C);
+        op.ap.qkv = qkv.p; op.ap.out = out.p; op.ap.B = B; op.ap.T = HW; op.ap.C = C; op.ap.scale = 1.0f / sqrtf((float)C); op.ap.kv_packed = kv_packed ? 1 : 0;
         op.ap.bias = upload(e, pfx + "proj_out.bias", W(e, pfx + "proj_out.bias").data); op.ap.residual = x.p;
         // the result's GroupNorm statistics: the core stores the fp32 partial sums of its 32-query tiles (plain stores), a micro-launch adds them per image
         // in tile order (deterministic; fp64 atomics from the tiles: +30 us per launch, a pass over the tensor itself: 14 us)
@@ -817,7 +821,7 @@ static Tensor attn_block(Builder& bd, const std::string& pfx, const Tensor& x, i
         // S = q k^T / sqrt(C), softmax, O = P v in one launch (attention.hip); the exact-fp32 mode and the retained
         // forward of the VJP (whose backward reads P) keep the three-launch path below
         Op op{}; op.kind = OP_ATTN;
-        op.ap.qkv = qkv.p; op.ap.out = o.p; op.ap.B = B; op.ap.T = HW; op.ap.C = C; op.ap.scale = 1.0f / sqrtf((float)C);
+        op.ap.qkv = qkv.p; op.ap.out = o.p; op.ap.B = B; op.ap.T = HW; op.ap.C = C; op.ap.scale = 1.0f / sqrtf((float)C); op.ap.kv_packed = kv_packed ? 1 : 0;
         op.flops = (size_t)4 * B * HW * HW * C;
         bd.plan->ops.push_back(op);
     } else {

@@ -96,7 +96,24 @@ struct ConvParams {
     int gnb_Ct, gnb_coff, gnb_silu;
     double* gnb_sum;             // [B][gnb_Ct][2] += (sum dyhat, sum dyhat*yhat)
     int xcd_map;          // split-fp16 kernel, set by its launcher: 1 = workgroup -> (tile, N-block) mapping that keeps neighbouring tiles and the N-blocks of a tile on one XCD
+    // round 6 (split-fp16 kernels): output channels >= pack_from_p1 - 1 (a multiple of 4; 0 = none) leave as PACKED fp16 pairs - per element the 32-bit word
+    // hi | lo << 16 with hi = RNE16(v), lo = RNE16(v - hi), the split the fused attention core applies to its keys and values - in place of the fp32 value: the
+    // stacked q,k,v conv packs its k and v channels, so the core's 32 query tiles per image unpack (two v_perm per pair) instead of each converting every key and value
+    int pack_from_p1;
 };
+
+// fp32 -> packed (hi | lo << 16) fp16 pair, the exact split of attention.hip's split4 (the value is made opaque first: see the note there)
+#if defined(__HIPCC__)
+__device__ __forceinline__ unsigned int pack_hilo(float v) {
+    asm volatile("" : "+v"(v));
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    return (unsigned int)__builtin_bit_cast(unsigned short, h) | ((unsigned int)__builtin_bit_cast(unsigned short, l) << 16);
+}
+__device__ __forceinline__ float4 pack_hilo4(float4 v) {
+    return make_float4(__uint_as_float(pack_hilo(v.x)), __uint_as_float(pack_hilo(v.y)), __uint_as_float(pack_hilo(v.z)), __uint_as_float(pack_hilo(v.w)));
+}
+#endif
 
 constexpr int CONV_KC = 16;   // channels per K-chunk staged in LDS
 
@@ -117,7 +134,8 @@ struct EdgeConvParams {
 // round 6 (engine.hip attn_block): with proj_out folded into the value projection (out = x + P (v Wp^T) + bp: exact algebra) the core's epilogue
 // adds `bias[c]` and `residual[b][t][c]`; both null = the plain core
 // `stats_part` [B][T / 32][C][2] (or null): fp32 (sum, sum of squares) of every 32-query tile of the result, for launch_partial_stats
-struct AttnParams { const float* qkv; float* out; int B, T, C; float scale; const float* bias; const float* residual; float* stats_part; };
+// `kv_packed`: the k and v channels of qkv hold packed fp16 pairs (ConvParams::pack_from_p1) instead of fp32 values
+struct AttnParams { const float* qkv; float* out; int B, T, C; float scale; const float* bias; const float* residual; float* stats_part; int kv_packed; };
 // GroupNorm statistics stats[b][C][2] of a tensor from per-tile partial sums part[B][nparts][C][2] (fp32), added in tile order in fp64 (plain stores): the
 // folded attention core's result (fp64 atomics from its 32-query tiles - 655 k per launch - cost 30 us of a 110 us kernel)
 hipError_t launch_partial_stats(const float* part, double* stats, int B, int nparts, int C, hipStream_t s);

@@ -1902,6 +1902,17 @@ def test_attention_output_projection_folded_into_the_value_projection(hip, tmp_p
             assert float((v[i:i + 1].cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
 
 
+def test_attention_keys_and_values_packed_by_the_qkv_conv(hip, tmp_path):
+    """Round 6: the stacked q,k,v conv of a fused attention block stores its k and v channels as packed fp16 (hi, lo) pairs (ConvParams::pack_from_p1) - the
+    split  hi = RNE16(v), lo = RNE16(v - hi)  the core applies to its keys and values, made once per element by the conv's epilogue instead of once per 32-query
+    tile by the core (32 tiles per image at 1 024 tokens: the long kernel was bound by its vector issue, 14 k VALU per wave).  The same arithmetic on the same
+    values: forwards with the test-only switch PNPFLOW_HIP_ATTN_PACK=0 are BIT-identical, on the 128^2 net (14 blocks, short kernel), a ragged batch, the 256^2 net
+    (key-blocked kernel), with and without the folded output projection, and in precision mode 2."""
+    _ab_forwards(tmp_path, (("celeba128", 160), ("celeba128", 37), ("afhq256", 40)), dict(PNPFLOW_HIP_ATTN_PACK="0"), dict(PNPFLOW_HIP_ATTN_PACK="1"), "attnpack", tol=0.0)
+    _ab_forwards(tmp_path, (("celeba128", 40),), dict(PNPFLOW_HIP_ATTN_PACK="0", PNPFLOW_HIP_ATTN_FOLD="0"), dict(PNPFLOW_HIP_ATTN_PACK="1", PNPFLOW_HIP_ATTN_FOLD="0"), "attnpack_nofold", tol=0.0)
+    _ab_forwards(tmp_path, (("celeba128", 40),), dict(PNPFLOW_HIP_ATTN_PACK="0"), dict(PNPFLOW_HIP_ATTN_PACK="1"), "attnpack_mode2", prec="2", tol=0.0)
+
+
 def _run_probe(name, args, env=None):
     import subprocess
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

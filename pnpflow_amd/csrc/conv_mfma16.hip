@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, conv16_lb(MT, WM, KC)) void conv_mfma16_kernel
             const int gy = oy0 * S - HALO + py, gx = ox0 * S - HALO + px;
             if (gy >= 0 && gy < Hv && gx >= 0 && gx < Wv && !(UP == 2 && ((gy | gx) & 1))) {
                 const int sy = UP ? (gy >> 1) : gy, sx = UP ? (gx >> 1) : gx;
-                a_pix[i] = (b * p.Hs + sy) * p.Ws + sx;
+                a_pix[i] = (b * p.Hs + sy) * (p.src_row_pitch > 0 ? p.src_row_pitch : p.Ws) + sx;
             }
         }
     }
@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256, conv16_lb(MT, WM, KC)) void conv_mfma16_kernel
             load_b(sg, ch, min(s + 2, nsteps - 1), nh_, nl_);
             __builtin_amdgcn_sched_barrier(0);
             const int tap = s / KS, j = s % KS;
-            const int ky = sg.taps == 9 ? tap / 3 : HALO, kx = sg.taps == 9 ? tap % 3 : HALO;
+            // (taps == 4: a 2 x 2 window at (oy, ox) inside the 3 x 3 neighbourhood - the phase forms of the upsampling conv's adjoint)
+            const int ky = sg.taps == 9 ? tap / 3 : (sg.taps == 4 ? (tap >> 1) + sg.oy : HALO), kx = sg.taps == 9 ? tap % 3 : (sg.taps == 4 ? (tap & 1) + sg.ox : HALO);
             f16x8 ah[MT], al[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {

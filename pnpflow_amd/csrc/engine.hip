@@ -1370,7 +1370,34 @@ static int build_backward(pf_engine* e, Plan* plan, Builder& bd) {
         GradEntry& gout = c.G(tr.out);
         if (!gout.has) { e->err = "internal: backward reached a tensor without gradient"; return PF_ERR_INVALID; }
         const int H = tr.out.H, Wd = tr.out.W;
-        if (tr.kind == TP_UP) {
+        static const bool upadj_env = !(getenv("PNPFLOW_HIP_UPPHASE_BWD") && atoi(getenv("PNPFLOW_HIP_UPPHASE_BWD")) == 0);      // test-only A/B switch
+        if (tr.kind == TP_UP && e->precision != 0 && upadj_env && tr.out.C % 16 == 0 && tr.in0.C % 4 == 0) {
+            // out = conv(nearest_up(x)) in its phase form (four 2 x 2 convs of x, see phase_weight): the adjoint is, per output phase (dy, dx), a 2 x 2 conv of the
+            // strided view g[2i + dy][2j + dx] of the gradient into dx - 16 multiply-adds per source pixel and channel pair instead of 36 + a sum-pool pass
+            // over the fine-resolution tensor.  Source (i, j) is read by phase (dy, dx) at output index i - ty - dy + 1: with u = 1 - ty the window covers rows
+            // i + u - dy = patch rows u + (1 - dy) of the 3 x 3 neighbourhood, and tap u carries the forward tap 1 - u.  Two launches of two K-segments each (the
+            // second accumulates); the views share the geometry: pixel pitch 2 C_out floats, row pitch two fine rows.
+            const int Cy = tr.out.C, Cx = tr.in0.C, Hs = tr.in0.H, Ws = tr.in0.W;
+            const std::string pk = phase_weight(e, tr.pfx + "weight");
+            const HostTensor& ph = W(e, pk);               // [(phase * Cy + co)][ci][ty * 2 + tx]   (the conv keeps the channel count: Cy == Cx)
+            GradEntry& gx = c.G(tr.in0);
+            for (int dy = 0; dy < 2; ++dy) {
+                ConvParams p = bwd_params(B, Hs, Ws, Hs, Ws, Cx);
+                p.src_row_pitch = 2 * Ws;
+                for (int dxp = 0; dxp < 2; ++dxp) {
+                    const std::string key = pk + "T" + std::to_string(dy) + std::to_string(dxp);
+                    if (!e->host.count(key)) {
+                        HostTensor tt; tt.shape = {Cx, Cy, 2, 2}; tt.data.resize((size_t)Cx * Cy * 4); tt.loaded = true;
+                        for (int ci = 0; ci < Cx; ++ci) for (int co = 0; co < Cy; ++co) for (int u = 0; u < 2; ++u) for (int v = 0; v < 2; ++v)
+                            tt.data[((size_t)ci * Cy + co) * 4 + u * 2 + v] = ph.data[(((size_t)(dy * 2 + dxp) * Cy + co) * Cx + ci) * 4 + (1 - u) * 2 + (1 - v)];
+                        e->host[key] = std::move(tt);
+                    }
+                    raw_seg(p, gout.t.p + ((size_t)dy * Wd + dxp) * Cy, Cy, 2 * Cy, 4, nullptr, packed_conv16(e, key, 0, Cy));
+                    p.seg[p.nseg - 1].oy = 1 - dy; p.seg[p.nseg - 1].ox = 1 - dxp;
+                }
+                c.conv_to(p, gx);
+            }
+        } else if (tr.kind == TP_UP) {
             // out = conv(nearest_up(x)): dU = adjoint conv at the fine resolution, dx = 2x2 sum-pool of dU
             Tensor dU = c.tmp(tr.in0.C, H, Wd);
             ConvParams p = bwd_params(B, H, Wd, H, Wd, tr.in0.C);

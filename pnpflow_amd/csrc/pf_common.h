@@ -52,6 +52,7 @@ struct ConvSeg {
     const void* w16;      // optional split-fp16 repack [chunk][tap][Cout][16 hi | 16 lo] (x256), see conv_mfma16.hip
     const void* w16h;     // optional hi-only repack [slice16][tap][Cout][16 hi] (x256) of the single-term mode's LDS-DMA kernel (conv_dma.hip)
     const void* a16;      // conv_dma.hip only: the pre-transformed fp16 operand of this segment (prep_split_kernel), or nullptr
+    int oy, ox;           // conv_mfma16.hip, taps == 4 only: the segment's 2 x 2 window covers patch rows oy + {0, 1}, columns ox + {0, 1} of the 3 x 3 neighbourhood
 };
 
 struct ConvParams {
@@ -100,6 +101,9 @@ struct ConvParams {
     // hi | lo << 16 with hi = RNE16(v), lo = RNE16(v - hi), the split the fused attention core applies to its keys and values - in place of the fp32 value: the
     // stacked q,k,v conv packs its k and v channels, so the core's 32 query tiles per image unpack (two v_perm per pair) instead of each converting every key and value
     int pack_from_p1;
+    // conv_mfma16.hip: source row pitch in pixels (of seg.cstride floats) when it is not Ws - a segment may then be a strided view of a larger tensor (every
+    // second row and column of the fine-resolution gradient: the phase form of the upsampling conv's adjoint, engine.hip); 0 = Ws
+    int src_row_pitch;
 };
 
 // fp32 -> packed (hi | lo << 16) fp16 pair, the exact split of attention.hip's split4 (the value is made opaque first: see the note there)

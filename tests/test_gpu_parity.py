@@ -1878,6 +1878,32 @@ def test_upsampling_conv_phase_form_is_fp32_equivalent(hip, tmp_path):
             assert float((v[i:i + 1].cpu() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-6
 
 
+def test_upsampling_conv_adjoint_in_its_phase_form(hip, tmp_path):
+    """Round 6: the input-gradient backward of Upsample (nearest x2 + 3x3 conv, models.py:41-47) in the phase form - per output phase (dy, dx) a 2 x 2 conv of the
+    strided view g[2i + dy][2j + dx] of the gradient, accumulated into dx (two launches of two K-segments with per-segment 2 x 2 windows; conv_mfma16's
+    taps = 4 / src_row_pitch) - instead of the 9-tap adjoint at the fine resolution + a 2 x 2 sum-pool.  The same linear map: J^T vec with the test-only switch
+    PNPFLOW_HIP_UPPHASE_BWD=0 agrees to the backward's fp32 rounding noise (3e-5 in relative L2, VJP_RTOL of max) on the 256^2 net at the OT-ODE batch and at a ragged one, and on the 128^2 net; the
+    reference-autograd goldens of test_unet_vjp_* run through this path."""
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dim, B in ((256, 32), (256, 5), (128, 32)):
+        outs = {}
+        for sw in ("0", "1"):
+            f = str(tmp_path / f"vjp_{dim}_{B}_{sw}.npz")
+            r = subprocess.run([sys.executable, "tools/gpu_vjp_only.py", str(dim), str(B), "1", f], cwd=repo, env=dict(os.environ, PNPFLOW_HIP_UPPHASE_BWD=sw),
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs[sw] = np.load(f)
+        assert np.array_equal(outs["0"]["v"], outs["1"]["v"])          # the forward is the same launches
+        # (a wrong tap or phase would be O(1).  Two correct backward walks of ~150 layers differ by accumulated fp32 rounding, amplified by the cancellations of
+        # the GroupNorm backward: measured 8.5e-6 in relative L2 at 256^2 - the same as between two forms of the OLD backward, PNPFLOW_HIP_GNB_FUSE=0 / 1: 9.8e-6,
+        # or with the forward on another conv kernel: 1.0e-5; the golden bound of the VJP itself is VJP_RTOL = 5e-5 of max)
+        ref = np.abs(outs["0"]["g"]).max()
+        d = outs["0"]["g"].astype(np.float64) - outs["1"]["g"].astype(np.float64)
+        rel = np.linalg.norm(d.ravel()) / np.linalg.norm(outs["0"]["g"].ravel().astype(np.float64))
+        assert np.isfinite(outs["1"]["g"]).all() and np.abs(d).max() <= VJP_RTOL * ref and rel <= 3e-5, (dim, B, np.abs(d).max(), ref, rel)
+
+
 def test_attention_output_projection_folded_into_the_value_projection(hip, tmp_path):
     """Round 6: SelfAttention.forward (models.py:145-162) ends in  x + proj_out(P v)  with nothing non-linear between the two products, so the engine
     merges proj_out into the value projection on the host (v' = GroupNorm(x) (Wp Wv)^T + Wp bv), the fused attention core adds proj_out's bias and x in its

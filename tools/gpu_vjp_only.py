@@ -17,3 +17,9 @@ for _ in range(n):
     m.vjp(x, t, vec)
 torch.cuda.synchronize()
 print(f"vjp dim={dim} B={B}: {(time.time() - t0) / n * 1e3:.2f} ms")
+if len(sys.argv) > 4:      # save (v, J^T vec) of a seeded input for A/B comparisons across environment switches (tests/test_gpu_parity.py)
+    import numpy as np
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, 3, dim, dim, generator=g).cuda(); t = torch.linspace(0.05, 0.95, B).cuda(); vec = torch.randn(B, 3, dim, dim, generator=g).cuda()
+    v, jt = m.vjp(x, t, vec)
+    np.savez(sys.argv[4], v=v.float().cpu().numpy(), g=jt.float().cpu().numpy())

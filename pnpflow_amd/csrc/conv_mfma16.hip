@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256, conv16_lb(MT, WM, KC)) void conv_mfma16_kernel
                     for (int i = 0; i < 4; ++i) {
                         const int px = (lane >> 3) + 8 * i;
                         const int oy = min(oy0 + (wm * MT + mt + g) * 2 + (px >> 4), p.H - 1), ox = min(ox0 + (px & 15), p.W - 1);
-                        const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
+                        const size_t pix = ((size_t)b * p.H + oy) * (p.dst_row_pitch > 0 ? p.dst_row_pitch : p.W) + ox;
                         rv[g][i] = *reinterpret_cast<const float4*>(p.residual + pix * p.res_cstride + min(n4, p.Cout - 4));
                     }
             }
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, conv16_lb(MT, WM, KC)) void conv_mfma16_kernel
                 const int oy = oy0 + (wm * MT + mt) * 2 + (px >> 4), ox = ox0 + (px & 15);
                 float4 v = *reinterpret_cast<const float4*>(s_tr + px * TP + cq * 4);
                 if (nok4 && oy < p.H && ox < p.W) {
-                    const size_t pix = ((size_t)b * p.H + oy) * p.W + ox;
+                    const size_t pix = ((size_t)b * p.H + oy) * (p.dst_row_pitch > 0 ? p.dst_row_pitch : p.W) + ox;
                     if (p.residual != nullptr) {
                         const float rsc = p.res_scale;
                         v.x = fmaf(rv[mt % RG][i].x, rsc, v.x); v.y = fmaf(rv[mt % RG][i].y, rsc, v.y); v.z = fmaf(rv[mt % RG][i].z, rsc, v.z); v.w = fmaf(rv[mt % RG][i].w, rsc, v.w);

@@ -1407,6 +1407,36 @@ static int build_backward(pf_engine* e, Plan* plan, Builder& bd) {
             Op op{}; op.kind = OP_SUMPOOL; op.P[0] = dU.p; op.O = gx.t.p; op.I[0] = tr.in0.H; op.I[1] = tr.in0.W; op.I[2] = tr.in0.C; op.I[3] = gx.has ? 1 : 0;
             gx.has = true; c.push(op);
             bd.recycle(dU.p);
+        } else if (tr.kind == TP_DOWN && e->precision != 0 && upadj_env && tr.out.C % 16 == 0 && tr.in0.C % 4 == 0) {
+            // out = conv_stride2(x) (Downsample, models.py:50-56): fine pixel (2a + py, 2b + px) is read by tap ky of output row i only when 2i + ky - 1 = 2a + py,
+            // i.e. py = 0: (ky, i) = (1, a); py = 1: (0, a + 1) and (2, a) - columns alike.  Per fine phase the adjoint is therefore a conv of the COARSE gradient
+            // with 1 / 2 / 2 / 4 taps inside the window rows {a, a + 1} x columns {b, b + 1}, written to every second row and column of dx: 13 multiply-adds per
+            // coarse pixel and channel pair (phase (0, 0) as a 1x1 conv, the others as 2 x 2 windows with their unused taps zero) instead of the 36 of a 9-tap
+            // conv over the zero-inserted gradient at the fine resolution, three quarters of whose operands are the inserted zeros.
+            const int Cy = tr.out.C, Cx = tr.in0.C, Hc = tr.out.H, Wc = tr.out.W;
+            const HostTensor& w = W(e, tr.pfx + "weight");       // [Cy][Cx][3][3]
+            GradEntry& gx = c.G(tr.in0);
+            static const int KOF[2][2] = {{1, -1}, {2, 0}};       // [phase][window index u] -> 3x3 tap index, -1: none
+            for (int py = 0; py < 2; ++py) for (int px = 0; px < 2; ++px) {
+                const bool one = py == 0 && px == 0;
+                const std::string key = tr.pfx + "weight#dT" + std::to_string(py) + std::to_string(px);
+                if (!e->host.count(key)) {
+                    const int kk = one ? 1 : 4;
+                    HostTensor tt; tt.shape = {Cx, Cy, one ? 1 : 2, one ? 1 : 2}; tt.data.assign((size_t)Cx * Cy * kk, 0.f); tt.loaded = true;
+                    for (int ci = 0; ci < Cx; ++ci) for (int co = 0; co < Cy; ++co) for (int u = 0; u < (one ? 1 : 2); ++u) for (int v = 0; v < (one ? 1 : 2); ++v) {
+                        const int ky = KOF[py][u], kx = KOF[px][v];
+                        if (ky >= 0 && kx >= 0) tt.data[((size_t)ci * Cy + co) * kk + u * 2 * (one ? 0 : 1) + v] = w.data[((size_t)co * Cx + ci) * 9 + ky * 3 + kx];
+                    }
+                    e->host[key] = std::move(tt);
+                }
+                ConvParams p = bwd_params(B, Hc, Wc, Hc, Wc, Cx);
+                raw_seg(p, gout.t.p, Cy, Cy, one ? 1 : 4, nullptr, packed_conv16(e, key, 0, Cy));
+                p.seg[0].oy = 1; p.seg[0].ox = 1;
+                p.out = gx.t.p + ((size_t)py * tr.in0.W + px) * Cx; p.out_cstride = 2 * Cx; p.dst_row_pitch = 2 * Wc;
+                if (gx.has) { p.residual = p.out; p.res_cstride = 2 * Cx; }
+                c.conv_plain(p);
+            }
+            gx.has = true;
         } else if (tr.kind == TP_DOWN) {
             // out = conv_stride2(x): dx = adjoint conv of the zero-inserted gradient
             ConvParams p = bwd_params(B, tr.in0.H, tr.in0.W, H, Wd, tr.in0.C);

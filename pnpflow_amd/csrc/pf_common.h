@@ -104,6 +104,9 @@ struct ConvParams {
     // conv_mfma16.hip: source row pitch in pixels (of seg.cstride floats) when it is not Ws - a segment may then be a strided view of a larger tensor (every
     // second row and column of the fine-resolution gradient: the phase form of the upsampling conv's adjoint, engine.hip); 0 = Ws
     int src_row_pitch;
+    // ... and the same for the result (and the residual it accumulates onto): row pitch in pixels of out_cstride floats; 0 = W.  With out = base + (py W + px) C,
+    // out_cstride = 2 C, dst_row_pitch = 2 W' the launch writes output phase (py, px) of a tensor twice as large (the stride-2 conv's adjoint, engine.hip)
+    int dst_row_pitch;
 };
 
 // fp32 -> packed (hi | lo << 16) fp16 pair, the exact split of attention.hip's split4 (the value is made opaque first: see the note there)

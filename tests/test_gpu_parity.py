@@ -1881,7 +1881,9 @@ def test_upsampling_conv_phase_form_is_fp32_equivalent(hip, tmp_path):
 def test_upsampling_conv_adjoint_in_its_phase_form(hip, tmp_path):
     """Round 6: the input-gradient backward of Upsample (nearest x2 + 3x3 conv, models.py:41-47) in the phase form - per output phase (dy, dx) a 2 x 2 conv of the
     strided view g[2i + dy][2j + dx] of the gradient, accumulated into dx (two launches of two K-segments with per-segment 2 x 2 windows; conv_mfma16's
-    taps = 4 / src_row_pitch) - instead of the 9-tap adjoint at the fine resolution + a 2 x 2 sum-pool.  The same linear map: J^T vec with the test-only switch
+    taps = 4 / src_row_pitch) - instead of the 9-tap adjoint at the fine resolution + a 2 x 2 sum-pool; and the backward of Downsample (3x3 conv, stride 2) per
+    fine-resolution phase as a conv of the coarse gradient with 1 / 2 / 2 / 4 taps written to every second row and column of dx (dst_row_pitch) instead of a 9-tap
+    conv over the zero-inserted gradient.  The same linear maps: J^T vec with the test-only switch
     PNPFLOW_HIP_UPPHASE_BWD=0 agrees to the backward's fp32 rounding noise (3e-5 in relative L2, VJP_RTOL of max) on the 256^2 net at the OT-ODE batch and at a ragged one, and on the 128^2 net; the
     reference-autograd goldens of test_unet_vjp_* run through this path."""
     import subprocess, sys

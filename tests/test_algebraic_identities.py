@@ -59,3 +59,51 @@ def test_proj_out_folds_into_the_value_projection(shape):
     v2 = (wp @ wv) @ h + (wp @ bv)[:, None]
     out = x + torch.bmm(v2, attn.permute(0, 2, 1)) + bp[:, None]      # the rows of attn sum to 1, so Wp bv passes through the average unchanged
     assert float((out - ref).abs().max()) <= 1e-12 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 4, 6, 6), (1, 3, 3, 5, 8)])
+def test_adjoint_of_upsample_conv_is_four_phase_convs_of_the_strided_gradient(shape):
+    """engine.hip build_backward, TP_UP: dx[i, j] = sum over phases (dy, dx) of a 2x2 conv of g[2i + dy][2j + dx] with the transposed phase weights, window rows
+    u + (1 - dy) of the 3x3 neighbourhood, tap u carrying the forward tap 1 - u.  Reference: autograd through interpolate + conv2d."""
+    B, Ci, Co, H, W = shape
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn(B, Ci, H, W, generator=gen, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Co, Ci, 3, 3, generator=gen, dtype=torch.float64)
+    g = torch.randn(B, Co, 2 * H, 2 * W, generator=gen, dtype=torch.float64)
+    F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, None, padding=1).backward(g)
+    ref = x.grad
+    out = torch.zeros_like(ref)
+    for (dy, dx), pw in phase_weights(w).items():
+        gp = F.pad(g[:, :, dy::2, dx::2], (1, 1, 1, 1))                       # the strided view, zero outside
+        v = pw.flip(2, 3).transpose(0, 1)                                     # [Ci][Co][u][v] = pw[co][ci][1 - u][1 - v]
+        oy, ox = 1 - dy, 1 - dx
+        out += F.conv2d(gp[:, :, oy:oy + H + 1, ox:ox + W + 1], v)
+    assert float((out - ref).abs().max()) <= 1e-12 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 4, 8, 8), (1, 3, 5, 6, 10)])
+def test_adjoint_of_stride2_conv_per_fine_phase(shape):
+    """engine.hip build_backward, TP_DOWN: fine pixel (2a + py, 2b + px) receives tap ky of output row i only when 2i + ky - 1 = 2a + py - py = 0: (ky, i) = (1, a);
+    py = 1: (0, a + 1), (2, a) - so each fine phase of dx is a conv of the coarse gradient with 1 / 2 / 2 / 4 taps inside rows {a, a + 1} x columns {b, b + 1}."""
+    B, Ci, Co, H, W = shape                     # H, W: the fine (input) size, even
+    gen = torch.Generator().manual_seed(14)
+    x = torch.randn(B, Ci, H, W, generator=gen, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Co, Ci, 3, 3, generator=gen, dtype=torch.float64)
+    g = torch.randn(B, Co, H // 2, W // 2, generator=gen, dtype=torch.float64)
+    F.conv2d(x, w, None, stride=2, padding=1).backward(g)
+    ref = x.grad
+    KOF = {(0, 0): 1, (0, 1): None, (1, 0): 2, (1, 1): 0}
+    out = torch.zeros_like(ref)
+    gp = F.pad(g, (0, 1, 0, 1))                                               # rows a, a + 1 / columns b, b + 1: one zero row / column past the end
+    taps = 0
+    for py in range(2):
+        for px in range(2):
+            v = torch.zeros(Ci, Co, 2, 2, dtype=torch.float64)
+            for u in range(2):
+                for t in range(2):
+                    ky, kx = KOF[(py, u)], KOF[(px, t)]
+                    if ky is not None and kx is not None:
+                        v[:, :, u, t] = w[:, :, ky, kx].transpose(0, 1); taps += 1
+            out[:, :, py::2, px::2] = F.conv2d(gp, v)
+    assert taps == 9
+    assert float((out - ref).abs().max()) <= 1e-12 * float(ref.abs().max())

@@ -83,7 +83,7 @@ def test_adjoint_of_upsample_conv_is_four_phase_convs_of_the_strided_gradient(sh
 
 @pytest.mark.parametrize("shape", [(2, 4, 4, 8, 8), (1, 3, 5, 6, 10)])
 def test_adjoint_of_stride2_conv_per_fine_phase(shape):
-    """engine.hip build_backward, TP_DOWN: fine pixel (2a + py, 2b + px) receives tap ky of output row i only when 2i + ky - 1 = 2a + py - py = 0: (ky, i) = (1, a);
+    """engine.hip build_backward, TP_DOWN: fine pixel (2a + py, 2b + px) receives tap ky of output row i only when 2i + ky - 1 = 2a + py, i.e. py = 0: (ky, i) = (1, a);
     py = 1: (0, a + 1), (2, a) - so each fine phase of dx is a conv of the coarse gradient with 1 / 2 / 2 / 4 taps inside rows {a, a + 1} x columns {b, b + 1}."""
     B, Ci, Co, H, W = shape                     # H, W: the fine (input) size, even
     gen = torch.Generator().manual_seed(14)
